@@ -1,0 +1,164 @@
+/*
+ * inr_abi.h -- C-ABI of libinr_mi355x.so, the MI355X (gfx950) engine for the coordinate-MLP
+ * fitting hot path of luisdavid64/MRI-Implicit-Neural-Representations.
+ *
+ * The reference has no FFI: the path sits behind torch.nn.Module + torch.optim.
+ * Each entry point below names the reference code it replaces (paths under /root/reference/src).
+ * Conventions:
+ *   - every function returns 0 on success, <0 on error; inr_last_error() gives the message
+ *     (thread-local); nothing throws or aborts across the ABI;
+ *   - all tensor arguments are DEVICE pointers to contiguous row-major fp32 buffers owned by the
+ *     caller; the library never allocates device memory and retains no pointer across calls;
+ *   - all work is enqueued on the hipStream_t passed as `stream` (void*); no implicit sync;
+ *   - a plan is immutable after creation and may be shared between threads and streams as long as
+ *     each in-flight call has its own workspace buffers.
+ *
+ * Parameter layout ("flat params", P floats): layer k's weight [M_k, K_k] (PyTorch [out,in]
+ * layout) followed by its bias [M_k], k = 0..D-1 -- i.e. the reference's state_dict order
+ * (SIREN: model.{k}.linear.weight/bias, networks.py:79,114-117; FFN: model.{2k}.weight/bias,
+ * networks.py:57-62).  Gradients and Adam moments use the same layout.
+ */
+#ifndef INR_ABI_H
+#define INR_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define INR_ABI_VERSION 1
+
+/* error codes */
+#define INR_OK 0
+#define INR_ERR_INVALID (-1)     /* bad argument (null pointer, B <= 0, unsupported shape) */
+#define INR_ERR_UNSUPPORTED (-2) /* valid request the engine has no kernel for */
+#define INR_ERR_HIP (-3)         /* a HIP runtime call failed */
+
+/* network family: which reference class the plan mirrors */
+enum inr_kind {
+  INR_KIND_SIREN = 0, /* models/networks.py:99-124  SIREN / SirenLayer :74-96 */
+  INR_KIND_FFN = 1    /* models/networks.py:48-69   FFN (ReLU hidden, Sigmoid output) */
+};
+
+/* activation of the last layer */
+enum inr_act {
+  INR_ACT_ID = 0,      /* network_last_linear: True (default), networks.py:96 */
+  INR_ACT_SIN = 1,     /* sin(w0 z): hidden SIREN layers; last layer if network_last_linear False */
+  INR_ACT_TANH = 2,    /* last_tanh: True, networks.py:94-95 */
+  INR_ACT_RELU = 3,    /* FFN hidden, networks.py:57-60 */
+  INR_ACT_SIGMOID = 4  /* FFN output, networks.py:63 */
+};
+
+/* how the first layer's input is produced */
+enum inr_input {
+  INR_INPUT_X = 0,     /* x [B, in_features] already in memory (what model.forward receives,
+                          train.py:163-169: coords = encoder.embedding(coords); model(coords)) */
+  INR_INPUT_GAUSS = 1  /* fused Positional_Encoder 'gauss' (networks.py:30-33): coords [B,3] and
+                          enc_B [E,3]; in_features must equal 2E; [B,2E] is never materialised */
+};
+
+/* pointwise losses the fused train step can evaluate in-kernel (others: inr_loss_grad + tier 1) */
+enum inr_loss {
+  INR_LOSS_L2_HALF = 0, /* 0.5 * torch.nn.MSELoss()   train.py:82,182 */
+  INR_LOSS_L1_HALF = 1, /* 0.5 * torch.nn.L1Loss()    train.py:92,182 */
+  INR_LOSS_TANH = 2,    /* TanhL2Loss                 metrics/losses.py:130-139 */
+  INR_LOSS_LOGSPACE = 3,/* LogSpaceLoss               metrics/losses.py:214-223 */
+  INR_LOSS_HDR = 4      /* HDRLoss_FF (separable form) metrics/losses.py:236-264 */
+};
+
+typedef struct inr_net_desc {
+  int32_t kind;         /* enum inr_kind */
+  int32_t in_features;  /* net.network_input_size */
+  int32_t width;        /* net.network_width (hidden), multiple of 32, <= 256 */
+  int32_t depth;        /* net.network_depth = number of Linear layers (>= 2) */
+  int32_t out_features; /* net.network_output_size, <= 32 */
+  int32_t last_act;     /* enum inr_act */
+  int32_t input;        /* enum inr_input */
+  int32_t enc_size;     /* E (encoder.embedding_size) when input == INR_INPUT_GAUSS */
+  float w0;             /* 30 for SIREN (networks.py:75); ignored for FFN */
+  int32_t reserved[7];
+} inr_net_desc;
+
+typedef struct inr_loss_desc {
+  int32_t kind;       /* enum inr_loss */
+  float eps;          /* loss_opts.hdr_eps */
+  float sigma;        /* loss_opts.hdr_ff_sigma */
+  float factor;       /* loss_opts.hdr_ff_factor */
+  float inv_count;    /* 1 / (number of rows entering the mean, summed over all ranks) */
+  float hdr_A;        /* mean_i((1-f_i)^2) over the batch's kcoords (HDR only) */
+  int32_t reserved[2];
+} inr_loss_desc;
+
+typedef struct inr_plan inr_plan;
+
+/* sizes (in bytes unless stated) a caller needs to allocate buffers for a plan */
+typedef struct inr_sizes {
+  int64_t n_params;        /* P: floats in flat params / grads / Adam moments */
+  int64_t packed_floats;   /* floats in the MFMA-fragment-ordered weight image */
+  int64_t tile_rows;       /* coordinates per workgroup tile (128) */
+  int64_t save_bytes_per_tile; /* activation stash per tile (tier 1: n_tiles of them) */
+  int64_t max_blocks;      /* upper bound on the persistent grid (slab count) */
+  int64_t slab_floats;     /* floats per gradient slab (= P + 4 loss words, padded) */
+} inr_sizes;
+
+int inr_abi_version(void);
+/* copies the calling thread's last error message; returns its length */
+int inr_last_error(char* buf, size_t cap);
+
+/* Replaces: SIREN.__init__ / FFN.__init__ shape bookkeeping (networks.py:100-119, 49-65). */
+int inr_plan_create(const inr_net_desc* desc, inr_plan** out);
+int inr_plan_destroy(inr_plan* plan);
+int inr_plan_sizes(const inr_plan* plan, inr_sizes* out);
+/* number of tiles / persistent blocks / workspace bytes for a batch of B rows */
+int inr_plan_launch_dims(const inr_plan* plan, int64_t B, int64_t* n_tiles, int64_t* n_blocks);
+
+/* Re-orders flat params into the MFMA A-fragment image the kernels stream (no reference
+ * counterpart: it is what `model.to(device)` + ATen's GEMM packing do implicitly). */
+int inr_pack_params(const inr_plan* plan, const float* params, float* packed, void* stream);
+
+/* Replaces Positional_Encoder.embedding, 'gauss' (networks.py:30-33): out [B, 2E]. */
+int inr_encode_gauss(const float* coords, const float* enc_B, int64_t B, int32_t E, float* out,
+                     void* stream);
+
+/* Replaces model.forward (networks.py:121-124 / 67-69).  `x` is [B,in_features] (INR_INPUT_X) or
+ * coords [B,3] (INR_INPUT_GAUSS, with enc_B [E,3]).  out [B,out_features].  `save` (may be NULL
+ * for a no_grad forward, train.py:203-220) receives n_tiles * save_bytes_per_tile bytes. */
+int inr_forward(const inr_plan* plan, const float* params, const float* packed, const float* x,
+                const float* enc_B, int64_t B, float* out, float* save, void* stream);
+
+/* Replaces loss.backward() through the model (train.py:189): given d(loss)/d(out) [B,out_features]
+ * and the forward's `save`, writes d(loss)/d(params) into grads [P].  `slabs` is workspace of
+ * n_blocks * slab_floats floats. */
+int inr_backward(const inr_plan* plan, const float* params, const float* packed, const float* x,
+                 const float* enc_B, int64_t B, const float* dout, const float* save, float* slabs,
+                 float* grads, void* stream);
+
+/* Replaces the loss modules + their autograd (train.py:178-182; metrics/losses.py): writes
+ * dout [B,2] = d(loss)/d(out) and accumulates the scalar loss into loss_out[0] (device).
+ * `mask` (may be NULL) is one byte per row: rows with 0 do not enter the loss (train.py:172-177).
+ * `kcoords` [B,3] is only read for INR_LOSS_HDR. */
+int inr_loss_grad(const inr_loss_desc* loss, const float* out, const float* gt, const float* kcoords,
+                  const uint8_t* mask, int64_t B, float* loss_out, float* dout, void* stream);
+
+/* Fused tier-2 step, stages 1-3 of train.py:163-189 in one launch: encode -> forward -> pointwise
+ * loss -> backward, then the fixed-order slab reduction.  Leaves grads [P] and loss_out[0];
+ * the caller all-reduces grads across ranks (if any) and calls inr_adam_step. */
+int inr_train_step(const inr_plan* plan, const inr_loss_desc* loss, const float* params,
+                   const float* packed, const float* x, const float* enc_B, const float* gt,
+                   const uint8_t* mask, int64_t B, float* save, float* slabs, float* grads,
+                   float* loss_out, void* stream);
+
+/* Replaces torch.optim.Adam.step (train.py:76,190; eps 1e-8, amsgrad False, L2-style
+ * weight_decay) plus the L1/L2 "regularization" gradient terms (models/regularization.py:21-36),
+ * and refreshes `packed` for the next forward.  `step` counts from 1.  Hyper-parameters are
+ * doubles because torch derives step_size = lr / (1 - beta1^t) etc. in Python doubles. */
+int inr_adam_step(const inr_plan* plan, float* params, const float* grads, float* exp_avg,
+                  float* exp_avg_sq, float* packed, double lr, double beta1, double beta2, double eps,
+                  double weight_decay, double l1, double l2, int32_t step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* INR_ABI_H */

@@ -1,0 +1,323 @@
+// inr_api.hip -- the C-ABI of libinr_mi355x.so (see include/inr_abi.h).  Plain pointers and
+// sizes only; validates arguments up front; never allocates device memory; never syncs.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "../../include/inr_abi.h"
+#include "inr_aux.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int hip_fail(hipError_t e, const char* what) {
+  return fail(INR_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+constexpr int kMaxBlocks = 256;  // one persistent workgroup per CU (MI355X: 256 CUs)
+
+}  // namespace
+
+struct inr_plan {
+  inr_net_desc desc;
+  NetDesc nd;
+  int64_t packed_floats;
+};
+
+extern "C" {
+
+int inr_abi_version(void) { return INR_ABI_VERSION; }
+
+int inr_last_error(char* buf, size_t cap) {
+  const size_t n = strlen(g_err);
+  if (buf != nullptr && cap > 0) {
+    const size_t c = n < cap - 1 ? n : cap - 1;
+    memcpy(buf, g_err, c);
+    buf[c] = 0;
+  }
+  return (int)n;
+}
+
+int inr_plan_create(const inr_net_desc* d, inr_plan** out) {
+  if (d == nullptr || out == nullptr) return fail(INR_ERR_INVALID, "inr_plan_create: null argument");
+  *out = nullptr;
+  if (d->kind != INR_KIND_SIREN && d->kind != INR_KIND_FFN)
+    return fail(INR_ERR_UNSUPPORTED, "inr_plan_create: kind %d has no kernel yet", d->kind);
+  if (d->depth < 2 || d->depth > INR_MAX_LAYERS)
+    return fail(INR_ERR_INVALID, "inr_plan_create: depth %d outside [2,%d]", d->depth, INR_MAX_LAYERS);
+  if (d->width != 32 && d->width != 256)
+    return fail(INR_ERR_UNSUPPORTED, "inr_plan_create: width %d (kernels are built for 32 and 256)", d->width);
+  if (d->out_features < 1 || d->out_features > 4)
+    return fail(INR_ERR_UNSUPPORTED, "inr_plan_create: out_features %d outside [1,4]", d->out_features);
+  if (d->in_features < 1) return fail(INR_ERR_INVALID, "inr_plan_create: in_features %d", d->in_features);
+  if (d->input == INR_INPUT_GAUSS) {
+    if (d->enc_size < 4 || (d->enc_size % 4) != 0)
+      return fail(INR_ERR_UNSUPPORTED, "inr_plan_create: enc_size %d must be a positive multiple of 4", d->enc_size);
+    if (d->in_features != 2 * d->enc_size)
+      return fail(INR_ERR_INVALID, "inr_plan_create: in_features %d != 2*enc_size %d", d->in_features,
+                  2 * d->enc_size);
+  } else if (d->input != INR_INPUT_X) {
+    return fail(INR_ERR_INVALID, "inr_plan_create: input mode %d", d->input);
+  }
+  if (d->last_act < INR_ACT_ID || d->last_act > INR_ACT_SIGMOID)
+    return fail(INR_ERR_INVALID, "inr_plan_create: last_act %d", d->last_act);
+
+  inr_plan* p = new (std::nothrow) inr_plan();
+  if (p == nullptr) return fail(INR_ERR_INVALID, "inr_plan_create: out of host memory");
+  p->desc = *d;
+  NetDesc& nd = p->nd;
+  memset(&nd, 0, sizeof(nd));
+  nd.D = d->depth;
+  nd.NB = d->width / 32;
+  nd.hact = d->kind == INR_KIND_SIREN ? ACT_SIN : ACT_RELU;
+  nd.last_act = d->last_act;
+  nd.input = d->input;
+  nd.E = d->enc_size;
+  nd.out_f = d->out_features;
+  nd.w0 = d->w0;
+  int poff = 0;
+  int64_t pk = 0;
+  for (int l = 0; l < nd.D; ++l) {
+    LayerDesc& L = nd.L[l];
+    L.K = l == 0 ? d->in_features : d->width;
+    L.M = l == nd.D - 1 ? d->out_features : d->width;
+    L.Kpad8 = round_up(L.K, 8);
+    L.Kblk = (L.K + 31) / 32;
+    L.Mblk = (L.M + 31) / 32;
+    L.Mpad8 = round_up(L.M, 8);
+    L.w_off = poff;
+    poff += L.M * L.K;
+    L.b_off = poff;
+    poff += L.M;
+    L.pf_off = (int)pk;
+    pk += (int64_t)L.Kpad8 * L.Mblk * 32;  // (Kpad8/8 groups) x Mblk x 64 lanes x 4
+    if (l >= 1) {
+      L.pb_off = (int)pk;
+      pk += (int64_t)L.Mpad8 * L.Kblk * 32;
+    } else {
+      L.pb_off = 0;
+    }
+  }
+  nd.P = poff;
+  nd.slab_floats = round_up(poff + 4, 64);
+  nd.save_floats_per_tile = 2 * (nd.D - 1) * nd.NB * 32 * INR_TILE + 4 * INR_TILE;
+  p->packed_floats = pk;
+  *out = p;
+  return INR_OK;
+}
+
+int inr_plan_destroy(inr_plan* plan) {
+  delete plan;
+  return INR_OK;
+}
+
+int inr_plan_sizes(const inr_plan* plan, inr_sizes* out) {
+  if (plan == nullptr || out == nullptr) return fail(INR_ERR_INVALID, "inr_plan_sizes: null argument");
+  out->n_params = plan->nd.P;
+  out->packed_floats = plan->packed_floats;
+  out->tile_rows = INR_TILE;
+  out->save_bytes_per_tile = (int64_t)plan->nd.save_floats_per_tile * 4;
+  out->max_blocks = kMaxBlocks;
+  out->slab_floats = plan->nd.slab_floats;
+  return INR_OK;
+}
+
+int inr_plan_launch_dims(const inr_plan* plan, int64_t B, int64_t* n_tiles, int64_t* n_blocks) {
+  if (plan == nullptr || n_tiles == nullptr || n_blocks == nullptr)
+    return fail(INR_ERR_INVALID, "inr_plan_launch_dims: null argument");
+  if (B <= 0) return fail(INR_ERR_INVALID, "inr_plan_launch_dims: B = %lld", (long long)B);
+  *n_tiles = (B + INR_TILE - 1) / INR_TILE;
+  *n_blocks = *n_tiles < kMaxBlocks ? *n_tiles : kMaxBlocks;
+  return INR_OK;
+}
+
+static int launch(const inr_plan* plan, const LossDesc& ld, const inr::MlpArgs& a, int mode, int grid,
+                  hipStream_t st) {
+  hipError_t e;
+  if (plan->nd.NB == 1)
+    e = inr::launch_mlp_nb1(plan->nd, ld, a, mode, grid, st);
+  else
+    e = inr::launch_mlp_nb8(plan->nd, ld, a, mode, grid, st);
+  if (e != hipSuccess) return hip_fail(e, "inr mlp kernel launch");
+  return INR_OK;
+}
+
+int inr_pack_params(const inr_plan* plan, const float* params, float* packed, void* stream) {
+  if (plan == nullptr || params == nullptr || packed == nullptr)
+    return fail(INR_ERR_INVALID, "inr_pack_params: null argument");
+  inr::AdamArgs aa;
+  memset(&aa, 0, sizeof(aa));
+  aa.do_update = 0;
+  hipError_t e = inr::launch_adam_pack(plan->nd, const_cast<float*>(params), nullptr, nullptr, nullptr, packed, aa,
+                                       (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "inr_pack_params");
+  return INR_OK;
+}
+
+int inr_encode_gauss(const float* coords, const float* enc_B, int64_t B, int32_t E, float* out, void* stream) {
+  if (coords == nullptr || enc_B == nullptr || out == nullptr)
+    return fail(INR_ERR_INVALID, "inr_encode_gauss: null argument");
+  if (B <= 0 || E <= 0) return fail(INR_ERR_INVALID, "inr_encode_gauss: B = %lld, E = %d", (long long)B, E);
+  hipError_t e = inr::launch_encode_gauss(coords, enc_B, B, E, out, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "inr_encode_gauss");
+  return INR_OK;
+}
+
+int inr_forward(const inr_plan* plan, const float* params, const float* packed, const float* x,
+                const float* enc_B, int64_t B, float* out, float* save, void* stream) {
+  if (plan == nullptr || params == nullptr || packed == nullptr || x == nullptr || out == nullptr)
+    return fail(INR_ERR_INVALID, "inr_forward: null argument");
+  if (plan->nd.input == IN_GAUSS && enc_B == nullptr) return fail(INR_ERR_INVALID, "inr_forward: enc_B is null");
+  if (B <= 0) return fail(INR_ERR_INVALID, "inr_forward: B = %lld", (long long)B);
+  int64_t nt, nb;
+  inr_plan_launch_dims(plan, B, &nt, &nb);
+  inr::MlpArgs a;
+  memset(&a, 0, sizeof(a));
+  a.params = params;
+  a.packed = packed;
+  a.x = x;
+  a.encB = enc_B;
+  a.out = out;
+  a.save = save;
+  a.B = B;
+  a.n_tiles = (int)nt;
+  a.save_by_block = 0;
+  LossDesc ld;
+  memset(&ld, 0, sizeof(ld));
+  return launch(plan, ld, a, 0, (int)nb, (hipStream_t)stream);
+}
+
+int inr_backward(const inr_plan* plan, const float* params, const float* packed, const float* x,
+                 const float* enc_B, int64_t B, const float* dout, const float* save, float* slabs,
+                 float* grads, void* stream) {
+  if (plan == nullptr || params == nullptr || packed == nullptr || x == nullptr || dout == nullptr ||
+      save == nullptr || slabs == nullptr || grads == nullptr)
+    return fail(INR_ERR_INVALID, "inr_backward: null argument");
+  if (plan->nd.input == IN_GAUSS && enc_B == nullptr) return fail(INR_ERR_INVALID, "inr_backward: enc_B is null");
+  if (B <= 0) return fail(INR_ERR_INVALID, "inr_backward: B = %lld", (long long)B);
+  int64_t nt, nb;
+  inr_plan_launch_dims(plan, B, &nt, &nb);
+  inr::MlpArgs a;
+  memset(&a, 0, sizeof(a));
+  a.params = params;
+  a.packed = packed;
+  a.x = x;
+  a.encB = enc_B;
+  a.dout = dout;
+  a.save = const_cast<float*>(save);
+  a.slabs = slabs;
+  a.B = B;
+  a.n_tiles = (int)nt;
+  a.save_by_block = 0;
+  LossDesc ld;
+  memset(&ld, 0, sizeof(ld));
+  int rc = launch(plan, ld, a, 1, (int)nb, (hipStream_t)stream);
+  if (rc != INR_OK) return rc;
+  hipError_t e = inr::launch_reduce_slabs(slabs, (int)nb, plan->nd.slab_floats, plan->nd.P, grads, nullptr,
+                                          (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "inr_backward: slab reduction");
+  return INR_OK;
+}
+
+static void to_loss_desc(const inr_loss_desc* l, LossDesc* o) {
+  o->kind = l->kind;
+  o->eps = l->eps;
+  o->sigma = l->sigma;
+  o->factor = l->factor;
+  o->inv_count = l->inv_count;
+  o->hdr_A = l->hdr_A;
+}
+
+int inr_loss_grad(const inr_loss_desc* loss, const float* out, const float* gt, const float* kcoords,
+                  const uint8_t* mask, int64_t B, float* loss_out, float* dout, void* stream) {
+  if (loss == nullptr || out == nullptr || gt == nullptr || loss_out == nullptr || dout == nullptr)
+    return fail(INR_ERR_INVALID, "inr_loss_grad: null argument");
+  if (loss->kind < INR_LOSS_L2_HALF || loss->kind > INR_LOSS_HDR)
+    return fail(INR_ERR_INVALID, "inr_loss_grad: loss kind %d", loss->kind);
+  if (B <= 0) return fail(INR_ERR_INVALID, "inr_loss_grad: B = %lld", (long long)B);
+  LossDesc ld;
+  to_loss_desc(loss, &ld);
+  hipError_t e = inr::launch_loss_grad(ld, out, gt, kcoords, mask, B, loss_out, dout, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "inr_loss_grad");
+  return INR_OK;
+}
+
+int inr_train_step(const inr_plan* plan, const inr_loss_desc* loss, const float* params, const float* packed,
+                   const float* x, const float* enc_B, const float* gt, const uint8_t* mask, int64_t B,
+                   float* save, float* slabs, float* grads, float* loss_out, void* stream) {
+  if (plan == nullptr || loss == nullptr || params == nullptr || packed == nullptr || x == nullptr ||
+      gt == nullptr || save == nullptr || slabs == nullptr || grads == nullptr || loss_out == nullptr)
+    return fail(INR_ERR_INVALID, "inr_train_step: null argument");
+  if (plan->nd.input == IN_GAUSS && enc_B == nullptr) return fail(INR_ERR_INVALID, "inr_train_step: enc_B is null");
+  if (loss->kind < INR_LOSS_L2_HALF || loss->kind > INR_LOSS_HDR)
+    return fail(INR_ERR_INVALID, "inr_train_step: loss kind %d", loss->kind);
+  if (loss->kind >= INR_LOSS_LOGSPACE && plan->nd.out_f != 2)
+    return fail(INR_ERR_INVALID, "inr_train_step: complex-row losses need out_features == 2");
+  if (B <= 0) return fail(INR_ERR_INVALID, "inr_train_step: B = %lld", (long long)B);
+  int64_t nt, nb;
+  inr_plan_launch_dims(plan, B, &nt, &nb);
+  inr::MlpArgs a;
+  memset(&a, 0, sizeof(a));
+  a.params = params;
+  a.packed = packed;
+  a.x = x;
+  a.encB = enc_B;
+  a.gt = gt;
+  a.mask = mask;
+  a.save = save;
+  a.slabs = slabs;
+  a.B = B;
+  a.n_tiles = (int)nt;
+  a.save_by_block = 1;
+  LossDesc ld;
+  to_loss_desc(loss, &ld);
+  int rc = launch(plan, ld, a, 2, (int)nb, (hipStream_t)stream);
+  if (rc != INR_OK) return rc;
+  hipError_t e = inr::launch_reduce_slabs(slabs, (int)nb, plan->nd.slab_floats, plan->nd.P, grads, loss_out,
+                                          (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "inr_train_step: slab reduction");
+  return INR_OK;
+}
+
+int inr_adam_step(const inr_plan* plan, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                  float* packed, double lr, double beta1, double beta2, double eps, double weight_decay,
+                  double l1, double l2, int32_t step, void* stream) {
+  if (plan == nullptr || params == nullptr || grads == nullptr || exp_avg == nullptr || exp_avg_sq == nullptr ||
+      packed == nullptr)
+    return fail(INR_ERR_INVALID, "inr_adam_step: null argument");
+  if (step < 1) return fail(INR_ERR_INVALID, "inr_adam_step: step %d (counts from 1)", step);
+  inr::AdamArgs aa;
+  aa.do_update = 1;
+  // torch computes these in Python doubles and passes them to fp32 kernels as scalars
+  const double bc1 = 1.0 - std::pow(beta1, (double)step);
+  const double bc2 = 1.0 - std::pow(beta2, (double)step);
+  aa.step_size = (float)(lr / bc1);
+  aa.bc2_sqrt = (float)std::sqrt(bc2);
+  aa.omb1 = (float)(1.0 - beta1);
+  aa.beta2 = (float)beta2;
+  aa.omb2 = (float)(1.0 - beta2);
+  aa.eps = (float)eps;
+  aa.weight_decay = (float)weight_decay;
+  aa.l1 = (float)l1;
+  aa.l2 = (float)l2;
+  hipError_t e = inr::launch_adam_pack(plan->nd, params, grads, exp_avg, exp_avg_sq, packed, aa, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "inr_adam_step");
+  return INR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,31 @@
+// inr_aux.h -- host-side launchers shared between the translation units of libinr_mi355x.so
+#pragma once
+#include "inr_device.h"
+#include "inr_mlp_args.h"
+
+namespace inr {
+
+struct AdamArgs {
+  int do_update;      // 0: pack only
+  float step_size;    // lr / (1 - beta1^t), computed in double on the host like torch does
+  float bc2_sqrt;     // sqrt(1 - beta2^t)
+  float omb1;         // float(1 - beta1): the lerp weight torch passes to exp_avg.lerp_
+  float beta2, omb2;  // float(beta2), float(1 - beta2)
+  float eps, weight_decay, l1, l2;
+};
+
+
+hipError_t launch_reduce_slabs(const float* slabs, int n_blocks, int slab_floats, int P, float* grads,
+                               float* loss_out, hipStream_t st);
+hipError_t launch_adam_pack(const NetDesc& nd, float* params, const float* grads, float* m1, float* m2,
+                            float* packed, const AdamArgs& aa, hipStream_t st);
+hipError_t launch_encode_gauss(const float* coords, const float* encB, long long B, int E, float* out,
+                               hipStream_t st);
+hipError_t launch_loss_grad(const LossDesc& ld, const float* out, const float* gt, const float* kcoords,
+                            const uint8_t* mask, long long B, float* loss_out, float* dout, hipStream_t st);
+
+// per-NB dispatchers (one translation unit each): mode 0 fwd, 1 bwd, 2 fused
+hipError_t launch_mlp_nb1(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int mode, int grid, hipStream_t st);
+hipError_t launch_mlp_nb8(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int mode, int grid, hipStream_t st);
+
+}  // namespace inr

@@ -1,0 +1,183 @@
+// inr_aux.hip -- HBM-bound helper kernels of the INR engine (gfx950): slab reduction,
+// Adam + weight re-packing, gauss encoder, pointwise losses.  All are coalesced streaming
+// kernels; none reshapes its work into a GEMM.
+#include "inr_device.h"
+#include "inr_aux.h"
+
+namespace inr {
+
+// ---------------------------------------------------------------------------------------------
+// grads[i] = sum_b slabs[b][i] in block order (deterministic); loss word summed by thread 0.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, int n_blocks,
+                                                           int slab_floats, int P, float* __restrict__ grads,
+                                                           float* __restrict__ loss_out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < P) {
+    float s = 0.f;
+    int b = 0;
+    for (; b + 4 <= n_blocks; b += 4) {
+      const float v0 = slabs[(size_t)(b + 0) * slab_floats + i];
+      const float v1 = slabs[(size_t)(b + 1) * slab_floats + i];
+      const float v2 = slabs[(size_t)(b + 2) * slab_floats + i];
+      const float v3 = slabs[(size_t)(b + 3) * slab_floats + i];
+      s = (((s + v0) + v1) + v2) + v3;
+    }
+    for (; b < n_blocks; ++b) s += slabs[(size_t)b * slab_floats + i];
+    grads[i] = s;
+  }
+  if (loss_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+    float l = 0.f;
+    for (int b = 0; b < n_blocks; ++b) l += slabs[(size_t)b * slab_floats + P];
+    loss_out[0] = l;
+  }
+}
+
+hipError_t launch_reduce_slabs(const float* slabs, int n_blocks, int slab_floats, int P, float* grads,
+                               float* loss_out, hipStream_t st) {
+  const int grid = (P + 255) / 256;
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(grid), dim3(256), 0, st, slabs, n_blocks, slab_floats, P, grads,
+                     loss_out);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Adam (torch.optim.Adam single-tensor algorithm, amsgrad=False; train.py:76,190) fused with the
+// re-pack of every weight into the two MFMA A-fragment images.  do_update == 0: pack only.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_pack_kernel(const NetDesc nd, float* __restrict__ params,
+                                                        const float* __restrict__ grads, float* __restrict__ m1,
+                                                        float* __restrict__ m2, float* __restrict__ packed,
+                                                        AdamArgs aa) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nd.P) return;
+  float p = params[i];
+  if (aa.do_update) {
+    float g = grads[i];
+    if (aa.weight_decay != 0.f) g = fmaf(aa.weight_decay, p, g);
+    if (aa.l1 != 0.f) g += aa.l1 * (p > 0.f ? 1.f : (p < 0.f ? -1.f : 0.f));  // d/dp lambda*sum|p|
+    if (aa.l2 != 0.f) g = fmaf(2.f * aa.l2, p, g);                             // d/dp lambda*|sum p^2|
+    float m = m1[i], v = m2[i];
+    m = m + (g - m) * aa.omb1;                    // exp_avg.lerp_(grad, 1 - beta1)
+    v = fmaf(g * g, aa.omb2, v * aa.beta2);       // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1 - beta2)
+    const float denom = sqrtf(v) / aa.bc2_sqrt + aa.eps;
+    p = p - aa.step_size * (m / denom);            // param.addcdiv_(exp_avg, denom, value=-step_size)
+    m1[i] = m;
+    m2[i] = v;
+    params[i] = p;
+  }
+  // locate (layer, row, col); biases are read straight from params by the kernels
+  for (int l = 0; l < nd.D; ++l) {
+    const LayerDesc& L = nd.L[l];
+    const int off = i - L.w_off;
+    if (off >= 0 && off < L.M * L.K) {
+      const int row = off / L.K, k = off - row * L.K;
+      {  // forward image A[i=row][k]
+        int h, s;
+        if (l == 0 && nd.input == IN_GAUSS) {
+          h = k >= nd.E;
+          s = h ? k - nd.E : k;
+        } else {
+          h = k & 1;
+          s = k >> 1;
+        }
+        const int s4 = s >> 2, e = s & 3, m = row >> 5, lane = h * 32 + (row & 31);
+        packed[L.pf_off + ((size_t)(s4 * L.Mblk + m) * 64 + lane) * 4 + e] = p;
+      }
+      if (l >= 1) {  // transposed image A'[i=k][k'=row]
+        const int h = row & 1, s = row >> 1;
+        const int s4 = s >> 2, e = s & 3, m = k >> 5, lane = h * 32 + (k & 31);
+        packed[L.pb_off + ((size_t)(s4 * L.Kblk + m) * 64 + lane) * 4 + e] = p;
+      }
+      return;
+    }
+  }
+}
+
+hipError_t launch_adam_pack(const NetDesc& nd, float* params, const float* grads, float* m1, float* m2,
+                            float* packed, const AdamArgs& aa, hipStream_t st) {
+  const int grid = (nd.P + 255) / 256;
+  hipLaunchKernelGGL(adam_pack_kernel, dim3(grid), dim3(256), 0, st, nd, params, grads, m1, m2, packed, aa);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Positional_Encoder.embedding 'gauss' (networks.py:30-33): out[r] = [sin(p) | cos(p)],
+// p = (2*pi*x_r) @ B^T.  One thread per (row, frequency); writes are coalesced along s.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void encode_gauss_kernel(const float* __restrict__ coords,
+                                                           const float* __restrict__ encB, long long B, int E,
+                                                           float* __restrict__ out) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= B * E) return;
+  const long long r = idx / E;
+  const int s = (int)(idx - r * E);
+  const float two_pi = 6.283185307179586f;
+  const float x0 = two_pi * coords[3 * r + 0], x1 = two_pi * coords[3 * r + 1], x2 = two_pi * coords[3 * r + 2];
+  const float ph = fmaf(x2, encB[3 * s + 2], fmaf(x1, encB[3 * s + 1], x0 * encB[3 * s + 0]));
+  float sn, cs;
+  sincosf(ph, &sn, &cs);
+  out[r * 2 * E + s] = sn;
+  out[r * 2 * E + E + s] = cs;
+}
+
+hipError_t launch_encode_gauss(const float* coords, const float* encB, long long B, int E, float* out,
+                               hipStream_t st) {
+  const long long n = B * E;
+  const int grid = (int)((n + 255) / 256);
+  hipLaunchKernelGGL(encode_gauss_kernel, dim3(grid), dim3(256), 0, st, coords, encB, B, E, out);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pointwise losses + their gradient w.r.t. the network output (tier 1; metrics/losses.py and
+// train.py:172-182).  64 blocks write ordered partial sums to loss_out[1..64]; a single thread
+// then folds them into loss_out[0] (deterministic).
+// ---------------------------------------------------------------------------------------------
+#define LOSS_BLOCKS 64
+
+__global__ __launch_bounds__(256) void loss_grad_kernel(const LossDesc ld, const float* __restrict__ out,
+                                                        const float* __restrict__ gt,
+                                                        const uint8_t* __restrict__ mask, long long B,
+                                                        float* __restrict__ loss_out, float* __restrict__ dout) {
+  __shared__ float red[256];
+  // contiguous row range per block, rows visited in order by a fixed thread -> fixed sum order
+  const long long per = (B + LOSS_BLOCKS - 1) / LOSS_BLOCKS;
+  const long long lo = (long long)blockIdx.x * per;
+  const long long hi = lo + per < B ? lo + per : B;
+  float acc = 0.f;
+  for (long long r = lo + threadIdx.x; r < hi; r += 256) {
+    float g[2] = {0.f, 0.f};
+    if (mask == nullptr || mask[r] != 0) {
+      const float y[2] = {out[2 * r], out[2 * r + 1]};
+      const float t[2] = {gt[2 * r], gt[2 * r + 1]};
+      acc += loss_row(ld, 2, y, t, g);
+    }
+    dout[2 * r] = g[0];
+    dout[2 * r + 1] = g[1];
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s >= 1; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss_out[1 + blockIdx.x] = red[0];
+}
+
+__global__ void loss_fold_kernel(float* loss_out) {
+  float s = 0.f;
+  for (int b = 0; b < LOSS_BLOCKS; ++b) s += loss_out[1 + b];
+  loss_out[0] = s;
+}
+
+hipError_t launch_loss_grad(const LossDesc& ld_in, const float* out, const float* gt, const float* kcoords,
+                            const uint8_t* mask, long long B, float* loss_out, float* dout, hipStream_t st) {
+  LossDesc ld = ld_in;
+  hipLaunchKernelGGL(loss_grad_kernel, dim3(LOSS_BLOCKS), dim3(256), 0, st, ld, out, gt, mask, B, loss_out, dout);
+  hipLaunchKernelGGL(loss_fold_kernel, dim3(1), dim3(1), 0, st, loss_out);
+  (void)kcoords;
+  return hipGetLastError();
+}
+
+}  // namespace inr

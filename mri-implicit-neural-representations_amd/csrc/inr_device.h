@@ -1,0 +1,157 @@
+// inr_device.h -- shared device-side definitions for the gfx950 INR engine.
+// Written for CDNA4 only: 64-lane wavefronts, v_mfma_f32_32x32x2_f32, 160 KiB LDS per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define INR_MAX_LAYERS 16
+#define INR_TILE 128     // coordinates per workgroup tile (4 waves x 32)
+#define INR_WAVES 4
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Activation codes (must match enum inr_act in include/inr_abi.h)
+#define ACT_ID 0
+#define ACT_SIN 1
+#define ACT_TANH 2
+#define ACT_RELU 3
+#define ACT_SIGMOID 4
+
+#define IN_X 0
+#define IN_GAUSS 1
+
+#define LOSS_L2_HALF 0
+#define LOSS_L1_HALF 1
+#define LOSS_TANH 2
+#define LOSS_LOGSPACE 3
+#define LOSS_HDR 4
+
+struct LayerDesc {
+  int K, M;          // logical in / out features
+  int Kpad8;         // K rounded up to a multiple of 8 (4 k-steps of 2 per A-fragment float4)
+  int Kblk;          // ceil(K / 32): 32-wide column blocks of dW
+  int Mblk;          // ceil(M / 32): 32-row blocks
+  int Mpad8;         // M rounded up to a multiple of 8 (k extent of the transposed product)
+  int w_off, b_off;  // offsets (floats) into flat params / grads / slabs
+  int pf_off;        // offset into packed: forward image  A[i=out][k=in]
+  int pb_off;        // offset into packed: transposed image A[i=in][k=out] (unused for layer 0)
+};
+
+struct NetDesc {
+  int D;             // number of Linear layers
+  int NB;            // hidden width / 32
+  int hact;          // hidden activation (ACT_SIN / ACT_RELU)
+  int last_act;
+  int input;         // IN_X / IN_GAUSS
+  int E;             // gauss encoder size (in_features == 2E)
+  int out_f;
+  float w0;
+  int P;             // total params
+  int slab_floats;   // P + loss words, padded to 64
+  int save_floats_per_tile;
+  LayerDesc L[INR_MAX_LAYERS];
+};
+
+struct LossDesc {
+  int kind;
+  float eps, sigma, factor, inv_count, hdr_A;
+};
+
+// Row of a 32x32 MFMA accumulator held in register r by lane-half h (guide section 3:
+// col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)).
+__device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+// Padded [feature][33] LDS image of one wave's 32 coordinates: conflict-free both for
+// "lane = coord" accesses (forward / dX B operand, epilogue stores) and for "lane = feature"
+// reads (dW A operand), and every address is  lane-part + compile-time immediate.
+#define INR_LDS_LD 33
+__device__ __forceinline__ int swz(int feat, int col) { return feat * INR_LDS_LD + col; }
+
+// Branch-free sincos for |x| <= 2^16: three-constant Cody-Waite reduction by pi/2 with FMA, then
+// the cephes single-precision minimax polynomials on [-pi/4, pi/4] (abs error ~1e-7; validated
+// against a float64 reference in tests/test_gpu_kernels.py).  The OCML sincosf carries a
+// Payne-Hanek slow path whose branches would split every MFMA k-step into basic blocks.
+__device__ __forceinline__ void sincos_cw(float x, float& sn, float& cs) {
+  const float k = rintf(x * 0.63661977236758134f);
+  float r = fmaf(k, -1.5707963705062866f, x);      // pi/2 hi
+  r = fmaf(k, 4.3711388286737929e-8f, r);          // -(pi/2 mid)
+  r = fmaf(k, 1.7151245100058e-15f, r);            // -(pi/2 lo)
+  const float s = r * r;
+  float ps = fmaf(s, -1.9515295891e-4f, 8.3321608736e-3f);
+  ps = fmaf(ps, s, -1.6666654611e-1f);
+  const float sr = fmaf(ps * s, r, r);
+  float pc = fmaf(s, 2.443315711809948e-5f, -1.388731625493765e-3f);
+  pc = fmaf(pc, s, 4.166664568298827e-2f);
+  const float cr = fmaf(pc * s, s, fmaf(-0.5f, s, 1.0f));
+  const int q = (int)k;
+  const float a = (q & 1) ? cr : sr;
+  const float b = (q & 1) ? sr : cr;
+  sn = (q & 2) ? -a : a;
+  cs = ((q + 1) & 2) ? -b : b;
+}
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.f;
+  return z;
+}
+
+namespace inr {
+// ---------------------------------------------------------------------------------------------
+// pointwise losses (metrics/losses.py).  y,t: the row's outputs / targets.
+// Returns the row's loss contribution; g[] = d(loss)/d(y).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float loss_row(const LossDesc& ld, int out_f, const float* y, const float* t, float* g) {
+  const float inv = ld.inv_count;
+  float loss = 0.f;
+  if (ld.kind == LOSS_L2_HALF) {  // 0.5 * mean((y - t)^2) over rows*out_f (train.py:82,182)
+    const float s = inv / (float)out_f;
+    for (int o = 0; o < out_f; ++o) {
+      const float e = y[o] - t[o];
+      loss += 0.5f * e * e * s;
+      g[o] = e * s;
+    }
+  } else if (ld.kind == LOSS_L1_HALF) {  // 0.5 * mean(|y - t|)
+    const float s = 0.5f * inv / (float)out_f;
+    for (int o = 0; o < out_f; ++o) {
+      const float e = y[o] - t[o];
+      loss += fabsf(e) * s;
+      g[o] = (e > 0.f ? s : (e < 0.f ? -s : 0.f));
+    }
+  } else if (ld.kind == LOSS_TANH) {  // TanhL2Loss (losses.py:130-139)
+    const float s = inv / (float)out_f;
+    for (int o = 0; o < out_f; ++o) {
+      const float ty = tanhf(y[o]);
+      const float d = ty - tanhf(t[o]);
+      loss += d * d * s;
+      g[o] = 2.f * d * (1.f - ty * ty) * s;
+    }
+  } else if (ld.kind == LOSS_LOGSPACE) {  // LogSpaceLoss (losses.py:214-223)
+    const float er = y[0] - t[0], ei = y[1] - t[1];
+    const float den = sqrtf(y[0] * y[0] + y[1] * y[1]) + ld.eps;
+    const float q = inv / (den * den);
+    loss = (er * er + ei * ei) * q;
+    g[0] = 2.f * er * q;
+    g[1] = 2.f * ei * q;
+  } else {  // LOSS_HDR: HDRLoss_FF, separable form (losses.py:236-264)
+    const float er = y[0] - t[0], ei = y[1] - t[1];
+    const float ya2 = y[0] * y[0] + y[1] * y[1];
+    const float den = sqrtf(ya2) + ld.eps;
+    const float ea2 = er * er + ei * ei;
+    const float lg = logf(sqrtf(ea2) / den);
+    const float rq = ld.factor * ld.hdr_A / (den * den);
+    loss = (lg * lg + rq * ya2) * inv;
+    const float c1 = 2.f * lg / ea2 * inv, c2 = 2.f * rq * inv;
+    g[0] = c1 * er + c2 * y[0];
+    g[1] = c1 * ei + c2 * y[1];
+  }
+  return loss;
+}
+
+}  // namespace inr

@@ -1,0 +1,28 @@
+// inr_mlp_args.h -- launch arguments of the fused MLP kernel (shared by the API and kernel TUs)
+#pragma once
+#include "inr_device.h"
+
+namespace inr {
+
+#define MODE_FWD 0
+#define MODE_BWD 1
+#define MODE_FUSED 2
+
+struct MlpArgs {
+  const float* params;
+  const float* packed;
+  const float* x;      // [B,K0] (IN_X) or coords [B,3] (IN_GAUSS)
+  const float* encB;   // [E,3]
+  const float* gt;     // [B,out_f]   (fused)
+  const uint8_t* mask; // [B] or null (fused)
+  const float* dout;   // [B,out_f]   (bwd)
+  float* out;          // [B,out_f]   (fwd; fused writes it when non-null)
+  float* save;         // stash
+  float* slabs;        // [grid][slab_floats]
+  long long B;
+  int n_tiles;
+  int save_by_block;   // 1: stash slot = blockIdx (fused); 0: slot = tile
+};
+
+
+}  // namespace inr

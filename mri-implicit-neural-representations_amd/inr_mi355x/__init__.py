@@ -1,0 +1,6 @@
+"""inr_mi355x -- MI355X-native engine for the coordinate-MLP fitting hot path of
+luisdavid64/MRI-Implicit-Neural-Representations (SIREN / FFN today; see DESIGN.md for the
+scope table).  The arithmetic lives in lib/libinr_mi355x.so (hand-written gfx950 HIP kernels
+behind the C-ABI of include/inr_abi.h); this package is the thin host side."""
+from .networks import SIREN, FFN, Positional_Encoder  # noqa: F401
+from .engine import MLPEngine, LossSpec, encode_gauss  # noqa: F401

@@ -1,0 +1,192 @@
+"""Host side of the MI355X INR engine: owns the flat parameter / gradient / Adam buffers and the
+workspaces (all torch device tensors -- PyTorch is the allocator and the stream provider) and
+calls the kernels through the C-ABI (include/inr_abi.h).  No arithmetic of the hot path happens
+in this file; there is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+
+
+@dataclass
+class LossSpec:
+    """Loss selection of train.py:81-98 (+ loss_opts of the YAML configs)."""
+    kind: int = L.LOSS_L2_HALF
+    eps: float = 1e-3
+    sigma: float = 2.0
+    factor: float = 0.5
+
+    @staticmethod
+    def from_config(config: dict) -> "LossSpec":
+        name = config["loss"]
+        opts = config.get("loss_opts", {}) or {}
+        kinds = {"L2": L.LOSS_L2_HALF, "L1": L.LOSS_L1_HALF, "tanh": L.LOSS_TANH, "HDR": L.LOSS_HDR,
+                 "LogSpace": L.LOSS_LOGSPACE}
+        if name not in kinds:
+            # the reference evaluates `NotImplementedError` without raising (train.py:98); we raise
+            raise NotImplementedError(f"loss {name!r} has no MI355X kernel (supported: {sorted(kinds)})")
+        return LossSpec(kinds[name], float(opts.get("hdr_eps", 1e-3)), float(opts.get("hdr_ff_sigma", 2.0)),
+                        float(opts.get("hdr_ff_factor", 0.5)))
+
+
+def _ptr(t: Optional[torch.Tensor], name: str, dtype=torch.float32) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} is on {t.device}: the INR engine only runs on an MI355X (no CPU fallback)")
+    if t.dtype != dtype or not t.is_contiguous():
+        raise RuntimeError(f"{name} must be a contiguous {dtype} tensor (got {t.dtype}, contiguous={t.is_contiguous()})")
+    return t.data_ptr()
+
+
+class MLPEngine:
+    """One plan + its device buffers.  Mirrors what nn.Module + torch.optim.Adam hold for SIREN / FFN
+    in the reference (models/networks.py:48-124; train.py:75-78)."""
+
+    def __init__(self, kind: int, in_features: int, width: int, depth: int, out_features: int, last_act: int,
+                 input_mode: int = L.INPUT_X, enc_size: int = 0, w0: float = 30.0):
+        self.lib = L.load()
+        desc = L.NetDesc(kind=kind, in_features=in_features, width=width, depth=depth, out_features=out_features,
+                         last_act=last_act, input=input_mode, enc_size=enc_size, w0=w0)
+        self.desc = desc
+        plan = C.c_void_p()
+        L.check(self.lib.inr_plan_create(C.byref(desc), C.byref(plan)))
+        self.plan = plan
+        sz = L.Sizes()
+        L.check(self.lib.inr_plan_sizes(plan, C.byref(sz)))
+        self.n_params = int(sz.n_params)
+        self.packed_floats = int(sz.packed_floats)
+        self.tile_rows = int(sz.tile_rows)
+        self.save_floats_per_tile = int(sz.save_bytes_per_tile) // 4
+        self.max_blocks = int(sz.max_blocks)
+        self.slab_floats = int(sz.slab_floats)
+        self.in_features, self.out_features = in_features, out_features
+        self.input_mode = input_mode
+        self.params: Optional[torch.Tensor] = None
+        self.grads = self.exp_avg = self.exp_avg_sq = self.packed = None
+        self._save = self._slabs = self._loss = None
+        self.step = 0
+
+    def __del__(self):
+        try:
+            if getattr(self, "plan", None):
+                self.lib.inr_plan_destroy(self.plan)
+                self.plan = None
+        except Exception:
+            pass
+
+    # ---- buffers ------------------------------------------------------------------------------
+    def bind(self, flat_params: torch.Tensor) -> None:
+        """Adopt a flat fp32 device tensor [P] (state_dict order) as the master weights."""
+        _ptr(flat_params, "flat_params")
+        if flat_params.numel() != self.n_params:
+            raise RuntimeError(f"flat_params has {flat_params.numel()} elements, plan needs {self.n_params}")
+        self.params = flat_params
+        dev = flat_params.device
+        self.grads = torch.zeros(self.n_params, device=dev)
+        self.exp_avg = torch.zeros(self.n_params, device=dev)
+        self.exp_avg_sq = torch.zeros(self.n_params, device=dev)
+        self.packed = torch.zeros(self.packed_floats, device=dev)  # padding entries stay zero forever
+        self._loss = torch.zeros(L.LOSS_WORDS, device=dev)
+        self.step = 0
+        self.pack()
+
+    def launch_dims(self, B: int):
+        nt, nb = C.c_int64(), C.c_int64()
+        L.check(self.lib.inr_plan_launch_dims(self.plan, B, C.byref(nt), C.byref(nb)))
+        return int(nt.value), int(nb.value)
+
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.params.device).cuda_stream
+
+    def _ws_save(self, n_slots: int) -> torch.Tensor:
+        need = n_slots * self.save_floats_per_tile
+        if self._save is None or self._save.numel() < need:
+            self._save = torch.empty(need, device=self.params.device)
+        return self._save
+
+    def _ws_slabs(self, n_blocks: int) -> torch.Tensor:
+        need = n_blocks * self.slab_floats
+        if self._slabs is None or self._slabs.numel() < need:
+            self._slabs = torch.empty(need, device=self.params.device)
+        return self._slabs
+
+    # ---- kernels ------------------------------------------------------------------------------
+    def pack(self) -> None:
+        L.check(self.lib.inr_pack_params(self.plan, _ptr(self.params, "params"), _ptr(self.packed, "packed"),
+                                         self._stream()))
+
+    def forward(self, x: torch.Tensor, enc_B: Optional[torch.Tensor] = None, save: bool = False) -> torch.Tensor:
+        B = x.shape[0]
+        nt, _ = self.launch_dims(B)
+        out = torch.empty(B, self.out_features, device=x.device)
+        sv = self._ws_save(nt) if save else None
+        L.check(self.lib.inr_forward(self.plan, _ptr(self.params, "params"), _ptr(self.packed, "packed"),
+                                     _ptr(x, "x"), _ptr(enc_B, "enc_B"), B, _ptr(out, "out"),
+                                     _ptr(sv, "save"), self._stream()))
+        return out
+
+    def backward(self, x: torch.Tensor, enc_B: Optional[torch.Tensor], dout: torch.Tensor) -> torch.Tensor:
+        """d(loss)/d(params) for the most recent forward(save=True) on the same x."""
+        B = x.shape[0]
+        nt, nb = self.launch_dims(B)
+        slabs = self._ws_slabs(nb)
+        L.check(self.lib.inr_backward(self.plan, _ptr(self.params, "params"), _ptr(self.packed, "packed"),
+                                      _ptr(x, "x"), _ptr(enc_B, "enc_B"), B, _ptr(dout, "dout"),
+                                      _ptr(self._ws_save(nt), "save"), _ptr(slabs, "slabs"),
+                                      _ptr(self.grads, "grads"), self._stream()))
+        return self.grads
+
+    def loss_desc(self, spec: LossSpec, count: int, hdr_A: float = 0.0) -> L.LossDesc:
+        return L.LossDesc(kind=spec.kind, eps=spec.eps, sigma=spec.sigma, factor=spec.factor,
+                          inv_count=1.0 / float(count), hdr_A=hdr_A)
+
+    def loss_grad(self, spec: LossSpec, out: torch.Tensor, gt: torch.Tensor, count: int,
+                  mask: Optional[torch.Tensor] = None, hdr_A: float = 0.0):
+        """Tier-1 loss: returns (loss scalar tensor view, dout [B,2])."""
+        B = out.shape[0]
+        dout = torch.empty_like(out)
+        ld = self.loss_desc(spec, count, hdr_A)
+        L.check(self.lib.inr_loss_grad(C.byref(ld), _ptr(out, "out"), _ptr(gt, "gt"), None,
+                                       _ptr(mask, "mask", torch.uint8), B, _ptr(self._loss, "loss"),
+                                       _ptr(dout, "dout"), self._stream()))
+        return self._loss[0], dout
+
+    def train_step(self, x: torch.Tensor, enc_B: Optional[torch.Tensor], gt: torch.Tensor, spec: LossSpec,
+                   count: Optional[int] = None, mask: Optional[torch.Tensor] = None, hdr_A: float = 0.0):
+        """Fused encode -> forward -> loss -> backward (stages of train.py:163-189).  Leaves the
+        un-reduced-across-ranks gradient in self.grads and returns the loss scalar (device)."""
+        B = x.shape[0]
+        _, nb = self.launch_dims(B)
+        ld = self.loss_desc(spec, B if count is None else count, hdr_A)
+        L.check(self.lib.inr_train_step(self.plan, C.byref(ld), _ptr(self.params, "params"),
+                                        _ptr(self.packed, "packed"), _ptr(x, "x"), _ptr(enc_B, "enc_B"),
+                                        _ptr(gt, "gt"), _ptr(mask, "mask", torch.uint8), B,
+                                        _ptr(self._ws_save(nb), "save"), _ptr(self._ws_slabs(nb), "slabs"),
+                                        _ptr(self.grads, "grads"), _ptr(self._loss, "loss"), self._stream()))
+        return self._loss[0]
+
+    def adam_step(self, lr: float, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,
+                  weight_decay: float = 0.0, l1: float = 0.0, l2: float = 0.0) -> None:
+        """torch.optim.Adam.step (train.py:190) on the flat buffers + weight re-pack."""
+        self.step += 1
+        L.check(self.lib.inr_adam_step(self.plan, _ptr(self.params, "params"), _ptr(self.grads, "grads"),
+                                       _ptr(self.exp_avg, "exp_avg"), _ptr(self.exp_avg_sq, "exp_avg_sq"),
+                                       _ptr(self.packed, "packed"), lr, beta1, beta2, eps, weight_decay, l1, l2,
+                                       self.step, self._stream()))
+
+
+def encode_gauss(coords: torch.Tensor, enc_B: torch.Tensor) -> torch.Tensor:
+    """Positional_Encoder.embedding, 'gauss' (networks.py:30-33) on the device."""
+    lib = L.load()
+    B, E = coords.shape[0], enc_B.shape[0]
+    out = torch.empty(B, 2 * E, device=coords.device)
+    L.check(lib.inr_encode_gauss(_ptr(coords, "coords"), _ptr(enc_B, "enc_B"), B, E, _ptr(out, "out"),
+                                 torch.cuda.current_stream(coords.device).cuda_stream))
+    return out

@@ -1,0 +1,213 @@
+"""Single-scale fitting driver: the loop of the reference's src/train.py:155-251 re-expressed
+over the fused MI355X engine (tier 2), with optional data parallelism over coordinates.
+
+Kept from the reference, on purpose: sequential unshuffled batches
+(batch i = rows [i*bs,(i+1)*bs) of the C-major grid, last batch short), per-EPOCH LambdaLR
+``lr*0.2**min(epoch/max_epoch,1)``, Adam with L2-style weight decay, loss on masked rows only
+when undersampled (forward still runs on every row), ``psnr`` with max(x).
+Changed, on purpose: inputs stay resident in HBM (no per-step H2D, no per-item DataLoader
+collate, no ``.item()`` sync per step), the encoder is fused into layer 0, and unsupported
+config values raise instead of falling through.
+
+CLI (same flags as the reference, train.py:255-258):
+    python -m inr_mi355x.train --config cfg.yaml [--output_path out] [--synthetic C,H,W]
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import time
+from typing import Optional
+
+import torch
+import yaml
+
+from . import _lib as L
+from .engine import LossSpec
+from .evalchain import psnr, reconstruct
+from .networks import FFN, SIREN, Positional_Encoder
+from .synthetic import make_kspace
+
+MODELS = {"SIREN": SIREN, "FFN": FFN}
+
+
+def get_config(path: str) -> dict:
+    """models/utils.py:25-32."""
+    if not path:
+        return {}
+    with open(path, "r") as f:
+        return yaml.load(f, Loader=yaml.Loader)
+
+
+def set_default_configs(config: dict) -> dict:
+    """utils.py:7-23."""
+    config.setdefault("per_coil", False)
+    config.setdefault("use_tv", False)
+    if "regularization" not in config:
+        config["regularization"] = {"type": "none"}
+    config.setdefault("undersampling", None)
+    return config
+
+
+def lr_factor(epoch: int, max_epoch: int) -> float:
+    """LambdaLR lambda of train.py:153."""
+    return 0.2 ** min(epoch / max_epoch, 1)
+
+
+def shard_rows(lo: int, hi: int, rank: int, world: int):
+    """Contiguous split of batch rows [lo,hi) over ranks: rank r gets
+    [lo + r*n//world, lo + (r+1)*n//world)."""
+    n = hi - lo
+    return lo + (rank * n) // world, lo + ((rank + 1) * n) // world
+
+
+class INRTrainer:
+    def __init__(self, config: dict, image: torch.Tensor, coords: torch.Tensor, shape, device,
+                 seed: int = 0, mask: Optional[torch.Tensor] = None, rank: int = 0, world: int = 1,
+                 process_group=None):
+        config = set_default_configs(dict(config))
+        self.config = config
+        self.device = torch.device(device)
+        self.rank, self.world, self.pg = rank, world, process_group
+        self.shape = shape
+        if config["model"] not in MODELS:
+            raise NotImplementedError(f"model {config['model']!r} has no MI355X kernel yet (have {sorted(MODELS)})")
+        if config.get("optimizer", "Adam") != "Adam":
+            raise NotImplementedError("only Adam (train.py:75-78)")
+        # construction order and RNG use of train.py:52-71: encoder, then model, on the CPU generator
+        torch.manual_seed(seed)
+        self.encoder = Positional_Encoder(config["encoder"], device=self.device)
+        self.model = MODELS[config["model"]](config["net"]).to(self.device)
+        emb = config["encoder"]["embedding"]
+        if emb == "gauss":
+            self.engine = self.model.fused_engine(config["encoder"]["embedding_size"])
+            self.enc_B = self.encoder.B.contiguous()
+        else:
+            self.engine = self.model._engine()
+            self.enc_B = None
+        self.loss = LossSpec.from_config(config)
+        reg = config["regularization"]
+        self.l1 = float(reg["strenght"]) if reg["type"] == "L1" else 0.0
+        self.l2 = float(reg["strenght"]) if reg["type"] == "L2" else 0.0
+        if reg["type"] not in ("none", "L1", "L2"):
+            raise NotImplementedError(f"regularization {reg['type']!r}")
+        # data resident in HBM for the whole fit
+        self.n = coords.shape[0]
+        self.coords = coords.to(self.device).contiguous()
+        self.image = image.to(self.device).contiguous()
+        self.mask_cpu = mask
+        self.mask = mask.to(torch.uint8).to(self.device).contiguous() if mask is not None else None
+        self.bs = int(config["batch_size"])
+        self.steps_per_epoch = math.ceil(self.n / self.bs)
+        self.global_step = 0
+        self._hdr_A = {}
+
+    # ---- one optimizer step on batch `it` of epoch `epoch` --------------------------------------
+    def _inputs(self, lo: int, hi: int):
+        if self.enc_B is not None:
+            return self.coords[lo:hi]
+        if self.config["encoder"]["embedding"] == "none":
+            return self.coords[lo:hi]
+        return self.encoder.embedding(self.coords[lo:hi])
+
+    def _batch_hdr_A(self, it: int, lo: int, hi: int) -> float:
+        """A = mean_i((1-f_i)^2) over ALL batch coordinates (losses.py:241-242,258)."""
+        if self.loss.kind != L.LOSS_HDR:
+            return 0.0
+        if it not in self._hdr_A:
+            kc = self.coords[lo:hi]
+            f = torch.exp(-(kc[:, 1] ** 2 + kc[:, 2] ** 2) / (2 * self.loss.sigma ** 2))
+            self._hdr_A[it] = float(torch.mean((1 - f) ** 2))
+        return self._hdr_A[it]
+
+    def step(self, epoch: int, it: int) -> torch.Tensor:
+        lo, hi = it * self.bs, min((it + 1) * self.bs, self.n)
+        if self.mask_cpu is not None:
+            count = int(self.mask_cpu[lo:hi].sum())
+        else:
+            count = hi - lo
+        A = self._batch_hdr_A(it, lo, hi)
+        slo, shi = shard_rows(lo, hi, self.rank, self.world)
+        m = self.mask[slo:shi] if self.mask is not None else None
+        loss = self.engine.train_step(self._inputs(slo, shi), self.enc_B, self.image[slo:shi], self.loss,
+                                      count=count, mask=m, hdr_A=A)
+        if self.world > 1:
+            import torch.distributed as dist
+            # un-normalised-by-rank partial sums: every rank divided by the GLOBAL count already
+            dist.all_reduce(self.engine.grads, op=dist.ReduceOp.SUM, group=self.pg)
+            loss = loss.clone()
+            dist.all_reduce(loss, op=dist.ReduceOp.SUM, group=self.pg)
+        lr = self.config["lr"] * lr_factor(epoch, self.config["max_epoch"])
+        self.engine.adam_step(lr, self.config["beta1"], self.config["beta2"], 1e-8, self.config["weight_decay"],
+                              self.l1, self.l2)
+        self.global_step += 1
+        return loss
+
+    def fit(self, max_steps: Optional[int] = None, log_every: int = 0):
+        """Runs epochs of sequential batches (train.py:155-198).  Returns the list of losses logged."""
+        logged = []
+        for epoch in range(self.config["max_epoch"]):
+            for it in range(self.steps_per_epoch):
+                if max_steps is not None and self.global_step >= max_steps:
+                    return logged
+                loss = self.step(epoch, it)
+                if log_every and self.global_step % log_every == 0:
+                    logged.append((self.global_step, float(loss)))
+        return logged
+
+    # ---- validation (train.py:199-231) -----------------------------------------------------------
+    @torch.no_grad()
+    def predict_all(self, chunk: int = 1 << 18) -> torch.Tensor:
+        outs = []
+        for lo in range(0, self.n, chunk):
+            hi = min(lo + chunk, self.n)
+            outs.append(self.engine.forward(self._inputs(lo, hi), self.enc_B, save=False))
+        return torch.cat(outs, 0)
+
+    @torch.no_grad()
+    def evaluate(self) -> float:
+        in_image_space = bool(self.config.get("transform", False))
+        ref = reconstruct(self.image, self.shape, in_image_space)
+        rec = reconstruct(self.predict_all(), self.shape, in_image_space)
+        return float(psnr(ref, rec))
+
+    def checkpoint(self) -> dict:
+        """Same dict as train.py:247-250 ('opt' in torch.optim.Adam.state_dict() layout)."""
+        sd = self.model.state_dict()
+        state, o = {}, 0
+        for i, (off, n, shp) in enumerate(self.model._layout):
+            state[i] = {"step": torch.tensor(float(self.engine.step)),
+                        "exp_avg": self.engine.exp_avg[off:off + n].view(shp).clone(),
+                        "exp_avg_sq": self.engine.exp_avg_sq[off:off + n].view(shp).clone()}
+        opt = {"state": state, "param_groups": [{"lr": self.config["lr"], "betas": (self.config["beta1"], self.config["beta2"]),
+                                                 "eps": 1e-8, "weight_decay": self.config["weight_decay"],
+                                                 "amsgrad": False, "params": list(range(len(self.model._layout)))}]}
+        return {"net": sd, "enc": self.encoder.B, "opt": opt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", type=str, required=True)
+    ap.add_argument("--data_samples", type=str, default="")
+    ap.add_argument("--output_path", type=str, default=".")
+    ap.add_argument("--synthetic", type=str, default="15,640,368", help="C,H,W of the synthetic k-space")
+    ap.add_argument("--max_steps", type=int, default=None)
+    opts = ap.parse_args()
+    config = set_default_configs(get_config(opts.config))
+    C, H, W = (int(v) for v in opts.synthetic.split(","))
+    image, coords, shape = make_kspace(C, H, W, normalization=config.get("normalization", "coil"),
+                                       image_space=bool(config.get("transform", False)))
+    tr = INRTrainer(config, image, coords, shape, "cuda")
+    t0 = time.time()
+    tr.fit(opts.max_steps, log_every=config.get("log_iter", 20))
+    torch.cuda.synchronize()
+    res = {"steps": tr.global_step, "seconds": time.time() - t0, "psnr": tr.evaluate()}
+    os.makedirs(opts.output_path, exist_ok=True)
+    torch.save(tr.checkpoint(), os.path.join(opts.output_path, "model_%06d.pt" % tr.global_step))
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
