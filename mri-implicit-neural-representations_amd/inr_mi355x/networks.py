@@ -60,7 +60,7 @@ class _MLPFunction(torch.autograd.Function):
     def forward(ctx, module, x, *params):
         eng = module._engine()
         eng.pack()  # parameters may have been stepped by an external optimizer
-        need_grad = any(p.requires_grad for p in params) and torch.is_grad_enabled()
+        need_grad = any(ctx.needs_input_grad[2:])  # (grad mode is always off inside Function.forward)
         x = x.contiguous()
         out = eng.forward(x, None, save=need_grad)
         ctx.module = module
