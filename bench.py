@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py -- coord-samples/sec (fwd+bwd) fitting synthetic 640x368x15-coil k-space.
+
+Workload (BASELINE.json configs[1]): SIREN depth 5 / width 256 / gauss-512 input, last_tanh,
+k-space, normalization 'coil', L2, lr 3e-5, batch 25 000 coordinates per GPU.  One "step" =
+fused encode->forward->loss->backward kernel + slab reduction (+ RCCL all-reduce of the 1.3 MB
+gradient when N>1) + Adam/re-pack kernel, on sequential batches resident in HBM.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.  Data is synthetic (seeded phantom), weights are random-init.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "mri-implicit-neural-representations_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+FLOP_PER_SAMPLE = 1_707_008  # SIREN 5x256/in512 fwd + dW + dX, 2 FLOP per MAC
+F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md chip table: v_mfma_f32_32x32x2_f32 dense peak
+
+CONFIG = {
+    "model": "SIREN", "loss": "L2", "optimizer": "Adam", "lr": 3e-5, "beta1": 0.9, "beta2": 0.999,
+    "weight_decay": 0.0, "max_epoch": 1000, "batch_size": 25000, "transform": False, "normalization": "coil",
+    "net": {"network_input_size": 512, "network_output_size": 2, "network_depth": 5, "network_width": 256,
+            "last_tanh": True},
+    "encoder": {"embedding": "gauss", "scale": 4, "embedding_size": 256, "coordinates_size": 3},
+}
+SHAPE = (15, 640, 368)
+
+
+def cpu_baseline(image, coords, seconds=12.0):
+    """The oracle (CPU restatement of the reference's step: encode -> SIREN -> 0.5*MSE -> autograd
+    -> Adam), timed on this host's cores on a bounded number of 25 000-row steps."""
+    import oracle as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    cfg = dict(CONFIG)
+    torch.manual_seed(0)
+    B = O.encoder_init(cfg["encoder"])
+    sd = O.init_model("SIREN", cfg["net"])
+    bs = cfg["batch_size"]
+    t_all, steps = [], 0
+
+    def rec(step, sd_, loss):
+        t_all.append(time.perf_counter())
+
+    t0 = time.perf_counter()
+    n_steps = 2
+    O.train_single_scale(cfg, sd, B, coords[: 2 * bs], image[: 2 * bs], n_steps, record=rec)  # warm-up
+    per = (time.perf_counter() - t0) / n_steps
+    k = max(3, min(60, int(seconds / max(per, 1e-3))))
+    t_all.clear()
+    t0 = time.perf_counter()
+    O.train_single_scale(cfg, sd, B, coords[: k * bs], image[: k * bs], k, record=rec)
+    dt = time.perf_counter() - t0
+    return {"value": k * bs / dt, "unit": "coord-samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{k} steps x {bs} rows of the same workload (oracle: PyTorch-CPU fp32, "
+                      f"encode+fwd+0.5*MSE+autograd+Adam), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=25000, help="coordinates per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--psnr-steps", type=int, default=1000, help="total steps before the PSNR read-out (N=1)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from inr_mi355x.synthetic import make_kspace
+    from inr_mi355x.train import INRTrainer
+    from inr_mi355x import _lib as L
+    import ctypes as C
+
+    image, coords, shape = make_kspace(*SHAPE, seed=1234, normalization="coil")
+    cfg = dict(CONFIG)
+    cfg["batch_size"] = args.batch * world  # weak scaling: every rank keeps `--batch` rows per step
+    tr = INRTrainer(cfg, image, coords, shape, dev, seed=0, rank=rank, world=world, process_group=pg)
+    spe = tr.steps_per_epoch
+
+    def run(n, start):
+        for i in range(n):
+            s = start + i
+            tr.step(s // spe, s % spe)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run(args.warmup, 0)
+    barrier()
+    t0 = time.perf_counter()
+    run(args.steps, args.warmup)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    rows = 0
+    for i in range(args.steps):
+        it = (args.warmup + i) % spe
+        rows += min((it + 1) * tr.bs, tr.n) - it * tr.bs
+    value = rows / dt
+
+    # ---- roofline of the dominant kernel (the fused MLP kernel), HIP events on the launch stream
+    eng = tr.engine
+    lo, hi = 0, args.batch
+    x, gt = tr.coords[lo:hi], tr.image[lo:hi]
+    ld = eng.loss_desc(tr.loss, args.batch)
+    _, nb = eng.launch_dims(args.batch)
+    save, slabs = eng._ws_save(nb), eng._ws_slabs(nb)
+    st = torch.cuda.current_stream(dev).cuda_stream
+
+    def fused_only():
+        L.check(eng.lib.inr_train_step(eng.plan, C.byref(ld), eng.params.data_ptr(), eng.packed.data_ptr(),
+                                       x.data_ptr(), tr.enc_B.data_ptr(), gt.data_ptr(), None, args.batch,
+                                       save.data_ptr(), slabs.data_ptr(), None, eng._loss.data_ptr(), st))
+
+    for _ in range(5):
+        fused_only()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 50
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        fused_only()
+    e1.record()
+    torch.cuda.synchronize()
+    k_ms = e0.elapsed_time(e1) / reps
+    achieved = FLOP_PER_SAMPLE * args.batch / (k_ms * 1e-3) / 1e12
+
+    out = {
+        "metric": "coord-samples/sec (fwd+bwd) fitting 640x368x15-coil k-space; PSNR@1k steps",
+        "value": value, "unit": "coord-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "SIREN 5x256 gauss-512 k-space fit, synthetic 640x368x15-coil, L2, Adam",
+                   "batch_per_gpu": args.batch, "global_batch": args.batch * world,
+                   "parallelism": f"dp{world}" if world > 1 else "single"},
+        "roofline": {"bound": "mfma", "kernel": "inr_mlp_kernel<8,GAUSS,SIN,FUSED>", "achieved": achieved,
+                     "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS,
+                     "kernel_ms": k_ms, "traffic": None,
+                     "note": "exact-fp32 path (v_mfma_f32_32x32x2_f32); peak = dense f32 MFMA"},
+    }
+    if world == 1 and rank == 0:
+        done = args.warmup + args.steps
+        if args.psnr_steps and args.psnr_steps > done:
+            run(args.psnr_steps - done, done)
+            out["psnr_at_1k_steps"] = {"steps": args.psnr_steps, "psnr_db": tr.evaluate()}
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(image, coords)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

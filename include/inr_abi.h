@@ -144,7 +144,8 @@ int inr_loss_grad(const inr_loss_desc* loss, const float* out, const float* gt, 
 
 /* Fused tier-2 step, stages 1-3 of train.py:163-189 in one launch: encode -> forward -> pointwise
  * loss -> backward, then the fixed-order slab reduction.  Leaves grads [P] and loss_out[0];
- * the caller all-reduces grads across ranks (if any) and calls inr_adam_step. */
+ * the caller all-reduces grads across ranks (if any) and calls inr_adam_step.  `grads` may be
+ * NULL to launch the fused kernel alone and leave the slabs unreduced (used to time it). */
 int inr_train_step(const inr_plan* plan, const inr_loss_desc* loss, const float* params,
                    const float* packed, const float* x, const float* enc_B, const float* gt,
                    const uint8_t* mask, int64_t B, float* save, float* slabs, float* grads,

@@ -261,7 +261,7 @@ int inr_train_step(const inr_plan* plan, const inr_loss_desc* loss, const float*
                    const float* x, const float* enc_B, const float* gt, const uint8_t* mask, int64_t B,
                    float* save, float* slabs, float* grads, float* loss_out, void* stream) {
   if (plan == nullptr || loss == nullptr || params == nullptr || packed == nullptr || x == nullptr ||
-      gt == nullptr || save == nullptr || slabs == nullptr || grads == nullptr || loss_out == nullptr)
+      gt == nullptr || save == nullptr || slabs == nullptr || loss_out == nullptr)
     return fail(INR_ERR_INVALID, "inr_train_step: null argument");
   if (plan->nd.input == IN_GAUSS && enc_B == nullptr) return fail(INR_ERR_INVALID, "inr_train_step: enc_B is null");
   if (loss->kind < INR_LOSS_L2_HALF || loss->kind > INR_LOSS_HDR)
@@ -288,6 +288,7 @@ int inr_train_step(const inr_plan* plan, const inr_loss_desc* loss, const float*
   to_loss_desc(loss, &ld);
   int rc = launch(plan, ld, a, 2, (int)nb, (hipStream_t)stream);
   if (rc != INR_OK) return rc;
+  if (grads == nullptr) return INR_OK;  // profiling: leave the per-block slabs unreduced
   hipError_t e = inr::launch_reduce_slabs(slabs, (int)nb, plan->nd.slab_floats, plan->nd.P, grads, loss_out,
                                           (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "inr_train_step: slab reduction");

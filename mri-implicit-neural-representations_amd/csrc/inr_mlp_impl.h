@@ -99,8 +99,8 @@ __device__ __forceinline__ void acc_to_lds(const f32x16 (&acc)[NBM], float* R, c
 // ---------------------------------------------------------------------------------------------
 template <int NB>
 __device__ __forceinline__ void fwd_layer0_gauss(f32x16 (&acc)[NB], const float* __restrict__ wp,
-                                                 const float* __restrict__ encB, int E, float xs0, float xs1,
-                                                 float xs2, int lane) {
+                                                 const float* encB_lds, int E, float xs0, float xs1, float xs2,
+                                                 int lane) {
   const int half = lane >> 5;
   const f32x4* p = reinterpret_cast<const f32x4*>(wp) + lane;
   const int n4 = E >> 2;
@@ -110,10 +110,13 @@ __device__ __forceinline__ void fwd_layer0_gauss(f32x16 (&acc)[NB], const float*
   for (int s4 = 0; s4 < n4; ++s4) {
     const int nx = (s4 + 1 < n4) ? (s4 + 1) : s4;
     load_afrag<NB>(a_nxt, p + (size_t)nx * NB * 64);
+    __builtin_amdgcn_sched_barrier(0);  // keep the next group's loads at the top of the iteration
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int s = 4 * s4 + e;
-      const float b0 = encB[3 * s + 0], b1 = encB[3 * s + 1], b2 = encB[3 * s + 2];
+      // encoder rows come from LDS (wave-uniform broadcast reads): a vector global load here
+      // would drag a vmcnt(0) behind it and drain the A-fragment prefetch every k-step
+      const float b0 = encB_lds[3 * s + 0], b1 = encB_lds[3 * s + 1], b2 = encB_lds[3 * s + 2];
       // (2*pi*x) @ B^T, K = 3 (networks.py:31)
       const float ph = fmaf(xs2, b2, fmaf(xs1, b1, xs0 * b0));
       float sn, cs;
@@ -122,6 +125,7 @@ __device__ __forceinline__ void fwd_layer0_gauss(f32x16 (&acc)[NB], const float*
 #pragma unroll
       for (int m = 0; m < NB; ++m) acc[m] = mfma32(a_cur[m][e], b, acc[m]);
     }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int m = 0; m < NB; ++m) a_cur[m] = a_nxt[m];
   }
@@ -165,18 +169,24 @@ __device__ __forceinline__ void fwd_layer(f32x16 (&acc)[NBOUT], const float* R, 
   const int half = lane >> 5, col = lane & 31;
   const f32x4* p = reinterpret_cast<const f32x4*>(wp) + lane;
   constexpr int n4 = NB * 4;  // K = 32*NB features -> 16*NB k-steps -> 4*NB groups of 4
+  const float* Rl = R + half * INR_LDS_LD + col;  // row k = 2*(4*s4+e) + half
   f32x4 a_cur[NBOUT], a_nxt[NBOUT];
+  float z_cur[4], z_nxt[4];
   load_afrag<NBOUT>(a_cur, p);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) z_cur[e] = Rl[(2 * e) * INR_LDS_LD];
 #pragma unroll 1
   for (int s4 = 0; s4 < n4; ++s4) {
     const int nx = (s4 + 1 < n4) ? (s4 + 1) : s4;
     load_afrag<NBOUT>(a_nxt, p + (size_t)nx * NBOUT * 64);
 #pragma unroll
+    for (int e = 0; e < 4; ++e) z_nxt[e] = Rl[(8 * nx + 2 * e) * INR_LDS_LD];
+    __builtin_amdgcn_sched_barrier(0);  // next group's operands are in flight behind this group's MFMAs
+#pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int k = 2 * (4 * s4 + e) + half;
-      const float z = R[swz(k, col)];
       float h, d;
-      act_fwd<HACT>(z, w0, h, d);
+      act_fwd<HACT>(z_cur[e], w0, h, d);
       if (SAVE) {
         sv_h[k * INR_TILE + wcol] = h;
         sv_d[k * INR_TILE + wcol] = d;
@@ -184,8 +194,11 @@ __device__ __forceinline__ void fwd_layer(f32x16 (&acc)[NBOUT], const float* R, 
 #pragma unroll
       for (int m = 0; m < NBOUT; ++m) acc[m] = mfma32(a_cur[m][e], h, acc[m]);
     }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int m = 0; m < NBOUT; ++m) a_cur[m] = a_nxt[m];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) z_cur[e] = z_nxt[e];
   }
 }
 
@@ -200,25 +213,44 @@ __device__ __forceinline__ void bwd_dx(f32x16 (&acc)[NB], float* R, const float*
   const int half = lane >> 5, col = lane & 31;
   const f32x4* p = reinterpret_cast<const f32x4*>(wpT) + lane;
   const int n4 = Mpad8 >> 3;
+  float* Rl = R + half * INR_LDS_LD + col;
+  const float* dl = HASD ? sv_d + half * INR_TILE + wcol : nullptr;
   f32x4 a_cur[NB], a_nxt[NB];
+  float g_cur[4], g_nxt[4], d_cur[4], d_nxt[4];
   load_afrag<NB>(a_cur, p);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    g_cur[e] = Rl[(2 * e) * INR_LDS_LD];
+    d_cur[e] = HASD ? dl[(2 * e) * INR_TILE] : 1.f;
+  }
 #pragma unroll 1
   for (int s4 = 0; s4 < n4; ++s4) {
     const int nx = (s4 + 1 < n4) ? (s4 + 1) : s4;
     load_afrag<NB>(a_nxt, p + (size_t)nx * NB * 64);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int k = 2 * (4 * s4 + e) + half;
-      float g = R[swz(k, col)];
+      g_nxt[e] = Rl[(8 * nx + 2 * e) * INR_LDS_LD];
+      d_nxt[e] = HASD ? dl[(8 * nx + 2 * e) * INR_TILE] : 1.f;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float g = g_cur[e];
       if (HASD) {
-        g *= sv_d[k * INR_TILE + wcol];
-        R[swz(k, col)] = g;
+        g *= d_cur[e];
+        Rl[(8 * s4 + 2 * e) * INR_LDS_LD] = g;  // dZ_l, read again by dW (rows of group nx are untouched)
       }
 #pragma unroll
       for (int m = 0; m < NB; ++m) acc[m] = mfma32(a_cur[m][e], g, acc[m]);
     }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int m = 0; m < NB; ++m) a_cur[m] = a_nxt[m];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      g_cur[e] = g_nxt[e];
+      d_cur[e] = d_nxt[e];
+    }
   }
 }
 
@@ -239,28 +271,34 @@ __device__ __forceinline__ void bwd_dz_inplace(float* R, int nfeat, const float*
 // ---------------------------------------------------------------------------------------------
 struct BSrcStash {  // h_{l-1} stash [feature][128]
   const float* __restrict__ h;
+  struct Raw { f32x4 v; };
   __device__ __forceinline__ void begin(int, int) {}
-  __device__ __forceinline__ f32x4 load4(int n, int q, int lane) const {
+  __device__ __forceinline__ Raw fetch(int n, int q, int lane) const {
     const int j = 32 * n + (lane & 31);
-    return *reinterpret_cast<const f32x4*>(h + j * INR_TILE + 8 * q + 4 * (lane >> 5));
+    return Raw{*reinterpret_cast<const f32x4*>(h + j * INR_TILE + 8 * q + 4 * (lane >> 5))};
   }
+  __device__ __forceinline__ f32x4 finish(const Raw& r) const { return r.v; }
 };
 
 struct BSrcX {  // x [B,K0] row-major
   const float* __restrict__ x;
   long long row0, B;
   int K0;
+  struct Raw { f32x4 v; };
   __device__ __forceinline__ void begin(int, int) {}
-  __device__ __forceinline__ f32x4 load4(int n, int q, int lane) const {
+  __device__ __forceinline__ Raw fetch(int n, int q, int lane) const {
     const int j = 32 * n + (lane & 31);
-    f32x4 v;
+    Raw r;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const long long r = row0 + 8 * q + 4 * (lane >> 5) + e;
-      v[e] = (j < K0 && r < B) ? x[r * K0 + j] : 0.f;
+      const long long row = row0 + 8 * q + 4 * (lane >> 5) + e;
+      const bool ok = j < K0 && row < B;
+      const float v = x[ok ? row * K0 + j : 0];
+      r.v[e] = ok ? v : 0.f;
     }
-    return v;
+    return r;
   }
+  __device__ __forceinline__ f32x4 finish(const Raw& r) const { return r.v; }
 };
 
 struct BSrcGauss {  // recompute the Fourier features of the tile's coordinates (never stored)
@@ -270,6 +308,7 @@ struct BSrcGauss {  // recompute the Fourier features of the tile's coordinates 
   int E;
   float b0, b1, b2;
   bool is_cos;
+  struct Raw { float x[4][3]; };
   __device__ __forceinline__ void begin(int n, int lane) {
     const int f = 32 * n + (lane & 31);
     is_cos = f >= E;
@@ -281,19 +320,26 @@ struct BSrcGauss {  // recompute the Fourier features of the tile's coordinates 
       b2 = encB[3 * s + 2];
     }
   }
-  __device__ __forceinline__ f32x4 load4(int, int q, int lane) const {
+  __device__ __forceinline__ Raw fetch(int, int q, int lane) const {
+    Raw r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const long long row = row0 + 8 * q + 4 * (lane >> 5) + e;
+      const bool ok = row < B;
+      const float* c = coords + (ok ? 3 * row : 0);
+      const float x0 = c[0], x1 = c[1], x2 = c[2];
+      r.x[e][0] = ok ? x0 : 0.f;
+      r.x[e][1] = ok ? x1 : 0.f;
+      r.x[e][2] = ok ? x2 : 0.f;
+    }
+    return r;
+  }
+  __device__ __forceinline__ f32x4 finish(const Raw& r) const {
     f32x4 v;
     const float two_pi = 6.283185307179586f;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const long long r = row0 + 8 * q + 4 * (lane >> 5) + e;
-      float x0 = 0.f, x1 = 0.f, x2 = 0.f;
-      if (r < B) {
-        x0 = coords[3 * r + 0];
-        x1 = coords[3 * r + 1];
-        x2 = coords[3 * r + 2];
-      }
-      const float ph = fmaf(two_pi * x2, b2, fmaf(two_pi * x1, b1, (two_pi * x0) * b0));
+      const float ph = fmaf(two_pi * r.x[e][2], b2, fmaf(two_pi * r.x[e][1], b1, (two_pi * r.x[e][0]) * b0));
       float sn, cs;
       sincos_cw(ph, sn, cs);
       v[e] = is_cos ? cs : sn;
@@ -328,20 +374,39 @@ __device__ __forceinline__ void dw_pass(const float* Rall, int region_stride, BS
   }
   bsrc.begin(n, lane);
   const float* Rl = Rall + li * INR_LDS_LD + 4 * half;
+  // software pipeline: operands of coordinate group q+1 are fetched while group q is multiplied
+  f32x4 bv_cur = bsrc.finish(bsrc.fetch(n, 0, lane)), bv_nxt;
+  float a_cur[4][MT], a_nxt[4][MT];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) a_cur[e][m] = Rl[32 * m * INR_LDS_LD + e];
 #pragma unroll 1
   for (int q = 0; q < INR_TILE / 8; ++q) {
-    const f32x4 bv = bsrc.load4(n, q, lane);
+    const int qn = (q + 1 < INR_TILE / 8) ? q + 1 : q;
+    const typename BSrc::Raw raw = bsrc.fetch(n, qn, lane);
     // coordinate 8q + 4*half + e lives in wave image q>>2, column 8(q&3) + 4*half + e
-    const float* Rq = Rl + (q >> 2) * region_stride + 8 * (q & 3);
+    const float* Rq = Rl + (qn >> 2) * region_stride + 8 * (qn & 3);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) a_nxt[e][m] = Rq[32 * m * INR_LDS_LD + e];
+    __builtin_amdgcn_sched_barrier(0);
+    bv_nxt = bsrc.finish(raw);  // ALU part (sincos for the encoder source) interleaves with the MFMAs
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
-        const float a = Rq[32 * m * INR_LDS_LD + e];
-        bsum[m] += a;
-        acc[m] = mfma32(a, bv[e], acc[m]);
+        bsum[m] += a_cur[e][m];
+        acc[m] = mfma32(a_cur[e][m], bv_cur[e], acc[m]);
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    bv_cur = bv_nxt;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) a_cur[e][m] = a_nxt[e][m];
   }
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
@@ -381,6 +446,11 @@ __global__ __launch_bounds__(256) void inr_mlp_kernel(const NetDesc nd, const Lo
   const int wcol = w * 32 + col;
   constexpr int RS = NB * 32 * INR_LDS_LD;  // floats per wave image
   float* R = lds + w * RS;
+  float* encB_lds = lds + INR_WAVES * RS;  // [E][3] encoder matrix (gauss mode)
+  if (INMODE == IN_GAUSS) {
+    for (int i = tid; i < 3 * nd.E; i += 256) encB_lds[i] = a.encB[i];
+    __syncthreads();
+  }
   const int D = nd.D;
   const float w0 = nd.w0;
   constexpr int HSZ = NB * 32 * INR_TILE;  // floats per stashed tensor
@@ -413,7 +483,7 @@ __global__ __launch_bounds__(256) void inr_mlp_kernel(const NetDesc nd, const Lo
             x2 = a.x[3 * crow + 2];
           }
           const float two_pi = 6.283185307179586f;
-          fwd_layer0_gauss<NB>(acc, a.packed + L0.pf_off, a.encB, nd.E, two_pi * x0, two_pi * x1, two_pi * x2, lane);
+          fwd_layer0_gauss<NB>(acc, a.packed + L0.pf_off, encB_lds, nd.E, two_pi * x0, two_pi * x1, two_pi * x2, lane);
         } else {
           fwd_layer0_x<NB>(acc, a.packed + L0.pf_off, a.x + (size_t)(valid ? crow : 0) * L0.K, valid, L0.K, L0.Kpad8,
                            lane);
@@ -551,12 +621,13 @@ __global__ __launch_bounds__(256) void inr_mlp_kernel(const NetDesc nd, const Lo
 // hipFuncSetAttribute + launch
 template <int NB, int INMODE, int HACT, int MODE>
 inline hipError_t launch_mlp(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int grid, hipStream_t st) {
-  const size_t lds_bytes = (size_t)INR_WAVES * NB * 32 * INR_LDS_LD * sizeof(float);
+  const size_t lds_bytes = ((size_t)INR_WAVES * NB * 32 * INR_LDS_LD + 3 * (size_t)nd.E) * sizeof(float);
   auto k = inr_mlp_kernel<NB, INMODE, HACT, MODE>;
   static thread_local bool attr_set = false;
+  if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds_bytes);
+                                       160 * 1024);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
