@@ -31,6 +31,10 @@ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 constexpr int kMaxBlocks = 256;  // one persistent workgroup per CU (MI355X: 256 CUs)
 
+#ifdef INR_STAMPS
+long long* g_stamp_buf = nullptr;  // diagnostic build only (make dbg): phase stamps of the fused kernel
+#endif
+
 }  // namespace
 
 struct inr_plan {
@@ -66,8 +70,8 @@ int inr_plan_create(const inr_net_desc* d, inr_plan** out) {
     return fail(INR_ERR_UNSUPPORTED, "inr_plan_create: out_features %d outside [1,4]", d->out_features);
   if (d->in_features < 1) return fail(INR_ERR_INVALID, "inr_plan_create: in_features %d", d->in_features);
   if (d->input == INR_INPUT_GAUSS) {
-    if (d->enc_size < 4 || (d->enc_size % 4) != 0)
-      return fail(INR_ERR_UNSUPPORTED, "inr_plan_create: enc_size %d must be a positive multiple of 4", d->enc_size);
+    if (d->enc_size < 8 || (d->enc_size % 8) != 0)
+      return fail(INR_ERR_UNSUPPORTED, "inr_plan_create: enc_size %d must be a positive multiple of 8", d->enc_size);
     if (d->in_features != 2 * d->enc_size)
       return fail(INR_ERR_INVALID, "inr_plan_create: in_features %d != 2*enc_size %d", d->in_features,
                   2 * d->enc_size);
@@ -115,7 +119,8 @@ int inr_plan_create(const inr_net_desc* d, inr_plan** out) {
   }
   nd.P = poff;
   nd.slab_floats = round_up(poff + 4, 64);
-  nd.save_floats_per_tile = 2 * (nd.D - 1) * nd.NB * 32 * INR_TILE + 4 * INR_TILE;
+  nd.save_floats_per_tile = 2 * (nd.D - 1) * nd.NB * 32 * INR_TILE + 4 * INR_TILE +
+                            (d->input == INR_INPUT_GAUSS ? nd.L[0].Kblk * 32 * INR_TILE : 0);
   p->packed_floats = pk;
   *out = p;
   return INR_OK;
@@ -284,6 +289,9 @@ int inr_train_step(const inr_plan* plan, const inr_loss_desc* loss, const float*
   a.B = B;
   a.n_tiles = (int)nt;
   a.save_by_block = 1;
+#ifdef INR_STAMPS
+  a.dbg = g_stamp_buf;
+#endif
   LossDesc ld;
   to_loss_desc(loss, &ld);
   int rc = launch(plan, ld, a, 2, (int)nb, (hipStream_t)stream);
@@ -320,5 +328,12 @@ int inr_adam_step(const inr_plan* plan, float* params, const float* grads, float
   if (e != hipSuccess) return hip_fail(e, "inr_adam_step");
   return INR_OK;
 }
+
+#ifdef INR_STAMPS
+int inr_debug_set_stamp_buffer(long long* buf) {
+  g_stamp_buf = buf;
+  return INR_OK;
+}
+#endif
 
 }  // extern "C"

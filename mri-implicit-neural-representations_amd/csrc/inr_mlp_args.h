@@ -22,6 +22,7 @@ struct MlpArgs {
   long long B;
   int n_tiles;
   int save_by_block;   // 1: stash slot = blockIdx (fused); 0: slot = tile
+  long long* dbg;      // diagnostic builds (-DINR_STAMPS) only: per-wave phase time stamps
 };
 
 

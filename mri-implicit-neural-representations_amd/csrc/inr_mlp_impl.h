@@ -93,41 +93,74 @@ __device__ __forceinline__ void acc_to_lds(const f32x16 (&acc)[NBM], float* R, c
   }
 }
 
+// Ask the scheduler for  N x { 1 MFMA, VALU_PER VALU }  in this order: the transcendental / address
+// VALU work of k-step e+1 then issues in the shadow of the 64-cycle MFMAs of k-step e instead of
+// in a block between them (one wave per SIMD: nothing else would cover the idle matrix pipe).
+template <int N, int VALU_PER>
+__device__ __forceinline__ void interleave_mfma_valu() {
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);         // MFMA
+    __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER, 0);  // VALU
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // forward, layer 0, fused gauss encoder (networks.py:30-33):
 //   k-step s in [0,E): lane half 0 feeds sin(p_s) (feature s), half 1 feeds cos(p_s) (feature E+s)
 // ---------------------------------------------------------------------------------------------
-template <int NB>
+__device__ __forceinline__ float gauss_feature(const float* encB_lds, int s, float xs0, float xs1, float xs2,
+                                               int half) {
+  // encoder rows come from LDS (wave-uniform broadcast reads): a vector global load here would
+  // drag a vmcnt(0) behind it and drain the A-fragment prefetch every k-step
+  const float b0 = encB_lds[3 * s + 0], b1 = encB_lds[3 * s + 1], b2 = encB_lds[3 * s + 2];
+  const float ph = fmaf(xs2, b2, fmaf(xs1, b1, xs0 * b0));  // (2*pi*x) @ B^T, K = 3 (networks.py:31)
+  float sn, cs;
+  sincos_cw(ph, sn, cs);
+  return half ? cs : sn;
+}
+
+template <int NB, bool SAVE>
+__device__ __forceinline__ void gauss_group(f32x16 (&acc)[NB], const f32x4 (&a_use)[NB], f32x4 (&a_load)[NB],
+                                            const f32x4* p_next, const float* encB_lds, int s4_next, float xs0,
+                                            float xs1, float xs2, int half, const float (&b_use)[4],
+                                            float (&b_load)[4], float* __restrict__ sv_enc_s4) {
+  load_afrag<NB>(a_load, p_next);
+  __builtin_amdgcn_sched_barrier(0);  // the next group's A fragments fly behind this group's MFMAs
+  // the next group's four features: four independent sincos chains give the single resident wave
+  // the VALU ILP it needs, and they issue in the shadow of this group's 4*NB MFMAs
+#pragma unroll
+  for (int e = 0; e < 4; ++e) b_load[e] = gauss_feature(encB_lds, 4 * s4_next + e, xs0, xs1, xs2, half);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    if (SAVE) sv_enc_s4[e * INR_TILE] = b_use[e];  // feature row (half ? E : 0) + 4*s4 + e, reused by dW_0
+#pragma unroll
+    for (int m = 0; m < NB; ++m) acc[m] = mfma32(a_use[m][e], b_use[e], acc[m]);
+  }
+  interleave_mfma_valu<4 * NB, 5>();
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int NB, bool SAVE>
 __device__ __forceinline__ void fwd_layer0_gauss(f32x16 (&acc)[NB], const float* __restrict__ wp,
                                                  const float* encB_lds, int E, float xs0, float xs1, float xs2,
-                                                 int lane) {
+                                                 float* __restrict__ sv_enc, int wcol, int lane) {
   const int half = lane >> 5;
+  float* sve = SAVE ? sv_enc + (half ? E : 0) * INR_TILE + wcol : nullptr;
   const f32x4* p = reinterpret_cast<const f32x4*>(wp) + lane;
-  const int n4 = E >> 2;
-  f32x4 a_cur[NB], a_nxt[NB];
-  load_afrag<NB>(a_cur, p);
+  const int n4 = E >> 2;  // even (E % 8 == 0)
+  f32x4 A0[NB], A1[NB];
+  float F0[4], F1[4];
+  load_afrag<NB>(A0, p);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) F0[e] = gauss_feature(encB_lds, e, xs0, xs1, xs2, half);
 #pragma unroll 1
-  for (int s4 = 0; s4 < n4; ++s4) {
-    const int nx = (s4 + 1 < n4) ? (s4 + 1) : s4;
-    load_afrag<NB>(a_nxt, p + (size_t)nx * NB * 64);
-    __builtin_amdgcn_sched_barrier(0);  // keep the next group's loads at the top of the iteration
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int s = 4 * s4 + e;
-      // encoder rows come from LDS (wave-uniform broadcast reads): a vector global load here
-      // would drag a vmcnt(0) behind it and drain the A-fragment prefetch every k-step
-      const float b0 = encB_lds[3 * s + 0], b1 = encB_lds[3 * s + 1], b2 = encB_lds[3 * s + 2];
-      // (2*pi*x) @ B^T, K = 3 (networks.py:31)
-      const float ph = fmaf(xs2, b2, fmaf(xs1, b1, xs0 * b0));
-      float sn, cs;
-      sincos_cw(ph, sn, cs);
-      const float b = half ? cs : sn;
-#pragma unroll
-      for (int m = 0; m < NB; ++m) acc[m] = mfma32(a_cur[m][e], b, acc[m]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int m = 0; m < NB; ++m) a_cur[m] = a_nxt[m];
+  for (int s4 = 0; s4 < n4; s4 += 2) {
+    const int n2 = (s4 + 2 < n4) ? (s4 + 2) : s4;
+    gauss_group<NB, SAVE>(acc, A0, A1, p + (size_t)(s4 + 1) * NB * 64, encB_lds, s4 + 1, xs0, xs1, xs2, half, F0, F1,
+                          sve + 4 * s4 * INR_TILE);
+    gauss_group<NB, SAVE>(acc, A1, A0, p + (size_t)n2 * NB * 64, encB_lds, n2, xs0, xs1, xs2, half, F1, F0,
+                          sve + 4 * (s4 + 1) * INR_TILE);
   }
 }
 
@@ -159,54 +192,100 @@ __device__ __forceinline__ void fwd_layer0_x(f32x16 (&acc)[NB], const float* __r
 }
 
 // ---------------------------------------------------------------------------------------------
-// forward, layer l >= 1: B operand = act(z_{l-1}) formed lazily from the LDS image.
-//   sv_h / sv_d: stash rows [feature][128 coords] for the backward pass (may be null).
+// forward, layer l >= 1: B operand = act(z_{l-1}) formed lazily from the LDS image, one k-step
+// ahead of the MFMAs that consume it.
+//   sv_h / sv_d: stash rows [feature][128 coords] for the backward pass.
 // ---------------------------------------------------------------------------------------------
+template <int NBOUT, int HACT, bool SAVE>
+__device__ __forceinline__ void fwd_group(f32x16 (&acc)[NBOUT], const f32x4 (&a_use)[NBOUT],
+                                          f32x4 (&a_load)[NBOUT], const f32x4* p_next, float (&z_buf)[4],
+                                          const float* Rl_next2, int s4, float w0, float* __restrict__ sv_h,
+                                          float* __restrict__ sv_d, const float (&h_use)[4],
+                                          const float (&d_use)[4], float (&h_load)[4], float (&d_load)[4]) {
+  // z_buf holds the pre-activations of group s4+1 (fetched one group ago); they become h_load/d_load
+  // during this group's MFMAs, and z_buf is refilled with group s4+2.
+  load_afrag<NBOUT>(a_load, p_next);
+  float z_next[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) z_next[e] = Rl_next2[(2 * e) * INR_LDS_LD];
+  __builtin_amdgcn_sched_barrier(0);  // operands of the following groups are in flight behind the MFMAs
+#pragma unroll
+  for (int e = 0; e < 4; ++e) act_fwd<HACT>(z_buf[e], w0, h_load[e], d_load[e]);  // 4 independent chains
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    if (SAVE) {
+      sv_h[(8 * s4 + 2 * e) * INR_TILE] = h_use[e];
+      sv_d[(8 * s4 + 2 * e) * INR_TILE] = d_use[e];
+    }
+#pragma unroll
+    for (int m = 0; m < NBOUT; ++m) acc[m] = mfma32(a_use[m][e], h_use[e], acc[m]);
+  }
+  if (NBOUT >= 4) interleave_mfma_valu<4 * NBOUT, (40 + NBOUT - 1) / NBOUT>();
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) z_buf[e] = z_next[e];
+}
+
 template <int NB, int NBOUT, int HACT, bool SAVE>
 __device__ __forceinline__ void fwd_layer(f32x16 (&acc)[NBOUT], const float* R, const float* __restrict__ wp,
                                           float w0, float* __restrict__ sv_h, float* __restrict__ sv_d, int wcol,
                                           int lane) {
   const int half = lane >> 5, col = lane & 31;
   const f32x4* p = reinterpret_cast<const f32x4*>(wp) + lane;
-  constexpr int n4 = NB * 4;  // K = 32*NB features -> 16*NB k-steps -> 4*NB groups of 4
+  constexpr int n4 = NB * 4;  // K = 32*NB features -> 16*NB k-steps -> 4*NB groups of 4 (even)
   const float* Rl = R + half * INR_LDS_LD + col;  // row k = 2*(4*s4+e) + half
-  f32x4 a_cur[NBOUT], a_nxt[NBOUT];
-  float z_cur[4], z_nxt[4];
-  load_afrag<NBOUT>(a_cur, p);
+  float* svh = SAVE ? sv_h + half * INR_TILE + wcol : nullptr;
+  float* svd = SAVE ? sv_d + half * INR_TILE + wcol : nullptr;
+  f32x4 A0[NBOUT], A1[NBOUT];
+  float Z[4], H0[4], D0[4], H1[4], D1[4];
+  load_afrag<NBOUT>(A0, p);
 #pragma unroll
-  for (int e = 0; e < 4; ++e) z_cur[e] = Rl[(2 * e) * INR_LDS_LD];
+  for (int e = 0; e < 4; ++e) {
+    act_fwd<HACT>(Rl[(2 * e) * INR_LDS_LD], w0, H0[e], D0[e]);
+    Z[e] = Rl[(8 + 2 * e) * INR_LDS_LD];  // group 1 (n4 >= 4)
+  }
 #pragma unroll 1
-  for (int s4 = 0; s4 < n4; ++s4) {
-    const int nx = (s4 + 1 < n4) ? (s4 + 1) : s4;
-    load_afrag<NBOUT>(a_nxt, p + (size_t)nx * NBOUT * 64);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) z_nxt[e] = Rl[(8 * nx + 2 * e) * INR_LDS_LD];
-    __builtin_amdgcn_sched_barrier(0);  // next group's operands are in flight behind this group's MFMAs
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int k = 2 * (4 * s4 + e) + half;
-      float h, d;
-      act_fwd<HACT>(z_cur[e], w0, h, d);
-      if (SAVE) {
-        sv_h[k * INR_TILE + wcol] = h;
-        sv_d[k * INR_TILE + wcol] = d;
-      }
-#pragma unroll
-      for (int m = 0; m < NBOUT; ++m) acc[m] = mfma32(a_cur[m][e], h, acc[m]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int m = 0; m < NBOUT; ++m) a_cur[m] = a_nxt[m];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) z_cur[e] = z_nxt[e];
+  for (int s4 = 0; s4 < n4; s4 += 2) {
+    const int n2 = (s4 + 2 < n4) ? (s4 + 2) : s4;
+    const int n3 = (s4 + 3 < n4) ? (s4 + 3) : s4;
+    fwd_group<NBOUT, HACT, SAVE>(acc, A0, A1, p + (size_t)(s4 + 1) * NBOUT * 64, Z, Rl + 8 * n2 * INR_LDS_LD, s4, w0,
+                                 svh, svd, H0, D0, H1, D1);
+    fwd_group<NBOUT, HACT, SAVE>(acc, A1, A0, p + (size_t)n2 * NBOUT * 64, Z, Rl + 8 * n3 * INR_LDS_LD, s4 + 1, w0,
+                                 svh, svd, H1, D1, H0, D0);
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-// backward: dH_{l-1}^T = W_l^T . dZ_l^T.  R holds dH_l (sv_d != null: multiplied in place by
-// act'(z_l) to give dZ_l, which dW then reads) or dZ_l itself (sv_d == null, last layer).
-//   k extent = Mpad8 of layer l.
+// backward: dH_{l-1}^T = W_l^T . dZ_l^T.  R holds dH_l (HASD: multiplied in place by act'(z_l)
+// to give dZ_l, which dW then reads) or dZ_l itself (last layer).  k extent = Mpad8 of layer l.
 // ---------------------------------------------------------------------------------------------
+template <int NB, bool HASD>
+__device__ __forceinline__ void dx_group(f32x16 (&acc)[NB], const f32x4 (&a_use)[NB], f32x4 (&a_load)[NB],
+                                         const f32x4* p_next, const float (&g_use)[4], float (&g_load)[4],
+                                         const float (&d_use)[4], float (&d_load)[4], float* Rl_cur,
+                                         const float* Rl_next, const float* dl_next, bool prefetch) {
+  if (prefetch) {
+    load_afrag<NB>(a_load, p_next);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      g_load[e] = Rl_next[(2 * e) * INR_LDS_LD];
+      d_load[e] = HASD ? dl_next[(2 * e) * INR_TILE] : 1.f;
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float g = g_use[e];
+    if (HASD) {
+      g *= d_use[e];
+      Rl_cur[(2 * e) * INR_LDS_LD] = g;  // dZ_l, read again by dW (rows of the next group are untouched)
+    }
+#pragma unroll
+    for (int m = 0; m < NB; ++m) acc[m] = mfma32(a_use[m][e], g, acc[m]);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 template <int NB, bool HASD>
 __device__ __forceinline__ void bwd_dx(f32x16 (&acc)[NB], float* R, const float* __restrict__ wpT, int Mpad8,
                                        const float* __restrict__ sv_d, int wcol, int lane) {
@@ -215,51 +294,59 @@ __device__ __forceinline__ void bwd_dx(f32x16 (&acc)[NB], float* R, const float*
   const int n4 = Mpad8 >> 3;
   float* Rl = R + half * INR_LDS_LD + col;
   const float* dl = HASD ? sv_d + half * INR_TILE + wcol : nullptr;
-  f32x4 a_cur[NB], a_nxt[NB];
-  float g_cur[4], g_nxt[4], d_cur[4], d_nxt[4];
-  load_afrag<NB>(a_cur, p);
+  f32x4 A0[NB], A1[NB];
+  float G0[4], G1[4], D0[4], D1[4];
+  load_afrag<NB>(A0, p);
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    g_cur[e] = Rl[(2 * e) * INR_LDS_LD];
-    d_cur[e] = HASD ? dl[(2 * e) * INR_TILE] : 1.f;
+    G0[e] = Rl[(2 * e) * INR_LDS_LD];
+    D0[e] = HASD ? dl[(2 * e) * INR_TILE] : 1.f;
+  }
+  if (n4 == 1) {  // last layer: out_features <= 8 -> a single group
+    dx_group<NB, HASD>(acc, A0, A1, p, G0, G1, D0, D1, Rl, Rl, dl, false);
+    return;
   }
 #pragma unroll 1
-  for (int s4 = 0; s4 < n4; ++s4) {
-    const int nx = (s4 + 1 < n4) ? (s4 + 1) : s4;
-    load_afrag<NB>(a_nxt, p + (size_t)nx * NB * 64);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      g_nxt[e] = Rl[(8 * nx + 2 * e) * INR_LDS_LD];
-      d_nxt[e] = HASD ? dl[(8 * nx + 2 * e) * INR_TILE] : 1.f;
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float g = g_cur[e];
-      if (HASD) {
-        g *= d_cur[e];
-        Rl[(8 * s4 + 2 * e) * INR_LDS_LD] = g;  // dZ_l, read again by dW (rows of group nx are untouched)
-      }
-#pragma unroll
-      for (int m = 0; m < NB; ++m) acc[m] = mfma32(a_cur[m][e], g, acc[m]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int m = 0; m < NB; ++m) a_cur[m] = a_nxt[m];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      g_cur[e] = g_nxt[e];
-      d_cur[e] = d_nxt[e];
-    }
+  for (int s4 = 0; s4 < n4; s4 += 2) {  // n4 even for hidden layers (width % 64 == 0 or NB*4 groups)
+    const int n2 = (s4 + 2 < n4) ? (s4 + 2) : s4;
+    dx_group<NB, HASD>(acc, A0, A1, p + (size_t)(s4 + 1) * NB * 64, G0, G1, D0, D1, Rl + 8 * s4 * INR_LDS_LD,
+                       Rl + 8 * (s4 + 1) * INR_LDS_LD, HASD ? dl + 8 * (s4 + 1) * INR_TILE : nullptr, true);
+    dx_group<NB, HASD>(acc, A1, A0, p + (size_t)n2 * NB * 64, G1, G0, D1, D0, Rl + 8 * (s4 + 1) * INR_LDS_LD,
+                       Rl + 8 * n2 * INR_LDS_LD, HASD ? dl + 8 * n2 * INR_TILE : nullptr, true);
   }
 }
 
-// first layer: only dZ_0 = dH_0 * act'(z_0), in place (there is no dX for the input)
-__device__ __forceinline__ void bwd_dz_inplace(float* R, int nfeat, const float* __restrict__ sv_d, int wcol,
-                                               int lane) {
+// first layer: dZ_0 = dH_0 * act'(z_0) is formed while the dX accumulators are stored to the image
+// (there is no dX for the input): 16*NBM independent coalesced stash loads, all in flight together.
+// Buffer descriptor from a wave-uniform pointer (readfirstlane makes the uniformity provable, so
+// hipcc emits plain buffer_load ... offen with an SGPR descriptor instead of waterfall loops or --
+// worse -- 128 hoisted 64-bit VGPR addresses that it then spills around the tile loop).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* p, int bytes) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  void* q = reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
+  return __builtin_amdgcn_make_buffer_rsrc(q, 0, bytes, 0x00020000);
+}
+
+template <int NBM>
+__device__ __forceinline__ void acc_times_d_to_lds(const f32x16 (&acc)[NBM], float* R,
+                                                   const float* __restrict__ sv_d, int wcol, int lane) {
   const int half = lane >> 5, col = lane & 31;
-  for (int k = half; k < nfeat; k += 2) {
-    R[swz(k, col)] *= sv_d[k * INR_TILE + wcol];
+  float* Rl = R + (4 * half) * INR_LDS_LD + col;
+  const __amdgpu_buffer_rsrc_t rs = uniform_rsrc(sv_d, NBM * 32 * INR_TILE * 4);
+  const int voff = ((4 * half) * INR_TILE + wcol) * 4;  // one per-lane byte offset for all 16*NBM loads
+#pragma unroll
+  for (int m = 0; m < NBM; ++m) {
+    float d[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      d[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                           rs, voff, (32 * m + (r & 3) + 8 * (r >> 2)) * INR_TILE * 4, 0));
+    __builtin_amdgcn_sched_barrier(0);  // all 16 loads of the block in flight before the first use
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Rl[(32 * m + (r & 3) + 8 * (r >> 2)) * INR_LDS_LD] = acc[m][r] * d[r];
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -270,6 +357,7 @@ __device__ __forceinline__ void bwd_dz_inplace(float* R, int nfeat, const float*
 //   k order: group q of 8 coordinates -> half h takes coords 8q+4h+(0..3) as 4 k-steps.
 // ---------------------------------------------------------------------------------------------
 struct BSrcStash {  // h_{l-1} stash [feature][128]
+  static constexpr int kValuPerMfma = 1;
   const float* __restrict__ h;
   struct Raw { f32x4 v; };
   __device__ __forceinline__ void begin(int, int) {}
@@ -281,6 +369,7 @@ struct BSrcStash {  // h_{l-1} stash [feature][128]
 };
 
 struct BSrcX {  // x [B,K0] row-major
+  static constexpr int kValuPerMfma = 1;
   const float* __restrict__ x;
   long long row0, B;
   int K0;
@@ -301,52 +390,28 @@ struct BSrcX {  // x [B,K0] row-major
   __device__ __forceinline__ f32x4 finish(const Raw& r) const { return r.v; }
 };
 
-struct BSrcGauss {  // recompute the Fourier features of the tile's coordinates (never stored)
-  const float* __restrict__ coords;
-  const float* __restrict__ encB;
-  long long row0, B;
-  int E;
-  float b0, b1, b2;
-  bool is_cos;
-  struct Raw { float x[4][3]; };
-  __device__ __forceinline__ void begin(int n, int lane) {
-    const int f = 32 * n + (lane & 31);
-    is_cos = f >= E;
-    const int s = is_cos ? f - E : f;
-    b0 = b1 = b2 = 0.f;
-    if (s < E) {  // columns >= 2E are padding of the last 32-wide block (masked on store)
-      b0 = encB[3 * s + 0];
-      b1 = encB[3 * s + 1];
-      b2 = encB[3 * s + 2];
-    }
-  }
-  __device__ __forceinline__ Raw fetch(int, int q, int lane) const {
-    Raw r;
+template <int MT, class BSrc>
+__device__ __forceinline__ void dw_group(f32x16 (&acc)[MT], float (&bsum)[MT], const float (&a_use)[4][MT],
+                                         float (&a_load)[4][MT], const f32x4& b_use, f32x4& b_load, BSrc& bsrc,
+                                         int n, int q_next, const float* Rq_next, int lane) {
+  const typename BSrc::Raw raw = bsrc.fetch(n, q_next, lane);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const long long row = row0 + 8 * q + 4 * (lane >> 5) + e;
-      const bool ok = row < B;
-      const float* c = coords + (ok ? 3 * row : 0);
-      const float x0 = c[0], x1 = c[1], x2 = c[2];
-      r.x[e][0] = ok ? x0 : 0.f;
-      r.x[e][1] = ok ? x1 : 0.f;
-      r.x[e][2] = ok ? x2 : 0.f;
-    }
-    return r;
-  }
-  __device__ __forceinline__ f32x4 finish(const Raw& r) const {
-    f32x4 v;
-    const float two_pi = 6.283185307179586f;
+  for (int e = 0; e < 4; ++e)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float ph = fmaf(two_pi * r.x[e][2], b2, fmaf(two_pi * r.x[e][1], b1, (two_pi * r.x[e][0]) * b0));
-      float sn, cs;
-      sincos_cw(ph, sn, cs);
-      v[e] = is_cos ? cs : sn;
+    for (int m = 0; m < MT; ++m) a_load[e][m] = Rq_next[32 * m * INR_LDS_LD + e];
+  __builtin_amdgcn_sched_barrier(0);
+  b_load = bsrc.finish(raw);  // ALU part (sincos for the encoder source) interleaves with the MFMAs
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      bsum[m] += a_use[e][m];
+      acc[m] = mfma32(a_use[e][m], b_use[e], acc[m]);
     }
-    return v;
   }
-};
+  if (MT >= 4) interleave_mfma_valu<4 * MT, BSrc::kValuPerMfma>();
+  __builtin_amdgcn_sched_barrier(0);
+}
 
 template <int MT, bool FULLM, class BSrc>
 __device__ __forceinline__ void dw_pass(const float* Rall, int region_stride, BSrc& bsrc, int n, float* slab_w,
@@ -374,39 +439,20 @@ __device__ __forceinline__ void dw_pass(const float* Rall, int region_stride, BS
   }
   bsrc.begin(n, lane);
   const float* Rl = Rall + li * INR_LDS_LD + 4 * half;
-  // software pipeline: operands of coordinate group q+1 are fetched while group q is multiplied
-  f32x4 bv_cur = bsrc.finish(bsrc.fetch(n, 0, lane)), bv_nxt;
-  float a_cur[4][MT], a_nxt[4][MT];
+  // software pipeline over groups q of 8 coordinates: operands of group q+1 are fetched while
+  // group q is multiplied; coordinate 8q + 4*half + e lives in wave image q>>2, column 8(q&3)+4*half+e
+  f32x4 B0 = bsrc.finish(bsrc.fetch(n, 0, lane)), B1;
+  float A0[4][MT], A1[4][MT];
 #pragma unroll
   for (int e = 0; e < 4; ++e)
 #pragma unroll
-    for (int m = 0; m < MT; ++m) a_cur[e][m] = Rl[32 * m * INR_LDS_LD + e];
+    for (int m = 0; m < MT; ++m) A0[e][m] = Rl[32 * m * INR_LDS_LD + e];
 #pragma unroll 1
-  for (int q = 0; q < INR_TILE / 8; ++q) {
-    const int qn = (q + 1 < INR_TILE / 8) ? q + 1 : q;
-    const typename BSrc::Raw raw = bsrc.fetch(n, qn, lane);
-    // coordinate 8q + 4*half + e lives in wave image q>>2, column 8(q&3) + 4*half + e
-    const float* Rq = Rl + (qn >> 2) * region_stride + 8 * (qn & 3);
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-#pragma unroll
-      for (int m = 0; m < MT; ++m) a_nxt[e][m] = Rq[32 * m * INR_LDS_LD + e];
-    __builtin_amdgcn_sched_barrier(0);
-    bv_nxt = bsrc.finish(raw);  // ALU part (sincos for the encoder source) interleaves with the MFMAs
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        bsum[m] += a_cur[e][m];
-        acc[m] = mfma32(a_cur[e][m], bv_cur[e], acc[m]);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    bv_cur = bv_nxt;
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-#pragma unroll
-      for (int m = 0; m < MT; ++m) a_cur[e][m] = a_nxt[e][m];
+  for (int q = 0; q < INR_TILE / 8; q += 2) {
+    const int q2 = (q + 2 < INR_TILE / 8) ? q + 2 : q;
+    dw_group<MT, BSrc>(acc, bsum, A0, A1, B0, B1, bsrc, n, q + 1, Rl + ((q + 1) >> 2) * region_stride + 8 * ((q + 1) & 3),
+                       lane);
+    dw_group<MT, BSrc>(acc, bsum, A1, A0, B1, B0, bsrc, n, q2, Rl + (q2 >> 2) * region_stride + 8 * (q2 & 3), lane);
   }
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
@@ -437,6 +483,19 @@ __device__ __forceinline__ void dw_pass(const float* Rall, int region_stride, BS
 // the kernel.  MODE 0: forward (save optional); 1: backward from dout + save; 2: fused
 // forward + pointwise loss + backward.
 // ---------------------------------------------------------------------------------------------
+// Diagnostic phase stamps (never compiled into the shipped library): s_memtime per wave at phase
+// boundaries, written to a buffer nothing else reads.
+#ifdef INR_STAMPS
+#define INR_STAMP(i)                                                                         \
+  do {                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    if (a.dbg != nullptr && lane == 0) a.dbg[(blockIdx.x * INR_WAVES + w) * 64 + (i)] = (long long)__builtin_amdgcn_s_memtime(); \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+  } while (0)
+#else
+#define INR_STAMP(i) do {} while (0)
+#endif
+
 template <int NB, int INMODE, int HACT, int MODE>
 __global__ __launch_bounds__(256) void inr_mlp_kernel(const NetDesc nd, const LossDesc ld, const MlpArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -469,6 +528,7 @@ __global__ __launch_bounds__(256) void inr_mlp_kernel(const NetDesc nd, const Lo
     float* sv_last = sv + (size_t)2 * (D - 1) * HSZ;  // [4][128]: act'(z_last) of output rows 0..3
 
     // ================================ forward =================================
+    INR_STAMP(0);
     if (MODE != MODE_BWD) {
       {
         f32x16 acc[NB];
@@ -483,13 +543,20 @@ __global__ __launch_bounds__(256) void inr_mlp_kernel(const NetDesc nd, const Lo
             x2 = a.x[3 * crow + 2];
           }
           const float two_pi = 6.283185307179586f;
-          fwd_layer0_gauss<NB>(acc, a.packed + L0.pf_off, encB_lds, nd.E, two_pi * x0, two_pi * x1, two_pi * x2, lane);
+          float* sv_enc = sv_last + 4 * INR_TILE;  // [Kblk0*32][128] encoder features (rows >= 2E unused)
+          if (saving)
+            fwd_layer0_gauss<NB, true>(acc, a.packed + L0.pf_off, encB_lds, nd.E, two_pi * x0, two_pi * x1,
+                                       two_pi * x2, sv_enc, wcol, lane);
+          else
+            fwd_layer0_gauss<NB, false>(acc, a.packed + L0.pf_off, encB_lds, nd.E, two_pi * x0, two_pi * x1,
+                                        two_pi * x2, nullptr, wcol, lane);
         } else {
           fwd_layer0_x<NB>(acc, a.packed + L0.pf_off, a.x + (size_t)(valid ? crow : 0) * L0.K, valid, L0.K, L0.Kpad8,
                            lane);
         }
         acc_to_lds<NB, true>(acc, R, a.params + L0.b_off, lane);
       }
+      INR_STAMP(1);
       for (int l = 1; l < D - 1; ++l) {
         const LayerDesc& Ll = nd.L[l];
         f32x16 acc[NB];
@@ -501,6 +568,7 @@ __global__ __launch_bounds__(256) void inr_mlp_kernel(const NetDesc nd, const Lo
         else
           fwd_layer<NB, NB, HACT, false>(acc, R, a.packed + Ll.pf_off, w0, nullptr, nullptr, wcol, lane);
         acc_to_lds<NB, true>(acc, R, a.params + Ll.b_off, lane);
+        INR_STAMP(1 + l);
       }
       // last layer: out_f <= 4 rows -> registers 0..3 of the lane-half-0 lanes of one row block
       f32x16 accL[1];
@@ -544,6 +612,7 @@ __global__ __launch_bounds__(256) void inr_mlp_kernel(const NetDesc nd, const Lo
     }
 
     // ================================ backward ================================
+    INR_STAMP(10);
     if (MODE != MODE_FWD) {
       if (MODE == MODE_BWD) {
 #pragma unroll
@@ -555,6 +624,7 @@ __global__ __launch_bounds__(256) void inr_mlp_kernel(const NetDesc nd, const Lo
         }
       }
       __syncthreads();  // every wave's dZ_last is in LDS
+      INR_STAMP(11);
       // ---- last layer: dW, db from (dZ_last, h_{D-2}); dH_{D-2} = W_last^T dZ_last
       {
         BSrcStash bs{sv + (size_t)(2 * (D - 2)) * HSZ};
@@ -562,12 +632,17 @@ __global__ __launch_bounds__(256) void inr_mlp_kernel(const NetDesc nd, const Lo
           dw_pass<1, false, BSrcStash>(lds, RS, bs, n, slab + LL.w_off, slab + LL.b_off, LL.M, LL.K, first, n == 0,
                                        lane);
       }
+      INR_STAMP(12);
       f32x16 gacc[NB];
 #pragma unroll
       for (int m = 0; m < NB; ++m) gacc[m] = zero16();
       bwd_dx<NB, false>(gacc, R, a.packed + LL.pb_off, LL.Mpad8, nullptr, wcol, lane);
       __syncthreads();  // all dW reads of the images are done
-      acc_to_lds<NB, false>(gacc, R, nullptr, lane);  // R <- dH_{D-2}
+      if (D == 2)
+        acc_times_d_to_lds<NB>(gacc, R, sv + (size_t)1 * HSZ, wcol, lane);  // R <- dZ_0
+      else
+        acc_to_lds<NB, false>(gacc, R, nullptr, lane);  // R <- dH_{D-2}
+      INR_STAMP(13);
 
       for (int l = D - 2; l >= 1; --l) {
         const LayerDesc& Ll = nd.L[l];
@@ -575,32 +650,41 @@ __global__ __launch_bounds__(256) void inr_mlp_kernel(const NetDesc nd, const Lo
         for (int m = 0; m < NB; ++m) gacc[m] = zero16();
         // dZ_l = dH_l * act'(z_l) (in place), dH_{l-1} = W_l^T dZ_l
         bwd_dx<NB, true>(gacc, R, a.packed + Ll.pb_off, Ll.Mpad8, sv + (size_t)(2 * l + 1) * HSZ, wcol, lane);
+        INR_STAMP(14 + 4 * l);
         __syncthreads();
+        INR_STAMP(15 + 4 * l);
         {
           BSrcStash bs{sv + (size_t)(2 * (l - 1)) * HSZ};
           for (int n = w; n < Ll.Kblk; n += INR_WAVES)
             dw_pass<NB, true, BSrcStash>(lds, RS, bs, n, slab + Ll.w_off, slab + Ll.b_off, Ll.M, Ll.K, first, n == 0,
                                          lane);
         }
+        INR_STAMP(16 + 4 * l);
         __syncthreads();
-        acc_to_lds<NB, false>(gacc, R, nullptr, lane);
+        if (l == 1)
+          acc_times_d_to_lds<NB>(gacc, R, sv + (size_t)1 * HSZ, wcol, lane);  // R <- dZ_0
+        else
+          acc_to_lds<NB, false>(gacc, R, nullptr, lane);                       // R <- dH_{l-1}
+        INR_STAMP(17 + 4 * l);
       }
       // ---- first layer: dZ_0 in place, then dW_0 against the (recomputed) input features
       {
         const LayerDesc& L0 = nd.L[0];
-        bwd_dz_inplace(R, NB * 32, sv + (size_t)1 * HSZ, wcol, lane);
-        __syncthreads();
+        __syncthreads();  // every wave's dZ_0 is in LDS
+        INR_STAMP(40);
         if (INMODE == IN_GAUSS) {
-          BSrcGauss bs{a.x, a.encB, row0, a.B, nd.E, 0.f, 0.f, 0.f, false};
+          BSrcStash bs{sv_last + 4 * INR_TILE};
           for (int n = w; n < L0.Kblk; n += INR_WAVES)
-            dw_pass<NB, true, BSrcGauss>(lds, RS, bs, n, slab + L0.w_off, slab + L0.b_off, L0.M, L0.K, first, n == 0,
+            dw_pass<NB, true, BSrcStash>(lds, RS, bs, n, slab + L0.w_off, slab + L0.b_off, L0.M, L0.K, first, n == 0,
                                          lane);
         } else {
           BSrcX bs{a.x, row0, a.B, L0.K};
           for (int n = w; n < L0.Kblk; n += INR_WAVES)
             dw_pass<NB, true, BSrcX>(lds, RS, bs, n, slab + L0.w_off, slab + L0.b_off, L0.M, L0.K, first, n == 0, lane);
         }
+        INR_STAMP(41);
         __syncthreads();  // images are overwritten by the next tile's forward / dZ_last
+        INR_STAMP(42);
       }
       first = false;
     }

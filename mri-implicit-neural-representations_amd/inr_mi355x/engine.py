@@ -108,7 +108,7 @@ class MLPEngine:
     def _ws_save(self, n_slots: int) -> torch.Tensor:
         need = n_slots * self.save_floats_per_tile
         if self._save is None or self._save.numel() < need:
-            self._save = torch.empty(need, device=self.params.device)
+            self._save = torch.zeros(need, device=self.params.device)
         return self._save
 
     def _ws_slabs(self, n_blocks: int) -> torch.Tensor:
