@@ -38,11 +38,24 @@ CONFIG = {
 SHAPE = (15, 640, 368)
 
 
+def usable_cores() -> int:
+    """Host threads this job may actually use: affinity mask, cgroup quota, and the GPU box's
+    per-GPU CPU share (16) -- oversubscribing 256 visible cores made the first baseline 40x slower."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return int(os.environ.get("INR_CPU_THREADS", min(n, 16)))
+
+
 def cpu_baseline(image, coords, seconds=12.0):
     """The oracle (CPU restatement of the reference's step: encode -> SIREN -> 0.5*MSE -> autograd
     -> Adam), timed on this host's cores on a bounded number of 25 000-row steps."""
     import oracle as O
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(usable_cores())
     cfg = dict(CONFIG)
     torch.manual_seed(0)
     B = O.encoder_init(cfg["encoder"])
@@ -156,6 +169,15 @@ def main():
     torch.cuda.synchronize()
     k_ms = e0.elapsed_time(e1) / reps
     achieved = FLOP_PER_SAMPLE * args.batch / (k_ms * 1e-3) / 1e12
+    # HBM bytes per launch come from separate rocprofv3 --pmc passes (cannot be collected from inside
+    # this process); the committed summary applies only to the workload it was measured on.
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
+        if args.batch == 25000:
+            traffic = tj["bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
 
     out = {
         "metric": "coord-samples/sec (fwd+bwd) fitting 640x368x15-coil k-space; PSNR@1k steps",
@@ -167,7 +189,7 @@ def main():
                    "parallelism": f"dp{world}" if world > 1 else "single"},
         "roofline": {"bound": "mfma", "kernel": "inr_mlp_kernel<8,GAUSS,SIN,FUSED>", "achieved": achieved,
                      "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS,
-                     "kernel_ms": k_ms, "traffic": None,
+                     "kernel_ms": k_ms, "traffic": traffic,
                      "note": "exact-fp32 path (v_mfma_f32_32x32x2_f32); peak = dense f32 MFMA"},
     }
     if world == 1 and rank == 0:

@@ -63,6 +63,20 @@ def shard_rows(lo: int, hi: int, rank: int, world: int):
     return lo + (rank * n) // world, lo + ((rank + 1) * n) // world
 
 
+def allreduce_step_outputs(grads: torch.Tensor, loss: torch.Tensor, world: int, group=None) -> torch.Tensor:
+    """The one exchange step of the data-parallel path: every rank holds the partial
+    sums of its contiguous row shard, already divided by the GLOBAL row count, so a plain SUM
+    all-reduce (RCCL over xGMI on the GPU box, gloo in the CPU tests) of the flat fp32 gradient and
+    of the loss scalar reproduces the single-GPU step up to summation order.  In place on `grads`."""
+    if world <= 1:
+        return loss
+    import torch.distributed as dist
+    dist.all_reduce(grads, op=dist.ReduceOp.SUM, group=group)
+    loss = loss.clone()
+    dist.all_reduce(loss, op=dist.ReduceOp.SUM, group=group)
+    return loss
+
+
 class INRTrainer:
     def __init__(self, config: dict, image: torch.Tensor, coords: torch.Tensor, shape, device,
                  seed: int = 0, mask: Optional[torch.Tensor] = None, rank: int = 0, world: int = 1,
@@ -133,12 +147,7 @@ class INRTrainer:
         m = self.mask[slo:shi] if self.mask is not None else None
         loss = self.engine.train_step(self._inputs(slo, shi), self.enc_B, self.image[slo:shi], self.loss,
                                       count=count, mask=m, hdr_A=A)
-        if self.world > 1:
-            import torch.distributed as dist
-            # un-normalised-by-rank partial sums: every rank divided by the GLOBAL count already
-            dist.all_reduce(self.engine.grads, op=dist.ReduceOp.SUM, group=self.pg)
-            loss = loss.clone()
-            dist.all_reduce(loss, op=dist.ReduceOp.SUM, group=self.pg)
+        loss = allreduce_step_outputs(self.engine.grads, loss, self.world, self.pg)
         lr = self.config["lr"] * lr_factor(epoch, self.config["max_epoch"])
         self.engine.adam_step(lr, self.config["beta1"], self.config["beta2"], 1e-8, self.config["weight_decay"],
                               self.l1, self.l2)
