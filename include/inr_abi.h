@@ -16,7 +16,10 @@
  * Parameter layout ("flat params", P floats): layer k's weight [M_k, K_k] (PyTorch [out,in]
  * layout) followed by its bias [M_k], k = 0..D-1 -- i.e. the reference's state_dict order
  * (SIREN: model.{k}.linear.weight/bias, networks.py:79,114-117; FFN: model.{2k}.weight/bias,
- * networks.py:57-62).  Gradients and Adam moments use the same layout.
+ * networks.py:57-62; WIRE: net.{k}.linear.weight/bias + net.{depth+1}.weight/bias with complex64
+ * tensors stored as interleaved (re, im) float pairs = torch.view_as_real; the frozen
+ * omega_0/scale_0 Parameters are NOT part of the flat buffer).  Gradients (torch's convention
+ * dL/dRe + j dL/dIm for complex tensors) and Adam moments use the same layout.
  */
 #ifndef INR_ABI_H
 #define INR_ABI_H
@@ -39,7 +42,8 @@ extern "C" {
 /* network family: which reference class the plan mirrors */
 enum inr_kind {
   INR_KIND_SIREN = 0, /* models/networks.py:99-124  SIREN / SirenLayer :74-96 */
-  INR_KIND_FFN = 1    /* models/networks.py:48-69   FFN (ReLU hidden, Sigmoid output) */
+  INR_KIND_FFN = 1,   /* models/networks.py:48-69   FFN (ReLU hidden, Sigmoid output) */
+  INR_KIND_WIRE = 2   /* models/networks.py:206-260 WIRE / ComplexGaborLayer :160-204 (complex64 layers) */
 };
 
 /* activation of the last layer */
@@ -71,14 +75,19 @@ enum inr_loss {
 typedef struct inr_net_desc {
   int32_t kind;         /* enum inr_kind */
   int32_t in_features;  /* net.network_input_size */
-  int32_t width;        /* net.network_width (hidden), multiple of 32, <= 256 */
-  int32_t depth;        /* net.network_depth = number of Linear layers (>= 2) */
+  int32_t width;        /* hidden features: net.network_width for SIREN/FFN (32 or 256); for WIRE the number of
+                           COMPLEX hidden features, int(network_width / sqrt(2)) (networks.py:228): <= 32 or 181 */
+  int32_t depth;        /* net.network_depth as the reference counts it: all Linear layers for SIREN/FFN,
+                           hidden complex layers only for WIRE (total Linear = depth + 2) */
   int32_t out_features; /* net.network_output_size, <= 32 */
   int32_t last_act;     /* enum inr_act */
   int32_t input;        /* enum inr_input */
   int32_t enc_size;     /* E (encoder.embedding_size) when input == INR_INPUT_GAUSS */
-  float w0;             /* 30 for SIREN (networks.py:75); ignored for FFN */
-  int32_t reserved[7];
+  float w0;             /* 30 for SIREN (networks.py:75); ignored otherwise */
+  float first_omega_0;  /* WIRE net.first_omega_0 */
+  float hidden_omega_0; /* WIRE net.hidden_omega_0 */
+  float scale_0;        /* WIRE net.scale */
+  int32_t reserved[4];
 } inr_net_desc;
 
 typedef struct inr_loss_desc {

@@ -60,15 +60,37 @@ int inr_last_error(char* buf, size_t cap) {
 int inr_plan_create(const inr_net_desc* d, inr_plan** out) {
   if (d == nullptr || out == nullptr) return fail(INR_ERR_INVALID, "inr_plan_create: null argument");
   *out = nullptr;
-  if (d->kind != INR_KIND_SIREN && d->kind != INR_KIND_FFN)
+  if (d->kind != INR_KIND_SIREN && d->kind != INR_KIND_FFN && d->kind != INR_KIND_WIRE)
     return fail(INR_ERR_UNSUPPORTED, "inr_plan_create: kind %d has no kernel yet", d->kind);
-  if (d->depth < 2 || d->depth > INR_MAX_LAYERS)
-    return fail(INR_ERR_INVALID, "inr_plan_create: depth %d outside [2,%d]", d->depth, INR_MAX_LAYERS);
-  if (d->width != 32 && d->width != 256)
-    return fail(INR_ERR_UNSUPPORTED, "inr_plan_create: width %d (kernels are built for 32 and 256)", d->width);
+  const bool wire = d->kind == INR_KIND_WIRE;
+  // number of Linear layers: SIREN/FFN network_depth counts all of them (networks.py:114-117);
+  // WIRE's counts the hidden complex layers only, total = depth + 2 (networks.py:234-250)
+  const int D = wire ? d->depth + 2 : d->depth;
+  if (D < 2 || D > INR_MAX_LAYERS)
+    return fail(INR_ERR_INVALID, "inr_plan_create: depth %d gives %d layers, outside [2,%d]", d->depth, D,
+                INR_MAX_LAYERS);
   if (d->out_features < 1 || d->out_features > 4)
     return fail(INR_ERR_UNSUPPORTED, "inr_plan_create: out_features %d outside [1,4]", d->out_features);
   if (d->in_features < 1) return fail(INR_ERR_INVALID, "inr_plan_create: in_features %d", d->in_features);
+  if (d->width < 1) return fail(INR_ERR_INVALID, "inr_plan_create: width %d", d->width);
+  // rows of the hidden activations as the kernel sees them: complex features are (Re, Im) row pairs
+  const int hid = wire ? 2 * d->width : d->width;
+  const int NB = (hid + 31) / 32;
+  int NW;
+  if (wire) {
+    if (NB <= 2) NW = 4;
+    else if (NB == 12) NW = 3;
+    else
+      return fail(INR_ERR_UNSUPPORTED, "inr_plan_create: WIRE with %d complex hidden features (kernels are built for "
+                  "<= 32 and for 181 = int(256/sqrt 2))", d->width);
+    if (d->input != INR_INPUT_X)
+      return fail(INR_ERR_UNSUPPORTED, "inr_plan_create: WIRE takes raw coordinates (input must be INR_INPUT_X)");
+    if (d->last_act != INR_ACT_ID) return fail(INR_ERR_INVALID, "inr_plan_create: WIRE's output is linear");
+  } else {
+    if (d->width != 32 && d->width != 256)
+      return fail(INR_ERR_UNSUPPORTED, "inr_plan_create: width %d (kernels are built for 32 and 256)", d->width);
+    NW = 4;
+  }
   if (d->input == INR_INPUT_GAUSS) {
     if (d->enc_size < 8 || (d->enc_size % 8) != 0)
       return fail(INR_ERR_UNSUPPORTED, "inr_plan_create: enc_size %d must be a positive multiple of 8", d->enc_size);
@@ -86,41 +108,74 @@ int inr_plan_create(const inr_net_desc* d, inr_plan** out) {
   p->desc = *d;
   NetDesc& nd = p->nd;
   memset(&nd, 0, sizeof(nd));
-  nd.D = d->depth;
-  nd.NB = d->width / 32;
-  nd.hact = d->kind == INR_KIND_SIREN ? ACT_SIN : ACT_RELU;
+  nd.D = D;
+  nd.NB = NB;
+  nd.NW = NW;
+  nd.hact = wire ? ACT_GABOR : (d->kind == INR_KIND_SIREN ? ACT_SIN : ACT_RELU);
   nd.last_act = d->last_act;
   nd.input = d->input;
   nd.E = d->enc_size;
   nd.out_f = d->out_features;
   nd.w0 = d->w0;
-  int poff = 0;
+  const int TL = 32 * NW;
+  int poff = 0, goff = 0;
   int64_t pk = 0;
-  for (int l = 0; l < nd.D; ++l) {
+  for (int l = 0; l < D; ++l) {
     LayerDesc& L = nd.L[l];
-    L.K = l == 0 ? d->in_features : d->width;
-    L.M = l == nd.D - 1 ? d->out_features : d->width;
-    L.Kpad8 = round_up(L.K, 8);
+    const bool first = l == 0, last = l == D - 1;
+    L.K = first ? d->in_features : hid;
+    L.M = last ? d->out_features : hid;
+    // hidden-to-hidden products run over all NB*32 image rows (padding rows carry zero weights)
+    L.Kpad8 = first ? round_up(L.K, 8) : NB * 32;
     L.Kblk = (L.K + 31) / 32;
     L.Mblk = (L.M + 31) / 32;
-    L.Mpad8 = round_up(L.M, 8);
+    L.Mpad8 = last ? round_up(L.M, 8) : NB * 32;
+    if (!wire) {
+      L.ltype = LT_REAL;
+      L.wn = L.M * L.K;
+      L.bn = L.M;
+      L.omega = d->w0;
+      L.s0 = 0.f;
+    } else if (first) {
+      L.ltype = LT_WIRE_FIRST;  // real weights on real coordinates (networks.py:185-188)
+      L.wn = d->width * L.K;
+      L.bn = d->width;
+      L.omega = d->first_omega_0;
+      L.s0 = d->scale_0;
+    } else if (!last) {
+      L.ltype = LT_WIRE_HIDDEN;
+      L.wn = d->width * d->width * 2;
+      L.bn = d->width * 2;
+      L.omega = d->hidden_omega_0;
+      L.s0 = d->scale_0;
+    } else {
+      L.ltype = LT_WIRE_LAST;  // complex Linear, output.real (networks.py:247-258)
+      L.wn = d->out_features * d->width * 2;
+      L.bn = d->out_features * 2;
+    }
     L.w_off = poff;
-    poff += L.M * L.K;
+    poff += L.wn;
     L.b_off = poff;
-    poff += L.M;
+    poff += L.bn;
+    L.gw_off = goff;
+    goff += L.M * L.K;
+    L.gb_off = goff;
+    goff += L.M;
     L.pf_off = (int)pk;
     pk += (int64_t)L.Kpad8 * L.Mblk * 32;  // (Kpad8/8 groups) x Mblk x 64 lanes x 4
     if (l >= 1) {
       L.pb_off = (int)pk;
       pk += (int64_t)L.Mpad8 * L.Kblk * 32;
-    } else {
-      L.pb_off = 0;
     }
+    L.pbias_off = (int)pk;
+    pk += L.Mblk * 32;
   }
   nd.P = poff;
-  nd.slab_floats = round_up(poff + 4, 64);
-  nd.save_floats_per_tile = 2 * (nd.D - 1) * nd.NB * 32 * INR_TILE + 4 * INR_TILE +
-                            (d->input == INR_INPUT_GAUSS ? nd.L[0].Kblk * 32 * INR_TILE : 0);
+  nd.slab_loss_off = goff;
+  nd.slab_floats = round_up(goff + 4, 64);
+  const int ns = wire ? 3 : 2;
+  nd.save_floats_per_tile = ns * (D - 1) * NB * 32 * TL + 4 * TL +
+                            (d->input == INR_INPUT_GAUSS ? nd.L[0].Kblk * 32 * TL : 0);
   p->packed_floats = pk;
   *out = p;
   return INR_OK;
@@ -135,7 +190,7 @@ int inr_plan_sizes(const inr_plan* plan, inr_sizes* out) {
   if (plan == nullptr || out == nullptr) return fail(INR_ERR_INVALID, "inr_plan_sizes: null argument");
   out->n_params = plan->nd.P;
   out->packed_floats = plan->packed_floats;
-  out->tile_rows = INR_TILE;
+  out->tile_rows = 32 * plan->nd.NW;
   out->save_bytes_per_tile = (int64_t)plan->nd.save_floats_per_tile * 4;
   out->max_blocks = kMaxBlocks;
   out->slab_floats = plan->nd.slab_floats;
@@ -146,7 +201,8 @@ int inr_plan_launch_dims(const inr_plan* plan, int64_t B, int64_t* n_tiles, int6
   if (plan == nullptr || n_tiles == nullptr || n_blocks == nullptr)
     return fail(INR_ERR_INVALID, "inr_plan_launch_dims: null argument");
   if (B <= 0) return fail(INR_ERR_INVALID, "inr_plan_launch_dims: B = %lld", (long long)B);
-  *n_tiles = (B + INR_TILE - 1) / INR_TILE;
+  const int tl = 32 * plan->nd.NW;
+  *n_tiles = (B + tl - 1) / tl;
   *n_blocks = *n_tiles < kMaxBlocks ? *n_tiles : kMaxBlocks;
   return INR_OK;
 }
@@ -154,10 +210,13 @@ int inr_plan_launch_dims(const inr_plan* plan, int64_t B, int64_t* n_tiles, int6
 static int launch(const inr_plan* plan, const LossDesc& ld, const inr::MlpArgs& a, int mode, int grid,
                   hipStream_t st) {
   hipError_t e;
-  if (plan->nd.NB == 1)
-    e = inr::launch_mlp_nb1(plan->nd, ld, a, mode, grid, st);
+  const NetDesc& nd = plan->nd;
+  if (nd.hact == ACT_GABOR)
+    e = nd.NB == 12 ? inr::launch_wire_nb12(nd, ld, a, mode, grid, st) : inr::launch_wire_nb2(nd, ld, a, mode, grid, st);
+  else if (nd.NB == 1)
+    e = inr::launch_mlp_nb1(nd, ld, a, mode, grid, st);
   else
-    e = inr::launch_mlp_nb8(plan->nd, ld, a, mode, grid, st);
+    e = inr::launch_mlp_nb8(nd, ld, a, mode, grid, st);
   if (e != hipSuccess) return hip_fail(e, "inr mlp kernel launch");
   return INR_OK;
 }
@@ -233,7 +292,7 @@ int inr_backward(const inr_plan* plan, const float* params, const float* packed,
   memset(&ld, 0, sizeof(ld));
   int rc = launch(plan, ld, a, 1, (int)nb, (hipStream_t)stream);
   if (rc != INR_OK) return rc;
-  hipError_t e = inr::launch_reduce_slabs(slabs, (int)nb, plan->nd.slab_floats, plan->nd.P, grads, nullptr,
+  hipError_t e = inr::launch_reduce_slabs(plan->nd, slabs, (int)nb, grads, nullptr,
                                           (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "inr_backward: slab reduction");
   return INR_OK;
@@ -297,7 +356,7 @@ int inr_train_step(const inr_plan* plan, const inr_loss_desc* loss, const float*
   int rc = launch(plan, ld, a, 2, (int)nb, (hipStream_t)stream);
   if (rc != INR_OK) return rc;
   if (grads == nullptr) return INR_OK;  // profiling: leave the per-block slabs unreduced
-  hipError_t e = inr::launch_reduce_slabs(slabs, (int)nb, plan->nd.slab_floats, plan->nd.P, grads, loss_out,
+  hipError_t e = inr::launch_reduce_slabs(plan->nd, slabs, (int)nb, grads, loss_out,
                                           (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "inr_train_step: slab reduction");
   return INR_OK;

@@ -15,8 +15,8 @@ struct AdamArgs {
 };
 
 
-hipError_t launch_reduce_slabs(const float* slabs, int n_blocks, int slab_floats, int P, float* grads,
-                               float* loss_out, hipStream_t st);
+hipError_t launch_reduce_slabs(const NetDesc& nd, const float* slabs, int n_blocks, float* grads, float* loss_out,
+                               hipStream_t st);
 hipError_t launch_adam_pack(const NetDesc& nd, float* params, const float* grads, float* m1, float* m2,
                             float* packed, const AdamArgs& aa, hipStream_t st);
 hipError_t launch_encode_gauss(const float* coords, const float* encB, long long B, int E, float* out,
@@ -27,5 +27,7 @@ hipError_t launch_loss_grad(const LossDesc& ld, const float* out, const float* g
 // per-NB dispatchers (one translation unit each): mode 0 fwd, 1 bwd, 2 fused
 hipError_t launch_mlp_nb1(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int mode, int grid, hipStream_t st);
 hipError_t launch_mlp_nb8(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int mode, int grid, hipStream_t st);
+hipError_t launch_wire_nb2(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int mode, int grid, hipStream_t st);
+hipError_t launch_wire_nb12(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int mode, int grid, hipStream_t st);
 
 }  // namespace inr

@@ -7,44 +7,135 @@
 namespace inr {
 
 // ---------------------------------------------------------------------------------------------
-// grads[i] = sum_b slabs[b][i] in block order (deterministic); loss word summed by thread 0.
+// Flat-parameter element -> where it lives in the virtual real matrices the fused kernel works on.
+// A flat float is a real weight (LT_REAL, LT_WIRE_FIRST), the Re or Im part of a complex weight
+// (LT_WIRE_HIDDEN: W = Wr + jWi acts as [[Wr,-Wi],[Wi,Wr]] on interleaved (Re,Im) rows;
+// LT_WIRE_LAST: only the real output row [Wr,-Wi] exists), or a bias entry.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, int n_blocks,
-                                                           int slab_floats, int P, float* __restrict__ grads,
+struct VirtualPos {
+  int n;          // number of virtual entries (0, 1 or 2)
+  int row[2], col[2];
+  float sign[2];
+  int bias_row;   // >= 0: this flat element is a bias entry of that virtual row (n == 0)
+};
+
+__device__ __forceinline__ bool locate(const NetDesc& nd, int i, int& l, VirtualPos& vp) {
+  vp.n = 0;
+  vp.bias_row = -1;
+  for (l = 0; l < nd.D; ++l) {
+    const LayerDesc& L = nd.L[l];
+    const int off = i - L.w_off;
+    if (off >= 0 && off < L.wn) {
+      if (L.ltype == LT_REAL) {
+        vp.n = 1; vp.row[0] = off / L.K; vp.col[0] = off - vp.row[0] * L.K; vp.sign[0] = 1.f;
+      } else if (L.ltype == LT_WIRE_FIRST) {
+        const int r = off / L.K;
+        vp.n = 1; vp.row[0] = 2 * r; vp.col[0] = off - r * L.K; vp.sign[0] = 1.f;
+      } else {
+        const int kc = L.K >> 1;  // complex in-features
+        const int r = off / (2 * kc), rem = off - r * 2 * kc, j = rem >> 1, c = rem & 1;
+        if (L.ltype == LT_WIRE_HIDDEN) {
+          vp.n = 2;
+          if (c == 0) {  // Wr -> (2r,2j) and (2r+1,2j+1)
+            vp.row[0] = 2 * r; vp.col[0] = 2 * j; vp.sign[0] = 1.f;
+            vp.row[1] = 2 * r + 1; vp.col[1] = 2 * j + 1; vp.sign[1] = 1.f;
+          } else {       // Wi -> +(2r+1,2j) and -(2r,2j+1)
+            vp.row[0] = 2 * r + 1; vp.col[0] = 2 * j; vp.sign[0] = 1.f;
+            vp.row[1] = 2 * r; vp.col[1] = 2 * j + 1; vp.sign[1] = -1.f;
+          }
+        } else {  // LT_WIRE_LAST: out = Re(W h + beta): row r = [Wr, -Wi]
+          vp.n = 1; vp.row[0] = r; vp.col[0] = 2 * j + c; vp.sign[0] = c ? -1.f : 1.f;
+        }
+      }
+      return true;
+    }
+    const int ob = i - L.b_off;
+    if (ob >= 0 && ob < L.bn) {
+      if (L.ltype == LT_REAL) vp.bias_row = ob;
+      else if (L.ltype == LT_WIRE_FIRST) vp.bias_row = 2 * ob;
+      else if (L.ltype == LT_WIRE_HIDDEN) vp.bias_row = ob;            // (i, c) -> row 2i + c
+      else vp.bias_row = (ob & 1) ? -2 : (ob >> 1);                    // imaginary output bias: no effect
+      return true;
+    }
+  }
+  return false;
+}
+
+// ---------------------------------------------------------------------------------------------
+// grads[i] = sum over blocks (in block order: deterministic) of the slab entries that flat
+// element i owns; the loss word is summed by thread 0.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const NetDesc nd, const float* __restrict__ slabs,
+                                                           int n_blocks, float* __restrict__ grads,
                                                            float* __restrict__ loss_out) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < P) {
+  const int sf = nd.slab_floats;
+  if (i < nd.P) {
+    int l;
+    VirtualPos vp;
     float s = 0.f;
-    int b = 0;
-    for (; b + 4 <= n_blocks; b += 4) {
-      const float v0 = slabs[(size_t)(b + 0) * slab_floats + i];
-      const float v1 = slabs[(size_t)(b + 1) * slab_floats + i];
-      const float v2 = slabs[(size_t)(b + 2) * slab_floats + i];
-      const float v3 = slabs[(size_t)(b + 3) * slab_floats + i];
-      s = (((s + v0) + v1) + v2) + v3;
+    if (locate(nd, i, l, vp)) {
+      const LayerDesc& L = nd.L[l];
+      if (vp.n >= 1) {
+        const size_t o0 = (size_t)L.gw_off + (size_t)vp.row[0] * L.K + vp.col[0];
+        if (vp.n == 1) {
+          int b = 0;
+          for (; b + 4 <= n_blocks; b += 4) {
+            const float v0 = slabs[(size_t)(b + 0) * sf + o0], v1 = slabs[(size_t)(b + 1) * sf + o0];
+            const float v2 = slabs[(size_t)(b + 2) * sf + o0], v3 = slabs[(size_t)(b + 3) * sf + o0];
+            s = (((s + v0) + v1) + v2) + v3;
+          }
+          for (; b < n_blocks; ++b) s += slabs[(size_t)b * sf + o0];
+          s *= vp.sign[0];
+        } else {
+          const size_t o1 = (size_t)L.gw_off + (size_t)vp.row[1] * L.K + vp.col[1];
+          for (int b = 0; b < n_blocks; ++b)
+            s += vp.sign[0] * slabs[(size_t)b * sf + o0] + vp.sign[1] * slabs[(size_t)b * sf + o1];
+        }
+      } else if (vp.bias_row >= 0) {
+        const size_t o0 = (size_t)L.gb_off + vp.bias_row;
+        for (int b = 0; b < n_blocks; ++b) s += slabs[(size_t)b * sf + o0];
+      }
     }
-    for (; b < n_blocks; ++b) s += slabs[(size_t)b * slab_floats + i];
     grads[i] = s;
   }
   if (loss_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
-    float l = 0.f;
-    for (int b = 0; b < n_blocks; ++b) l += slabs[(size_t)b * slab_floats + P];
-    loss_out[0] = l;
+    float lsum = 0.f;
+    for (int b = 0; b < n_blocks; ++b) lsum += slabs[(size_t)b * sf + nd.slab_loss_off];
+    loss_out[0] = lsum;
   }
 }
 
-hipError_t launch_reduce_slabs(const float* slabs, int n_blocks, int slab_floats, int P, float* grads,
-                               float* loss_out, hipStream_t st) {
-  const int grid = (P + 255) / 256;
-  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(grid), dim3(256), 0, st, slabs, n_blocks, slab_floats, P, grads,
-                     loss_out);
+hipError_t launch_reduce_slabs(const NetDesc& nd, const float* slabs, int n_blocks, float* grads, float* loss_out,
+                               hipStream_t st) {
+  const int grid = (nd.P + 255) / 256;
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(grid), dim3(256), 0, st, nd, slabs, n_blocks, grads, loss_out);
   return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------
 // Adam (torch.optim.Adam single-tensor algorithm, amsgrad=False; train.py:76,190) fused with the
-// re-pack of every weight into the two MFMA A-fragment images.  do_update == 0: pack only.
+// re-pack of every weight into the two MFMA A-fragment images and of every bias into its padded
+// bias image.  do_update == 0: pack only.
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void put_fwd(const NetDesc& nd, const LayerDesc& L, int l, float* packed, int row, int k,
+                                        float v) {
+  int h, s;
+  if (l == 0 && nd.input == IN_GAUSS) {
+    h = k >= nd.E;
+    s = h ? k - nd.E : k;
+  } else {
+    h = k & 1;
+    s = k >> 1;
+  }
+  packed[L.pf_off + ((size_t)((s >> 2) * L.Mblk + (row >> 5)) * 64 + h * 32 + (row & 31)) * 4 + (s & 3)] = v;
+}
+
+__device__ __forceinline__ void put_tr(const LayerDesc& L, float* packed, int row, int k, float v) {
+  const int h = row & 1, s = row >> 1;  // transposed image A'[i=k][k'=row]
+  packed[L.pb_off + ((size_t)((s >> 2) * L.Kblk + (k >> 5)) * 64 + h * 32 + (k & 31)) * 4 + (s & 3)] = v;
+}
+
 __global__ __launch_bounds__(256) void adam_pack_kernel(const NetDesc nd, float* __restrict__ params,
                                                         const float* __restrict__ grads, float* __restrict__ m1,
                                                         float* __restrict__ m2, float* __restrict__ packed,
@@ -58,40 +149,23 @@ __global__ __launch_bounds__(256) void adam_pack_kernel(const NetDesc nd, float*
     if (aa.l1 != 0.f) g += aa.l1 * (p > 0.f ? 1.f : (p < 0.f ? -1.f : 0.f));  // d/dp lambda*sum|p|
     if (aa.l2 != 0.f) g = fmaf(2.f * aa.l2, p, g);                             // d/dp lambda*|sum p^2|
     float m = m1[i], v = m2[i];
-    m = m + (g - m) * aa.omb1;                    // exp_avg.lerp_(grad, 1 - beta1)
-    v = fmaf(g * g, aa.omb2, v * aa.beta2);       // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1 - beta2)
+    m = m + (g - m) * aa.omb1;                // exp_avg.lerp_(grad, 1 - beta1)
+    v = fmaf(g * g, aa.omb2, v * aa.beta2);   // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1 - beta2)
     const float denom = sqrtf(v) / aa.bc2_sqrt + aa.eps;
-    p = p - aa.step_size * (m / denom);            // param.addcdiv_(exp_avg, denom, value=-step_size)
+    p = p - aa.step_size * (m / denom);       // param.addcdiv_(exp_avg, denom, value=-step_size)
     m1[i] = m;
     m2[i] = v;
     params[i] = p;
   }
-  // locate (layer, row, col); biases are read straight from params by the kernels
-  for (int l = 0; l < nd.D; ++l) {
-    const LayerDesc& L = nd.L[l];
-    const int off = i - L.w_off;
-    if (off >= 0 && off < L.M * L.K) {
-      const int row = off / L.K, k = off - row * L.K;
-      {  // forward image A[i=row][k]
-        int h, s;
-        if (l == 0 && nd.input == IN_GAUSS) {
-          h = k >= nd.E;
-          s = h ? k - nd.E : k;
-        } else {
-          h = k & 1;
-          s = k >> 1;
-        }
-        const int s4 = s >> 2, e = s & 3, m = row >> 5, lane = h * 32 + (row & 31);
-        packed[L.pf_off + ((size_t)(s4 * L.Mblk + m) * 64 + lane) * 4 + e] = p;
-      }
-      if (l >= 1) {  // transposed image A'[i=k][k'=row]
-        const int h = row & 1, s = row >> 1;
-        const int s4 = s >> 2, e = s & 3, m = k >> 5, lane = h * 32 + (k & 31);
-        packed[L.pb_off + ((size_t)(s4 * L.Kblk + m) * 64 + lane) * 4 + e] = p;
-      }
-      return;
-    }
+  int l;
+  VirtualPos vp;
+  if (!locate(nd, i, l, vp)) return;
+  const LayerDesc& L = nd.L[l];
+  for (int t = 0; t < vp.n; ++t) {
+    put_fwd(nd, L, l, packed, vp.row[t], vp.col[t], vp.sign[t] * p);
+    if (l >= 1) put_tr(L, packed, vp.row[t], vp.col[t], vp.sign[t] * p);
   }
+  if (vp.bias_row >= 0) packed[L.pbias_off + vp.bias_row] = p;
 }
 
 hipError_t launch_adam_pack(const NetDesc& nd, float* params, const float* grads, float* m1, float* m2,

@@ -5,8 +5,7 @@
 #include <stdint.h>
 
 #define INR_MAX_LAYERS 16
-#define INR_TILE 128     // coordinates per workgroup tile (4 waves x 32)
-#define INR_WAVES 4
+#define INR_MAX_WAVES 4   // waves per workgroup (tile = 32 coordinates per wave)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -17,6 +16,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define ACT_TANH 2
 #define ACT_RELU 3
 #define ACT_SIGMOID 4
+#define ACT_GABOR 5   // WIRE complex Gabor wavelet on interleaved (Re, Im) rows; hidden layers only
+
+// how a layer's virtual real matrix [M x K] maps to the flat parameters
+#define LT_REAL 0          // weight [M,K] f32, bias [M]                       (SIREN / FFN)
+#define LT_WIRE_FIRST 1    // weight [M/2,K] f32 -> rows 2i, rows 2i+1 are zero (networks.py:185-188)
+#define LT_WIRE_HIDDEN 2   // weight [M/2,K/2] complex64 -> [[Wr,-Wi],[Wi,Wr]] interleaved
+#define LT_WIRE_LAST 3     // weight [M,K/2] complex64, output = real part: row o = [Wr, -Wi] interleaved
 
 #define IN_X 0
 #define IN_GAUSS 1
@@ -28,14 +34,19 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define LOSS_HDR 4
 
 struct LayerDesc {
-  int K, M;          // logical in / out features
+  int K, M;          // in / out features of the (virtual) real matrix the kernel multiplies
   int Kpad8;         // K rounded up to a multiple of 8 (4 k-steps of 2 per A-fragment float4)
   int Kblk;          // ceil(K / 32): 32-wide column blocks of dW
   int Mblk;          // ceil(M / 32): 32-row blocks
   int Mpad8;         // M rounded up to a multiple of 8 (k extent of the transposed product)
-  int w_off, b_off;  // offsets (floats) into flat params / grads / slabs
+  int ltype;         // LT_*
+  int w_off, b_off;  // offsets (floats) into flat params / grads
+  int wn, bn;        // floats of the weight / bias tensors in flat params
+  int gw_off, gb_off;// offsets into a gradient slab: dW [M x K] and db [M] of the virtual matrix
   int pf_off;        // offset into packed: forward image  A[i=out][k=in]
   int pb_off;        // offset into packed: transposed image A[i=in][k=out] (unused for layer 0)
+  int pbias_off;     // offset into packed: bias image, Mblk*32 entries, zero padded
+  float omega, s0;   // activation constants of this layer's OUTPUT (SIREN w0 / WIRE omega_0, scale_0)
 };
 
 struct NetDesc {
@@ -47,8 +58,10 @@ struct NetDesc {
   int E;             // gauss encoder size (in_features == 2E)
   int out_f;
   float w0;
-  int P;             // total params
-  int slab_floats;   // P + loss words, padded to 64
+  int P;             // total params (floats in flat params)
+  int NW;            // waves per workgroup: tile = 32*NW coordinates
+  int slab_floats;   // floats per gradient slab (virtual dW/db of every layer + loss word, padded to 64)
+  int slab_loss_off; // position of the block's loss partial inside its slab
   int save_floats_per_tile;
   LayerDesc L[INR_MAX_LAYERS];
 };

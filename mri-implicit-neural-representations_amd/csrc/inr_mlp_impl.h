@@ -1,27 +1,28 @@
 // inr_mlp_impl.h -- the fused coordinate-MLP kernel (fp32-exact path) for gfx950.
 //
-// One workgroup = 4 waves = one tile of 128 coordinates; each wave owns 32 coordinates and
+// One workgroup = NW waves = one tile of TL = 32*NW coordinates; each wave owns 32 coordinates and
 // carries them through EVERY layer on its own (no inter-wave traffic in the forward pass):
 //
 //   * activations live TRANSPOSED, X^T [features x coords], coordinates on the MFMA lanes.
 //     Y^T = W . X^T makes the PyTorch-layout weight matrix the A operand and the activations the
 //     B operand of v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains -> bit-level agreement with a
 //     k-ordered CPU fmaf chain, 157 TFLOP/s peak);
-//   * between layers the pre-activations (bias added) sit in a per-wave XOR-swizzled LDS image
-//     [feature][32 coords]; the CONSUMER applies sin(w0 z) lazily while it streams the image as
-//     its B operand, so the transcendental VALU work overlaps the MFMA pipe, and stashes h and
-//     w0*cos(w0 z) for the backward pass;
+//   * between layers the pre-activations (bias added) sit in a per-wave padded LDS image
+//     [feature][33]; the CONSUMER applies the activation lazily, one 4-k-step group ahead of the
+//     MFMAs that use it, and stashes h and act' for the backward pass;
 //   * weights are streamed as pre-packed A fragments (one float4 = 4 k-steps per lane), software
-//     prefetched one group ahead;
+//     prefetched one group ahead into ping-pong register sets;
 //   * backward: dX^T = W^T . dZ^T reuses the same structure (dZ = dH * act' formed lazily and
-//     written back into the LDS image), then dW = dZ^T . H contracts over the tile's 128
-//     coordinates with dZ read "feature on lane" from the same LDS image (the swizzle makes both
-//     access directions conflict-free) and H read from the stash;
+//     written back into the LDS image), then dW = dZ^T . H contracts over the tile's coordinates
+//     with dZ read "feature on lane" from the same LDS image (the padding makes both access
+//     directions conflict-free) and H read from the stash;
 //   * each persistent workgroup accumulates its dW in a private slab (plain stores, fixed order),
 //     a second kernel sums the slabs in block order: deterministic, no float atomics.
 //
-// Reference semantics: SirenLayer.forward / SIREN (models/networks.py:91-96,121-124), FFN
-// (:48-69), Positional_Encoder 'gauss' (:30-33), autograd adjoint per SURVEY.md Appendix A.2.
+// Families (HACT): SIN = SIREN (models/networks.py:74-124), RELU = FFN (:48-69), GABOR = WIRE
+// (:160-260; complex layers run as interleaved real rows 2i = Re, 2i+1 = Im of twice the width).
+// Input stage (INMODE): fused gauss Positional_Encoder (:30-33) or a matrix x [B,K0].
+// Adjoint per SURVEY.md Appendix A.2 / A.3.
 #pragma once
 #include "inr_device.h"
 #include "inr_mlp_args.h"
@@ -54,6 +55,24 @@ __device__ __forceinline__ void act_fwd(float z, float w0, float& h, float& d) {
   }
 }
 
+// Complex Gabor wavelet of WIRE (networks.py:199-204): lin = a + jb, y = exp(j*omega*lin - |s0*lin|^2)
+//   = E (cos(omega a) + j sin(omega a)),  E = exp(-omega b - s0^2 (a^2 + b^2)).
+// Pre-activation rows are interleaved (row 2i = a_i, row 2i+1 = b_i); a lane of half h owns row
+// 2i+h, emits y_r (h = 0) or y_i (h = 1) and the two Jacobian entries of ITS row:
+//   dZ[row] = p * dA + q * dB   with (p, q) = dL/d(y_r, y_i) of the pair.
+__device__ __forceinline__ void act_gabor(float za, float zb, float omega, float s0, int half, float& h,
+                                          float& dA, float& dB) {
+  float sn, cs;
+  sincos_cw(omega * za, sn, cs);
+  const float s2 = s0 * s0;
+  const float E = expf(-omega * zb - s2 * (za * za + zb * zb));
+  const float yr = E * cs, yi = E * sn;
+  h = half ? yi : yr;
+  const float ka = -2.f * s2 * za, kb = -omega - 2.f * s2 * zb;
+  dA = half ? kb * yr : fmaf(ka, yr, -omega * yi);  // d(y_r)/d(row)
+  dB = half ? kb * yi : fmaf(ka, yi, omega * yr);   // d(y_i)/d(row)
+}
+
 __device__ __forceinline__ void act_fwd_rt(int act, float z, float w0, float& h, float& d) {
   switch (act) {
     case ACT_SIN: act_fwd<ACT_SIN>(z, w0, h, d); break;
@@ -73,8 +92,20 @@ __device__ __forceinline__ void load_afrag(f32x4 (&a)[NBM], const f32x4* __restr
   for (int m = 0; m < NBM; ++m) a[m] = p[m * 64];
 }
 
+// Buffer descriptor from a wave-uniform pointer (readfirstlane makes the uniformity provable, so
+// hipcc emits plain buffer_load ... offen with an SGPR descriptor instead of waterfall loops or --
+// worse -- 128 hoisted 64-bit VGPR addresses that it then spills around the tile loop).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* p, int bytes) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  void* q = reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
+  return __builtin_amdgcn_make_buffer_rsrc(q, 0, bytes, 0x00020000);
+}
+
 // acc (+bias) -> this wave's LDS image rows [0, NBM*32).  Rows of register group g = r>>2 are
-// 32m + 8g + 4*half + (0..3): one float4 of bias per group.  The layer's M must equal NBM*32.
+// 32m + 8g + 4*half + (0..3): one float4 of bias per group.  `bias` is the zero-padded bias image
+// (NBM*32 entries) kept inside the packed buffer.
 template <int NBM, bool BIAS>
 __device__ __forceinline__ void acc_to_lds(const f32x16 (&acc)[NBM], float* R, const float* __restrict__ bias,
                                            int lane) {
@@ -93,9 +124,45 @@ __device__ __forceinline__ void acc_to_lds(const f32x16 (&acc)[NBM], float* R, c
   }
 }
 
-// Ask the scheduler for  N x { 1 MFMA, VALU_PER VALU }  in this order: the transcendental / address
-// VALU work of k-step e+1 then issues in the shadow of the 64-cycle MFMAs of k-step e instead of
-// in a block between them (one wave per SIMD: nothing else would cover the idle matrix pipe).
+// First layer: dZ_0 = dH_0 * act'(z_0) is formed while the dX accumulators are stored to the image
+// (there is no dX for the input): 16*NBM independent coalesced stash loads, all in flight together.
+// PAIR (WIRE): rows (2i, 2i+1) = registers (2p, 2p+1) of one lane:  dZ[row] = p*dA[row] + q*dB[row].
+template <int NBM, int TL, bool PAIR>
+__device__ __forceinline__ void acc_times_d_to_lds(const f32x16 (&acc)[NBM], float* R,
+                                                   const float* __restrict__ sv_dA,
+                                                   const float* __restrict__ sv_dB, int wcol, int lane) {
+  const int half = lane >> 5, col = lane & 31;
+  float* Rl = R + (4 * half) * INR_LDS_LD + col;
+  const __amdgpu_buffer_rsrc_t rsA = uniform_rsrc(sv_dA, NBM * 32 * TL * 4);
+  const __amdgpu_buffer_rsrc_t rsB = uniform_rsrc(PAIR ? sv_dB : sv_dA, NBM * 32 * TL * 4);
+  const int voff = ((4 * half) * TL + wcol) * 4;  // one per-lane byte offset for all loads
+#pragma unroll
+  for (int m = 0; m < NBM; ++m) {
+    float dA[16], dB[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int soff = (32 * m + (r & 3) + 8 * (r >> 2)) * TL * 4;
+      dA[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsA, voff, soff, 0));
+      dB[r] = PAIR ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsB, voff, soff, 0)) : 0.f;
+    }
+    __builtin_amdgcn_sched_barrier(0);  // all loads of the block in flight before the first use
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v;
+      if (PAIR) {
+        const float pp = acc[m][r & ~1], qq = acc[m][r | 1];
+        v = fmaf(pp, dA[r], qq * dB[r]);
+      } else {
+        v = acc[m][r] * dA[r];
+      }
+      Rl[(32 * m + (r & 3) + 8 * (r >> 2)) * INR_LDS_LD] = v;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// Ask the scheduler for  N x { 1 MFMA, VALU_PER VALU }  in this order, so the VALU work of the next
+// group is spread between this group's MFMAs instead of sitting in a block in front of them.
 template <int N, int VALU_PER>
 __device__ __forceinline__ void interleave_mfma_valu() {
 #pragma unroll
@@ -120,20 +187,18 @@ __device__ __forceinline__ float gauss_feature(const float* encB_lds, int s, flo
   return half ? cs : sn;
 }
 
-template <int NB, bool SAVE>
+template <int NB, int TL, bool SAVE>
 __device__ __forceinline__ void gauss_group(f32x16 (&acc)[NB], const f32x4 (&a_use)[NB], f32x4 (&a_load)[NB],
                                             const f32x4* p_next, const float* encB_lds, int s4_next, float xs0,
                                             float xs1, float xs2, int half, const float (&b_use)[4],
                                             float (&b_load)[4], float* __restrict__ sv_enc_s4) {
   load_afrag<NB>(a_load, p_next);
   __builtin_amdgcn_sched_barrier(0);  // the next group's A fragments fly behind this group's MFMAs
-  // the next group's four features: four independent sincos chains give the single resident wave
-  // the VALU ILP it needs, and they issue in the shadow of this group's 4*NB MFMAs
 #pragma unroll
   for (int e = 0; e < 4; ++e) b_load[e] = gauss_feature(encB_lds, 4 * s4_next + e, xs0, xs1, xs2, half);
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    if (SAVE) sv_enc_s4[e * INR_TILE] = b_use[e];  // feature row (half ? E : 0) + 4*s4 + e, reused by dW_0
+    if (SAVE) sv_enc_s4[e * TL] = b_use[e];  // feature row (half ? E : 0) + 4*s4 + e, reused by dW_0
 #pragma unroll
     for (int m = 0; m < NB; ++m) acc[m] = mfma32(a_use[m][e], b_use[e], acc[m]);
   }
@@ -141,12 +206,12 @@ __device__ __forceinline__ void gauss_group(f32x16 (&acc)[NB], const f32x4 (&a_u
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int NB, bool SAVE>
+template <int NB, int TL, bool SAVE>
 __device__ __forceinline__ void fwd_layer0_gauss(f32x16 (&acc)[NB], const float* __restrict__ wp,
                                                  const float* encB_lds, int E, float xs0, float xs1, float xs2,
                                                  float* __restrict__ sv_enc, int wcol, int lane) {
   const int half = lane >> 5;
-  float* sve = SAVE ? sv_enc + (half ? E : 0) * INR_TILE + wcol : nullptr;
+  float* sve = SAVE ? sv_enc + (half ? E : 0) * TL + wcol : nullptr;
   const f32x4* p = reinterpret_cast<const f32x4*>(wp) + lane;
   const int n4 = E >> 2;  // even (E % 8 == 0)
   f32x4 A0[NB], A1[NB];
@@ -157,10 +222,10 @@ __device__ __forceinline__ void fwd_layer0_gauss(f32x16 (&acc)[NB], const float*
 #pragma unroll 1
   for (int s4 = 0; s4 < n4; s4 += 2) {
     const int n2 = (s4 + 2 < n4) ? (s4 + 2) : s4;
-    gauss_group<NB, SAVE>(acc, A0, A1, p + (size_t)(s4 + 1) * NB * 64, encB_lds, s4 + 1, xs0, xs1, xs2, half, F0, F1,
-                          sve + 4 * s4 * INR_TILE);
-    gauss_group<NB, SAVE>(acc, A1, A0, p + (size_t)n2 * NB * 64, encB_lds, n2, xs0, xs1, xs2, half, F1, F0,
-                          sve + 4 * (s4 + 1) * INR_TILE);
+    gauss_group<NB, TL, SAVE>(acc, A0, A1, p + (size_t)(s4 + 1) * NB * 64, encB_lds, s4 + 1, xs0, xs1, xs2, half, F0,
+                              F1, sve + 4 * s4 * TL);
+    gauss_group<NB, TL, SAVE>(acc, A1, A0, p + (size_t)n2 * NB * 64, encB_lds, n2, xs0, xs1, xs2, half, F1, F0,
+                              sve + 4 * (s4 + 1) * TL);
   }
 }
 
@@ -192,30 +257,67 @@ __device__ __forceinline__ void fwd_layer0_x(f32x16 (&acc)[NB], const float* __r
 }
 
 // ---------------------------------------------------------------------------------------------
-// forward, layer l >= 1: B operand = act(z_{l-1}) formed lazily from the LDS image, one k-step
-// ahead of the MFMAs that consume it.
-//   sv_h / sv_d: stash rows [feature][128 coords] for the backward pass.
+// forward, layer l >= 1: B operand = act(z_{l-1}) formed lazily from the LDS image, one group of
+// four k-steps ahead of the MFMAs that consume it (four independent chains).
+//   stash (SAVE): rows [feature][TL coords] of h, d (HACT != GABOR) or h, dA, dB (GABOR).
 // ---------------------------------------------------------------------------------------------
-template <int NBOUT, int HACT, bool SAVE>
+struct ActParams {
+  float w0;  // SIREN omega (30) / WIRE omega_0 of the producing layer
+  float s0;  // WIRE scale_0 of the producing layer
+};
+
+template <int HACT>
+__device__ __forceinline__ void lazy_act(const float (&z)[4], const float (&zp)[4], const ActParams& ap, int half,
+                                         float (&h)[4], float (&d)[4], float (&d2)[4]) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    if (HACT == ACT_GABOR) {
+      // z = Re row value, zp = Im row value of the pair (both halves read both rows)
+      act_gabor(z[e], zp[e], ap.w0, ap.s0, half, h[e], d[e], d2[e]);
+    } else {
+      act_fwd<HACT>(z[e], ap.w0, h[e], d[e]);
+      d2[e] = 0.f;
+    }
+  }
+}
+
+// image rows of group s4 for a lane: PAIR: the pair rows 8*s4 + 2e (Re) and 8*s4 + 2e + 1 (Im);
+// otherwise the lane's own row 8*s4 + 2e + half
+template <bool PAIR>
+__device__ __forceinline__ void load_z(float (&z)[4], float (&zp)[4], const float* Rcol, int s4, int half) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    if (PAIR) {
+      z[e] = Rcol[(8 * s4 + 2 * e) * INR_LDS_LD];
+      zp[e] = Rcol[(8 * s4 + 2 * e + 1) * INR_LDS_LD];
+    } else {
+      z[e] = Rcol[(8 * s4 + 2 * e + half) * INR_LDS_LD];
+      zp[e] = 0.f;
+    }
+  }
+}
+
+template <int NBOUT, int TL, int HACT, bool SAVE>
 __device__ __forceinline__ void fwd_group(f32x16 (&acc)[NBOUT], const f32x4 (&a_use)[NBOUT],
                                           f32x4 (&a_load)[NBOUT], const f32x4* p_next, float (&z_buf)[4],
-                                          const float* Rl_next2, int s4, float w0, float* __restrict__ sv_h,
-                                          float* __restrict__ sv_d, const float (&h_use)[4],
-                                          const float (&d_use)[4], float (&h_load)[4], float (&d_load)[4]) {
+                                          float (&zp_buf)[4], const float* Rcol, int s4_next2, int s4,
+                                          const ActParams& ap, int half, float* __restrict__ svl, int hsz,
+                                          const float (&h_use)[4], const float (&d_use)[4],
+                                          const float (&d2_use)[4], float (&h_load)[4], float (&d_load)[4],
+                                          float (&d2_load)[4]) {
   // z_buf holds the pre-activations of group s4+1 (fetched one group ago); they become h_load/d_load
   // during this group's MFMAs, and z_buf is refilled with group s4+2.
   load_afrag<NBOUT>(a_load, p_next);
-  float z_next[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) z_next[e] = Rl_next2[(2 * e) * INR_LDS_LD];
+  float z_next[4], zp_next[4];
+  load_z<HACT == ACT_GABOR>(z_next, zp_next, Rcol, s4_next2, half);
   __builtin_amdgcn_sched_barrier(0);  // operands of the following groups are in flight behind the MFMAs
-#pragma unroll
-  for (int e = 0; e < 4; ++e) act_fwd<HACT>(z_buf[e], w0, h_load[e], d_load[e]);  // 4 independent chains
+  lazy_act<HACT>(z_buf, zp_buf, ap, half, h_load, d_load, d2_load);
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     if (SAVE) {
-      sv_h[(8 * s4 + 2 * e) * INR_TILE] = h_use[e];
-      sv_d[(8 * s4 + 2 * e) * INR_TILE] = d_use[e];
+      svl[(8 * s4 + 2 * e) * TL] = h_use[e];
+      svl[hsz + (8 * s4 + 2 * e) * TL] = d_use[e];
+      if (HACT == ACT_GABOR) svl[2 * hsz + (8 * s4 + 2 * e) * TL] = d2_use[e];
     }
 #pragma unroll
     for (int m = 0; m < NBOUT; ++m) acc[m] = mfma32(a_use[m][e], h_use[e], acc[m]);
@@ -223,53 +325,57 @@ __device__ __forceinline__ void fwd_group(f32x16 (&acc)[NBOUT], const f32x4 (&a_
   if (NBOUT >= 4) interleave_mfma_valu<4 * NBOUT, (40 + NBOUT - 1) / NBOUT>();
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int e = 0; e < 4; ++e) z_buf[e] = z_next[e];
+  for (int e = 0; e < 4; ++e) {
+    z_buf[e] = z_next[e];
+    zp_buf[e] = zp_next[e];
+  }
 }
 
-template <int NB, int NBOUT, int HACT, bool SAVE>
+template <int NB, int NBOUT, int TL, int HACT, bool SAVE>
 __device__ __forceinline__ void fwd_layer(f32x16 (&acc)[NBOUT], const float* R, const float* __restrict__ wp,
-                                          float w0, float* __restrict__ sv_h, float* __restrict__ sv_d, int wcol,
-                                          int lane) {
+                                          const ActParams& ap, float* __restrict__ sv, int wcol, int lane) {
   const int half = lane >> 5, col = lane & 31;
   const f32x4* p = reinterpret_cast<const f32x4*>(wp) + lane;
   constexpr int n4 = NB * 4;  // K = 32*NB features -> 16*NB k-steps -> 4*NB groups of 4 (even)
-  const float* Rl = R + half * INR_LDS_LD + col;  // row k = 2*(4*s4+e) + half
-  float* svh = SAVE ? sv_h + half * INR_TILE + wcol : nullptr;
-  float* svd = SAVE ? sv_d + half * INR_TILE + wcol : nullptr;
+  constexpr int hsz = NB * 32 * TL;
+  constexpr bool PAIR = HACT == ACT_GABOR;
+  const float* Rcol = R + col;
+  float* svl = SAVE ? sv + half * TL + wcol : nullptr;  // stash row k = 8*s4 + 2e + half
   f32x4 A0[NBOUT], A1[NBOUT];
-  float Z[4], H0[4], D0[4], H1[4], D1[4];
+  float Z[4], ZP[4], H0[4], D0[4], E0[4], H1[4], D1[4], E1[4];
   load_afrag<NBOUT>(A0, p);
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    act_fwd<HACT>(Rl[(2 * e) * INR_LDS_LD], w0, H0[e], D0[e]);
-    Z[e] = Rl[(8 + 2 * e) * INR_LDS_LD];  // group 1 (n4 >= 4)
-  }
+  load_z<PAIR>(Z, ZP, Rcol, 0, half);
+  lazy_act<HACT>(Z, ZP, ap, half, H0, D0, E0);
+  load_z<PAIR>(Z, ZP, Rcol, 1, half);  // group 1 (n4 >= 4)
 #pragma unroll 1
   for (int s4 = 0; s4 < n4; s4 += 2) {
     const int n2 = (s4 + 2 < n4) ? (s4 + 2) : s4;
     const int n3 = (s4 + 3 < n4) ? (s4 + 3) : s4;
-    fwd_group<NBOUT, HACT, SAVE>(acc, A0, A1, p + (size_t)(s4 + 1) * NBOUT * 64, Z, Rl + 8 * n2 * INR_LDS_LD, s4, w0,
-                                 svh, svd, H0, D0, H1, D1);
-    fwd_group<NBOUT, HACT, SAVE>(acc, A1, A0, p + (size_t)n2 * NBOUT * 64, Z, Rl + 8 * n3 * INR_LDS_LD, s4 + 1, w0,
-                                 svh, svd, H1, D1, H0, D0);
+    fwd_group<NBOUT, TL, HACT, SAVE>(acc, A0, A1, p + (size_t)(s4 + 1) * NBOUT * 64, Z, ZP, Rcol, n2, s4, ap, half, svl,
+                                     hsz, H0, D0, E0, H1, D1, E1);
+    fwd_group<NBOUT, TL, HACT, SAVE>(acc, A1, A0, p + (size_t)n2 * NBOUT * 64, Z, ZP, Rcol, n3, s4 + 1, ap, half, svl,
+                                     hsz, H1, D1, E1, H0, D0, E0);
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-// backward: dH_{l-1}^T = W_l^T . dZ_l^T.  R holds dH_l (HASD: multiplied in place by act'(z_l)
-// to give dZ_l, which dW then reads) or dZ_l itself (last layer).  k extent = Mpad8 of layer l.
+// backward: dH_{l-1}^T = W_l^T . dZ_l^T.  R holds dH_l (HASD: turned in place into dZ_l with the
+// stashed act', which dW then reads) or dZ_l itself (last layer).  k extent = Mpad8 of layer l.
 // ---------------------------------------------------------------------------------------------
-template <int NB, bool HASD>
+template <int NB, int TL, bool PAIR, bool HASD>
 __device__ __forceinline__ void dx_group(f32x16 (&acc)[NB], const f32x4 (&a_use)[NB], f32x4 (&a_load)[NB],
-                                         const f32x4* p_next, const float (&g_use)[4], float (&g_load)[4],
-                                         const float (&d_use)[4], float (&d_load)[4], float* Rl_cur,
-                                         const float* Rl_next, const float* dl_next, bool prefetch) {
+                                         const f32x4* p_next, const float (&g_use)[4], const float (&gp_use)[4],
+                                         float (&g_load)[4], float (&gp_load)[4], const float (&d_use)[4],
+                                         const float (&d2_use)[4], float (&d_load)[4], float (&d2_load)[4],
+                                         float* Rcol, int s4, int s4_next, const float* dl, int hsz, int half,
+                                         bool prefetch) {
   if (prefetch) {
     load_afrag<NB>(a_load, p_next);
+    load_z<HASD && PAIR>(g_load, gp_load, Rcol, s4_next, half);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      g_load[e] = Rl_next[(2 * e) * INR_LDS_LD];
-      d_load[e] = HASD ? dl_next[(2 * e) * INR_TILE] : 1.f;
+      d_load[e] = HASD ? dl[(8 * s4_next + 2 * e) * TL] : 1.f;
+      d2_load[e] = (HASD && PAIR) ? dl[hsz + (8 * s4_next + 2 * e) * TL] : 0.f;
     }
   }
   __builtin_amdgcn_sched_barrier(0);
@@ -277,8 +383,13 @@ __device__ __forceinline__ void dx_group(f32x16 (&acc)[NB], const f32x4 (&a_use)
   for (int e = 0; e < 4; ++e) {
     float g = g_use[e];
     if (HASD) {
-      g *= d_use[e];
-      Rl_cur[(2 * e) * INR_LDS_LD] = g;  // dZ_l, read again by dW (rows of the next group are untouched)
+      if (PAIR)
+        g = fmaf(g_use[e], d_use[e], gp_use[e] * d2_use[e]);  // p*dA + q*dB (g_use = Re row, gp_use = Im row)
+      else
+        g *= d_use[e];
+      // dZ_l, read again by dW.  Rows of the prefetched group are untouched; for PAIR both halves
+      // have already read this pair (the loads were issued one group ago, LDS ops stay in order).
+      Rcol[(8 * s4 + 2 * e + half) * INR_LDS_LD] = g;
     }
 #pragma unroll
     for (int m = 0; m < NB; ++m) acc[m] = mfma32(a_use[m][e], g, acc[m]);
@@ -286,95 +397,64 @@ __device__ __forceinline__ void dx_group(f32x16 (&acc)[NB], const f32x4 (&a_use)
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int NB, bool HASD>
+template <int NB, int TL, bool PAIR, bool HASD>
 __device__ __forceinline__ void bwd_dx(f32x16 (&acc)[NB], float* R, const float* __restrict__ wpT, int Mpad8,
                                        const float* __restrict__ sv_d, int wcol, int lane) {
   const int half = lane >> 5, col = lane & 31;
   const f32x4* p = reinterpret_cast<const f32x4*>(wpT) + lane;
   const int n4 = Mpad8 >> 3;
-  float* Rl = R + half * INR_LDS_LD + col;
-  const float* dl = HASD ? sv_d + half * INR_TILE + wcol : nullptr;
+  constexpr int hsz = NB * 32 * TL;
+  float* Rcol = R + col;
+  const float* dl = HASD ? sv_d + half * TL + wcol : nullptr;  // own row's act' entries
   f32x4 A0[NB], A1[NB];
-  float G0[4], G1[4], D0[4], D1[4];
+  float G0[4], P0[4], G1[4], P1[4], D0[4], E0[4], D1[4], E1[4];
   load_afrag<NB>(A0, p);
+  load_z<HASD && PAIR>(G0, P0, Rcol, 0, half);
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    G0[e] = Rl[(2 * e) * INR_LDS_LD];
-    D0[e] = HASD ? dl[(2 * e) * INR_TILE] : 1.f;
+    D0[e] = HASD ? dl[(2 * e) * TL] : 1.f;
+    E0[e] = (HASD && PAIR) ? dl[hsz + (2 * e) * TL] : 0.f;
   }
   if (n4 == 1) {  // last layer: out_features <= 8 -> a single group
-    dx_group<NB, HASD>(acc, A0, A1, p, G0, G1, D0, D1, Rl, Rl, dl, false);
+    dx_group<NB, TL, PAIR, HASD>(acc, A0, A1, p, G0, P0, G1, P1, D0, E0, D1, E1, Rcol, 0, 0, dl, hsz, half, false);
     return;
   }
 #pragma unroll 1
-  for (int s4 = 0; s4 < n4; s4 += 2) {  // n4 even for hidden layers (width % 64 == 0 or NB*4 groups)
+  for (int s4 = 0; s4 < n4; s4 += 2) {  // n4 even for hidden layers
     const int n2 = (s4 + 2 < n4) ? (s4 + 2) : s4;
-    dx_group<NB, HASD>(acc, A0, A1, p + (size_t)(s4 + 1) * NB * 64, G0, G1, D0, D1, Rl + 8 * s4 * INR_LDS_LD,
-                       Rl + 8 * (s4 + 1) * INR_LDS_LD, HASD ? dl + 8 * (s4 + 1) * INR_TILE : nullptr, true);
-    dx_group<NB, HASD>(acc, A1, A0, p + (size_t)n2 * NB * 64, G1, G0, D1, D0, Rl + 8 * (s4 + 1) * INR_LDS_LD,
-                       Rl + 8 * n2 * INR_LDS_LD, HASD ? dl + 8 * n2 * INR_TILE : nullptr, true);
-  }
-}
-
-// first layer: dZ_0 = dH_0 * act'(z_0) is formed while the dX accumulators are stored to the image
-// (there is no dX for the input): 16*NBM independent coalesced stash loads, all in flight together.
-// Buffer descriptor from a wave-uniform pointer (readfirstlane makes the uniformity provable, so
-// hipcc emits plain buffer_load ... offen with an SGPR descriptor instead of waterfall loops or --
-// worse -- 128 hoisted 64-bit VGPR addresses that it then spills around the tile loop).
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* p, int bytes) {
-  const unsigned long long a = reinterpret_cast<unsigned long long>(p);
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
-  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-  void* q = reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
-  return __builtin_amdgcn_make_buffer_rsrc(q, 0, bytes, 0x00020000);
-}
-
-template <int NBM>
-__device__ __forceinline__ void acc_times_d_to_lds(const f32x16 (&acc)[NBM], float* R,
-                                                   const float* __restrict__ sv_d, int wcol, int lane) {
-  const int half = lane >> 5, col = lane & 31;
-  float* Rl = R + (4 * half) * INR_LDS_LD + col;
-  const __amdgpu_buffer_rsrc_t rs = uniform_rsrc(sv_d, NBM * 32 * INR_TILE * 4);
-  const int voff = ((4 * half) * INR_TILE + wcol) * 4;  // one per-lane byte offset for all 16*NBM loads
-#pragma unroll
-  for (int m = 0; m < NBM; ++m) {
-    float d[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-      d[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                           rs, voff, (32 * m + (r & 3) + 8 * (r >> 2)) * INR_TILE * 4, 0));
-    __builtin_amdgcn_sched_barrier(0);  // all 16 loads of the block in flight before the first use
-#pragma unroll
-    for (int r = 0; r < 16; ++r) Rl[(32 * m + (r & 3) + 8 * (r >> 2)) * INR_LDS_LD] = acc[m][r] * d[r];
-    __builtin_amdgcn_sched_barrier(0);
+    dx_group<NB, TL, PAIR, HASD>(acc, A0, A1, p + (size_t)(s4 + 1) * NB * 64, G0, P0, G1, P1, D0, E0, D1, E1, Rcol, s4,
+                                 s4 + 1, dl, hsz, half, true);
+    dx_group<NB, TL, PAIR, HASD>(acc, A1, A0, p + (size_t)n2 * NB * 64, G1, P1, G0, P0, D1, E1, D0, E0, Rcol, s4 + 1,
+                                 n2, dl, hsz, half, true);
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-// dW pass: MT row blocks x one 32-column block n, contraction over the tile's 128 coordinates.
-//   A[k=coord][i=out feature] from the four waves' LDS images (lane = feature),
+// dW pass: MT row blocks x one 32-column block n, contraction over the tile's TL coordinates.
+//   A[k=coord][i=out feature] from the waves' LDS images (lane = feature),
 //   B[k=coord][j=in feature]  from the source functor (lane = feature),
 //   k order: group q of 8 coordinates -> half h takes coords 8q+4h+(0..3) as 4 k-steps.
 // ---------------------------------------------------------------------------------------------
-struct BSrcStash {  // h_{l-1} stash [feature][128]
-  static constexpr int kValuPerMfma = 1;
+template <int TL>
+struct BSrcStash {  // h_{l-1} stash [feature][TL]
   const float* __restrict__ h;
-  struct Raw { f32x4 v; };
-  __device__ __forceinline__ void begin(int, int) {}
+  struct Raw {
+    f32x4 v;
+  };
   __device__ __forceinline__ Raw fetch(int n, int q, int lane) const {
     const int j = 32 * n + (lane & 31);
-    return Raw{*reinterpret_cast<const f32x4*>(h + j * INR_TILE + 8 * q + 4 * (lane >> 5))};
+    return Raw{*reinterpret_cast<const f32x4*>(h + j * TL + 8 * q + 4 * (lane >> 5))};
   }
   __device__ __forceinline__ f32x4 finish(const Raw& r) const { return r.v; }
 };
 
 struct BSrcX {  // x [B,K0] row-major
-  static constexpr int kValuPerMfma = 1;
   const float* __restrict__ x;
   long long row0, B;
   int K0;
-  struct Raw { f32x4 v; };
-  __device__ __forceinline__ void begin(int, int) {}
+  struct Raw {
+    f32x4 v;
+  };
   __device__ __forceinline__ Raw fetch(int n, int q, int lane) const {
     const int j = 32 * n + (lane & 31);
     Raw r;
@@ -400,7 +480,7 @@ __device__ __forceinline__ void dw_group(f32x16 (&acc)[MT], float (&bsum)[MT], c
 #pragma unroll
     for (int m = 0; m < MT; ++m) a_load[e][m] = Rq_next[32 * m * INR_LDS_LD + e];
   __builtin_amdgcn_sched_barrier(0);
-  b_load = bsrc.finish(raw);  // ALU part (sincos for the encoder source) interleaves with the MFMAs
+  b_load = bsrc.finish(raw);
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
 #pragma unroll
@@ -409,11 +489,11 @@ __device__ __forceinline__ void dw_group(f32x16 (&acc)[MT], float (&bsum)[MT], c
       acc[m] = mfma32(a_use[e][m], b_use[e], acc[m]);
     }
   }
-  if (MT >= 4) interleave_mfma_valu<4 * MT, BSrc::kValuPerMfma>();
+  if (MT >= 4) interleave_mfma_valu<4 * MT, 1>();
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int MT, bool FULLM, class BSrc>
+template <int MT, int TL, bool FULLM, class BSrc>
 __device__ __forceinline__ void dw_pass(const float* Rall, int region_stride, BSrc& bsrc, int n, float* slab_w,
                                         float* slab_b, int M, int K, bool first, bool do_bias, int lane) {
   const int half = lane >> 5, li = lane & 31;
@@ -437,7 +517,6 @@ __device__ __forceinline__ void dw_pass(const float* Rall, int region_stride, BS
       }
     }
   }
-  bsrc.begin(n, lane);
   const float* Rl = Rall + li * INR_LDS_LD + 4 * half;
   // software pipeline over groups q of 8 coordinates: operands of group q+1 are fetched while
   // group q is multiplied; coordinate 8q + 4*half + e lives in wave image q>>2, column 8(q&3)+4*half+e
@@ -448,8 +527,8 @@ __device__ __forceinline__ void dw_pass(const float* Rall, int region_stride, BS
 #pragma unroll
     for (int m = 0; m < MT; ++m) A0[e][m] = Rl[32 * m * INR_LDS_LD + e];
 #pragma unroll 1
-  for (int q = 0; q < INR_TILE / 8; q += 2) {
-    const int q2 = (q + 2 < INR_TILE / 8) ? q + 2 : q;
+  for (int q = 0; q < TL / 8; q += 2) {
+    const int q2 = (q + 2 < TL / 8) ? q + 2 : q;
     dw_group<MT, BSrc>(acc, bsum, A0, A1, B0, B1, bsrc, n, q + 1, Rl + ((q + 1) >> 2) * region_stride + 8 * ((q + 1) & 3),
                        lane);
     dw_group<MT, BSrc>(acc, bsum, A1, A0, B1, B0, bsrc, n, q2, Rl + (q2 >> 2) * region_stride + 8 * (q2 & 3), lane);
@@ -486,46 +565,55 @@ __device__ __forceinline__ void dw_pass(const float* Rall, int region_stride, BS
 // Diagnostic phase stamps (never compiled into the shipped library): s_memtime per wave at phase
 // boundaries, written to a buffer nothing else reads.
 #ifdef INR_STAMPS
-#define INR_STAMP(i)                                                                         \
-  do {                                                                                       \
-    __builtin_amdgcn_sched_barrier(0);                                                       \
-    if (a.dbg != nullptr && lane == 0) a.dbg[(blockIdx.x * INR_WAVES + w) * 64 + (i)] = (long long)__builtin_amdgcn_s_memtime(); \
-    __builtin_amdgcn_sched_barrier(0);                                                       \
+#define INR_STAMP(i)                                                                     \
+  do {                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                   \
+    if (a.dbg != nullptr && lane == 0)                                                   \
+      a.dbg[(blockIdx.x * NW + w) * 64 + (i)] = (long long)__builtin_amdgcn_s_memtime(); \
+    __builtin_amdgcn_sched_barrier(0);                                                   \
   } while (0)
 #else
-#define INR_STAMP(i) do {} while (0)
+#define INR_STAMP(i) \
+  do {               \
+  } while (0)
 #endif
 
-template <int NB, int INMODE, int HACT, int MODE>
-__global__ __launch_bounds__(256) void inr_mlp_kernel(const NetDesc nd, const LossDesc ld, const MlpArgs a) {
+template <int NB, int NW, int INMODE, int HACT, int MODE>
+__global__ __launch_bounds__(NW * 64) void inr_mlp_kernel(const NetDesc nd, const LossDesc ld, const MlpArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int TL = NW * 32;                      // coordinates per tile
+  constexpr bool PAIR = HACT == ACT_GABOR;         // complex layers as interleaved (Re, Im) rows
+  constexpr int NS = PAIR ? 3 : 2;                 // stashed tensors per hidden layer
   const int tid = threadIdx.x;
   const int lane = tid & 63, w = tid >> 6;
   const int half = lane >> 5, col = lane & 31;
   const int wcol = w * 32 + col;
   constexpr int RS = NB * 32 * INR_LDS_LD;  // floats per wave image
   float* R = lds + w * RS;
-  float* encB_lds = lds + INR_WAVES * RS;  // [E][3] encoder matrix (gauss mode)
+  float* encB_lds = lds + NW * RS;  // [E][3] encoder matrix (gauss mode)
   if (INMODE == IN_GAUSS) {
-    for (int i = tid; i < 3 * nd.E; i += 256) encB_lds[i] = a.encB[i];
+    for (int i = tid; i < 3 * nd.E; i += NW * 64) encB_lds[i] = a.encB[i];
     __syncthreads();
   }
   const int D = nd.D;
-  const float w0 = nd.w0;
-  constexpr int HSZ = NB * 32 * INR_TILE;  // floats per stashed tensor
+  constexpr int HSZ = NB * 32 * TL;  // floats per stashed tensor
   float* slab = (MODE != MODE_FWD) ? a.slabs + (size_t)blockIdx.x * nd.slab_floats : nullptr;
   float loss_acc = 0.f;
   bool first = true;
   const LayerDesc& LL = nd.L[D - 1];
+  // hidden rows == NB*32 except for WIRE's 181 complex features (362 rows padded to 384); the plan
+  // only pairs NB == 12 with that width (inr_api.hip)
+  constexpr bool HFULL = !(PAIR && NB == 12);
 
   for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
-    const long long row0 = (long long)tile * INR_TILE;
+    const long long row0 = (long long)tile * TL;
     const long long crow = row0 + wcol;
     const bool valid = crow < a.B;
     const bool saving = (MODE != MODE_FWD) || (a.save != nullptr);
     float* sv = a.save;
     if (saving) sv += (size_t)(a.save_by_block ? blockIdx.x : tile) * nd.save_floats_per_tile;
-    float* sv_last = sv + (size_t)2 * (D - 1) * HSZ;  // [4][128]: act'(z_last) of output rows 0..3
+    float* sv_last = sv + (size_t)NS * (D - 1) * HSZ;  // [4][TL]: act'(z_last) of output rows 0..3
+    float* sv_enc = sv_last + 4 * TL;                   // [Kblk0*32][TL] encoder features (gauss mode)
 
     // ================================ forward =================================
     INR_STAMP(0);
@@ -543,56 +631,57 @@ __global__ __launch_bounds__(256) void inr_mlp_kernel(const NetDesc nd, const Lo
             x2 = a.x[3 * crow + 2];
           }
           const float two_pi = 6.283185307179586f;
-          float* sv_enc = sv_last + 4 * INR_TILE;  // [Kblk0*32][128] encoder features (rows >= 2E unused)
           if (saving)
-            fwd_layer0_gauss<NB, true>(acc, a.packed + L0.pf_off, encB_lds, nd.E, two_pi * x0, two_pi * x1,
-                                       two_pi * x2, sv_enc, wcol, lane);
+            fwd_layer0_gauss<NB, TL, true>(acc, a.packed + L0.pf_off, encB_lds, nd.E, two_pi * x0, two_pi * x1,
+                                           two_pi * x2, sv_enc, wcol, lane);
           else
-            fwd_layer0_gauss<NB, false>(acc, a.packed + L0.pf_off, encB_lds, nd.E, two_pi * x0, two_pi * x1,
-                                        two_pi * x2, nullptr, wcol, lane);
+            fwd_layer0_gauss<NB, TL, false>(acc, a.packed + L0.pf_off, encB_lds, nd.E, two_pi * x0, two_pi * x1,
+                                            two_pi * x2, nullptr, wcol, lane);
         } else {
           fwd_layer0_x<NB>(acc, a.packed + L0.pf_off, a.x + (size_t)(valid ? crow : 0) * L0.K, valid, L0.K, L0.Kpad8,
                            lane);
         }
-        acc_to_lds<NB, true>(acc, R, a.params + L0.b_off, lane);
+        acc_to_lds<NB, true>(acc, R, a.packed + L0.pbias_off, lane);
       }
       INR_STAMP(1);
       for (int l = 1; l < D - 1; ++l) {
         const LayerDesc& Ll = nd.L[l];
+        const ActParams ap{nd.L[l - 1].omega, nd.L[l - 1].s0};
         f32x16 acc[NB];
 #pragma unroll
         for (int m = 0; m < NB; ++m) acc[m] = zero16();
-        float* sh = sv + (size_t)(2 * (l - 1)) * HSZ;
+        float* sh = sv + (size_t)(NS * (l - 1)) * HSZ;
         if (saving)
-          fwd_layer<NB, NB, HACT, true>(acc, R, a.packed + Ll.pf_off, w0, sh, sh + HSZ, wcol, lane);
+          fwd_layer<NB, NB, TL, HACT, true>(acc, R, a.packed + Ll.pf_off, ap, sh, wcol, lane);
         else
-          fwd_layer<NB, NB, HACT, false>(acc, R, a.packed + Ll.pf_off, w0, nullptr, nullptr, wcol, lane);
-        acc_to_lds<NB, true>(acc, R, a.params + Ll.b_off, lane);
+          fwd_layer<NB, NB, TL, HACT, false>(acc, R, a.packed + Ll.pf_off, ap, nullptr, wcol, lane);
+        acc_to_lds<NB, true>(acc, R, a.packed + Ll.pbias_off, lane);
         INR_STAMP(1 + l);
       }
       // last layer: out_f <= 4 rows -> registers 0..3 of the lane-half-0 lanes of one row block
       f32x16 accL[1];
       accL[0] = zero16();
       {
-        float* sh = sv + (size_t)(2 * (D - 2)) * HSZ;
+        const ActParams ap{nd.L[D - 2].omega, nd.L[D - 2].s0};
+        float* sh = sv + (size_t)(NS * (D - 2)) * HSZ;
         if (saving)
-          fwd_layer<NB, 1, HACT, true>(accL, R, a.packed + LL.pf_off, w0, sh, sh + HSZ, wcol, lane);
+          fwd_layer<NB, 1, TL, HACT, true>(accL, R, a.packed + LL.pf_off, ap, sh, wcol, lane);
         else
-          fwd_layer<NB, 1, HACT, false>(accL, R, a.packed + LL.pf_off, w0, nullptr, nullptr, wcol, lane);
+          fwd_layer<NB, 1, TL, HACT, false>(accL, R, a.packed + LL.pf_off, ap, nullptr, wcol, lane);
       }
       float y[4], dy[4], g[4];
 #pragma unroll
       for (int o = 0; o < 4; ++o) {
         float z = accL[0][o];
-        if (o < nd.out_f) z += a.params[LL.b_off + o];
-        act_fwd_rt(nd.last_act, z, w0, y[o], dy[o]);
+        if (o < nd.out_f) z += a.packed[LL.pbias_off + o];
+        act_fwd_rt(nd.last_act, z, nd.w0, y[o], dy[o]);
         g[o] = 0.f;
         if (half == 0 && valid && o < nd.out_f && a.out != nullptr) a.out[crow * nd.out_f + o] = y[o];
       }
       if (MODE == MODE_FWD) {
         if (saving && half == 0) {
 #pragma unroll
-          for (int o = 0; o < 4; ++o) sv_last[o * INR_TILE + wcol] = dy[o];
+          for (int o = 0; o < 4; ++o) sv_last[o * TL + wcol] = dy[o];
         }
       } else {
         // fused: pointwise loss of this row (both outputs of a row sit in one half-0 lane)
@@ -618,8 +707,7 @@ __global__ __launch_bounds__(256) void inr_mlp_kernel(const NetDesc nd, const Lo
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           float v = 0.f;
-          if (r < 4 && half == 0 && r < nd.out_f && valid)
-            v = a.dout[crow * nd.out_f + r] * sv_last[r * INR_TILE + wcol];
+          if (r < 4 && half == 0 && r < nd.out_f && valid) v = a.dout[crow * nd.out_f + r] * sv_last[r * TL + wcol];
           R[swz(acc_row(r, half), col)] = v;
         }
       }
@@ -627,19 +715,19 @@ __global__ __launch_bounds__(256) void inr_mlp_kernel(const NetDesc nd, const Lo
       INR_STAMP(11);
       // ---- last layer: dW, db from (dZ_last, h_{D-2}); dH_{D-2} = W_last^T dZ_last
       {
-        BSrcStash bs{sv + (size_t)(2 * (D - 2)) * HSZ};
-        for (int n = w; n < LL.Kblk; n += INR_WAVES)
-          dw_pass<1, false, BSrcStash>(lds, RS, bs, n, slab + LL.w_off, slab + LL.b_off, LL.M, LL.K, first, n == 0,
-                                       lane);
+        BSrcStash<TL> bs{sv + (size_t)(NS * (D - 2)) * HSZ};
+        for (int n = w; n < LL.Kblk; n += NW)
+          dw_pass<1, TL, false, BSrcStash<TL>>(lds, RS, bs, n, slab + LL.gw_off, slab + LL.gb_off, LL.M, LL.K, first,
+                                               n == 0, lane);
       }
       INR_STAMP(12);
       f32x16 gacc[NB];
 #pragma unroll
       for (int m = 0; m < NB; ++m) gacc[m] = zero16();
-      bwd_dx<NB, false>(gacc, R, a.packed + LL.pb_off, LL.Mpad8, nullptr, wcol, lane);
+      bwd_dx<NB, TL, PAIR, false>(gacc, R, a.packed + LL.pb_off, LL.Mpad8, nullptr, wcol, lane);
       __syncthreads();  // all dW reads of the images are done
       if (D == 2)
-        acc_times_d_to_lds<NB>(gacc, R, sv + (size_t)1 * HSZ, wcol, lane);  // R <- dZ_0
+        acc_times_d_to_lds<NB, TL, PAIR>(gacc, R, sv + (size_t)1 * HSZ, sv + (size_t)2 * HSZ, wcol, lane);  // dZ_0
       else
         acc_to_lds<NB, false>(gacc, R, nullptr, lane);  // R <- dH_{D-2}
       INR_STAMP(13);
@@ -649,38 +737,40 @@ __global__ __launch_bounds__(256) void inr_mlp_kernel(const NetDesc nd, const Lo
 #pragma unroll
         for (int m = 0; m < NB; ++m) gacc[m] = zero16();
         // dZ_l = dH_l * act'(z_l) (in place), dH_{l-1} = W_l^T dZ_l
-        bwd_dx<NB, true>(gacc, R, a.packed + Ll.pb_off, Ll.Mpad8, sv + (size_t)(2 * l + 1) * HSZ, wcol, lane);
+        bwd_dx<NB, TL, PAIR, true>(gacc, R, a.packed + Ll.pb_off, Ll.Mpad8, sv + (size_t)(NS * l + 1) * HSZ, wcol,
+                                   lane);
         INR_STAMP(14 + 4 * l);
         __syncthreads();
         INR_STAMP(15 + 4 * l);
         {
-          BSrcStash bs{sv + (size_t)(2 * (l - 1)) * HSZ};
-          for (int n = w; n < Ll.Kblk; n += INR_WAVES)
-            dw_pass<NB, true, BSrcStash>(lds, RS, bs, n, slab + Ll.w_off, slab + Ll.b_off, Ll.M, Ll.K, first, n == 0,
-                                         lane);
+          BSrcStash<TL> bs{sv + (size_t)(NS * (l - 1)) * HSZ};
+          for (int n = w; n < Ll.Kblk; n += NW)
+            dw_pass<NB, TL, HFULL, BSrcStash<TL>>(lds, RS, bs, n, slab + Ll.gw_off, slab + Ll.gb_off, Ll.M, Ll.K,
+                                                  first, n == 0, lane);
         }
         INR_STAMP(16 + 4 * l);
         __syncthreads();
         if (l == 1)
-          acc_times_d_to_lds<NB>(gacc, R, sv + (size_t)1 * HSZ, wcol, lane);  // R <- dZ_0
+          acc_times_d_to_lds<NB, TL, PAIR>(gacc, R, sv + (size_t)1 * HSZ, sv + (size_t)2 * HSZ, wcol, lane);  // dZ_0
         else
-          acc_to_lds<NB, false>(gacc, R, nullptr, lane);                       // R <- dH_{l-1}
+          acc_to_lds<NB, false>(gacc, R, nullptr, lane);  // R <- dH_{l-1}
         INR_STAMP(17 + 4 * l);
       }
-      // ---- first layer: dZ_0 in place, then dW_0 against the (recomputed) input features
+      // ---- first layer: dW_0 against the stashed encoder features / the input matrix
       {
         const LayerDesc& L0 = nd.L[0];
         __syncthreads();  // every wave's dZ_0 is in LDS
         INR_STAMP(40);
         if (INMODE == IN_GAUSS) {
-          BSrcStash bs{sv_last + 4 * INR_TILE};
-          for (int n = w; n < L0.Kblk; n += INR_WAVES)
-            dw_pass<NB, true, BSrcStash>(lds, RS, bs, n, slab + L0.w_off, slab + L0.b_off, L0.M, L0.K, first, n == 0,
-                                         lane);
+          BSrcStash<TL> bs{sv_enc};
+          for (int n = w; n < L0.Kblk; n += NW)
+            dw_pass<NB, TL, HFULL, BSrcStash<TL>>(lds, RS, bs, n, slab + L0.gw_off, slab + L0.gb_off, L0.M, L0.K, first,
+                                                 n == 0, lane);
         } else {
           BSrcX bs{a.x, row0, a.B, L0.K};
-          for (int n = w; n < L0.Kblk; n += INR_WAVES)
-            dw_pass<NB, true, BSrcX>(lds, RS, bs, n, slab + L0.w_off, slab + L0.b_off, L0.M, L0.K, first, n == 0, lane);
+          for (int n = w; n < L0.Kblk; n += NW)
+            dw_pass<NB, TL, HFULL, BSrcX>(lds, RS, bs, n, slab + L0.gw_off, slab + L0.gb_off, L0.M, L0.K, first,
+                                          n == 0, lane);
         }
         INR_STAMP(41);
         __syncthreads();  // images are overwritten by the next tile's forward / dZ_last
@@ -691,22 +781,26 @@ __global__ __launch_bounds__(256) void inr_mlp_kernel(const NetDesc nd, const Lo
   }
 
   if (MODE == MODE_FUSED) {
-    // block loss partial -> slab word P (fixed order: wave shuffle tree, then waves 0..3 in order)
+    // block loss partial -> slab loss word (fixed order: wave shuffle tree, then waves in order)
     float v = loss_acc;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
     __syncthreads();
     if (lane == 0) lds[w] = v;
     __syncthreads();
-    if (tid == 0) slab[nd.P] = ((lds[0] + lds[1]) + lds[2]) + lds[3];
+    if (tid == 0) {
+      float t = 0.f;
+      for (int i = 0; i < NW; ++i) t += lds[i];
+      slab[nd.slab_loss_off] = t;
+    }
   }
 }
 
 // hipFuncSetAttribute + launch
-template <int NB, int INMODE, int HACT, int MODE>
+template <int NB, int NW, int INMODE, int HACT, int MODE>
 inline hipError_t launch_mlp(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int grid, hipStream_t st) {
-  const size_t lds_bytes = ((size_t)INR_WAVES * NB * 32 * INR_LDS_LD + 3 * (size_t)nd.E) * sizeof(float);
-  auto k = inr_mlp_kernel<NB, INMODE, HACT, MODE>;
+  const size_t lds_bytes = ((size_t)NW * NB * 32 * INR_LDS_LD + 3 * (size_t)nd.E) * sizeof(float);
+  auto k = inr_mlp_kernel<NB, NW, INMODE, HACT, MODE>;
   static thread_local bool attr_set = false;
   if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
   if (!attr_set) {
@@ -715,7 +809,7 @@ inline hipError_t launch_mlp(const NetDesc& nd, const LossDesc& ld, const MlpArg
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds_bytes, st, nd, ld, a);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(NW * 64), lds_bytes, st, nd, ld, a);
   return hipGetLastError();
 }
 

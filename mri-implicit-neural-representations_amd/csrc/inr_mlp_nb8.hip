@@ -1,4 +1,5 @@
-// hidden width 256 (the graded SIREN 5x256 / 4x256 shapes)
+// hidden width 256 (the graded SIREN 5x256 / 4x256 shapes), 4 waves = 128-coordinate tiles
 #define INR_NB 8
+#define INR_NW 4
 #define INR_LAUNCH_NAME launch_mlp_nb8
 #include "inr_mlp_inst.h"

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("INR_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "lib", "libinr_mi355x.so")
 
 # enums (include/inr_abi.h)
-KIND_SIREN, KIND_FFN = 0, 1
+KIND_SIREN, KIND_FFN, KIND_WIRE = 0, 1, 2
 ACT_ID, ACT_SIN, ACT_TANH, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3, 4
 INPUT_X, INPUT_GAUSS = 0, 1
 LOSS_L2_HALF, LOSS_L1_HALF, LOSS_TANH, LOSS_LOGSPACE, LOSS_HDR = 0, 1, 2, 3, 4
@@ -22,7 +22,8 @@ LOSS_WORDS = 128  # floats a loss_out buffer must hold (word 0 = loss, 1..64 = o
 class NetDesc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("in_features", C.c_int32), ("width", C.c_int32), ("depth", C.c_int32),
                 ("out_features", C.c_int32), ("last_act", C.c_int32), ("input", C.c_int32),
-                ("enc_size", C.c_int32), ("w0", C.c_float), ("reserved", C.c_int32 * 7)]
+                ("enc_size", C.c_int32), ("w0", C.c_float), ("first_omega_0", C.c_float),
+                ("hidden_omega_0", C.c_float), ("scale_0", C.c_float), ("reserved", C.c_int32 * 4)]
 
 
 class LossDesc(C.Structure):

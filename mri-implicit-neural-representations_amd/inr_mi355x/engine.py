@@ -50,10 +50,12 @@ class MLPEngine:
     in the reference (models/networks.py:48-124; train.py:75-78)."""
 
     def __init__(self, kind: int, in_features: int, width: int, depth: int, out_features: int, last_act: int,
-                 input_mode: int = L.INPUT_X, enc_size: int = 0, w0: float = 30.0):
+                 input_mode: int = L.INPUT_X, enc_size: int = 0, w0: float = 30.0, first_omega_0: float = 0.0,
+                 hidden_omega_0: float = 0.0, scale_0: float = 0.0):
         self.lib = L.load()
         desc = L.NetDesc(kind=kind, in_features=in_features, width=width, depth=depth, out_features=out_features,
-                         last_act=last_act, input=input_mode, enc_size=enc_size, w0=w0)
+                         last_act=last_act, input=input_mode, enc_size=enc_size, w0=w0,
+                         first_omega_0=first_omega_0, hidden_omega_0=hidden_omega_0, scale_0=scale_0)
         self.desc = desc
         plan = C.c_void_p()
         L.check(self.lib.inr_plan_create(C.byref(desc), C.byref(plan)))

@@ -53,6 +53,13 @@ class Positional_Encoder:
         return x
 
 
+def _view(flat: torch.Tensor, off: int, n: int, shape, is_complex: bool) -> torch.Tensor:
+    """View of the flat fp32 buffer as the parameter tensor (complex64 = interleaved (re, im) pairs)."""
+    if is_complex:
+        return torch.view_as_complex(flat[off:off + n].view(*shape, 2))
+    return flat[off:off + n].view(shape)
+
+
 class _MLPFunction(torch.autograd.Function):
     """Tier-1 bridge: ``model(x)`` + ``loss.backward()`` + stock ``torch.optim.Adam`` work unchanged."""
 
@@ -73,7 +80,7 @@ class _MLPFunction(torch.autograd.Function):
         module = ctx.module
         eng = module._engine()
         flat_grad = eng.backward(x, None, dout.contiguous())
-        grads = [flat_grad[o:o + n].view(s) for (o, n, s) in module._layout]
+        grads = [_view(flat_grad, o, n, s, c) for (o, n, s, c) in module._layout]
         return (None, None, *grads)
 
 
@@ -92,9 +99,63 @@ class _SirenLayerShell(nn.Module):
         self.linear = holder  # key: model.{k}.linear.weight / .bias
 
 
-class _FlatMLP(nn.Module):
-    """Common machinery: flat parameter buffer + views + engine."""
+class _FlatModel(nn.Module):
+    """Common machinery: ONE flat fp32 parameter buffer, nn.Parameters that are views of it (in
+    state_dict order), and the engine bound to it."""
 
+    def _flatten(self, tensors: List[torch.Tensor]) -> List[nn.Parameter]:
+        """tensors: the trainable tensors in state_dict order (real or complex64)."""
+        reals = [torch.view_as_real(t) if t.is_complex() else t for t in tensors]
+        P = sum(r.numel() for r in reals)
+        flat = torch.empty(P)
+        self._layout = []
+        off = 0
+        for t, r in zip(tensors, reals):
+            flat[off:off + r.numel()] = r.reshape(-1)
+            self._layout.append((off, r.numel(), tuple(t.shape), t.is_complex()))
+            off += r.numel()
+        self._flat = flat
+        self._eng: Optional[MLPEngine] = None
+        self._flat_params = [nn.Parameter(_view(flat, o, n, s, c)) for (o, n, s, c) in self._layout]
+        return self._flat_params
+
+    # moving the module re-points every parameter at a view of the moved flat buffer
+    def _apply(self, fn, recurse=True):
+        new_flat = fn(self._flat)
+        for p, (o, n, s, c) in zip(self._flat_params, self._layout):
+            p.data = _view(new_flat, o, n, s, c)
+            p.grad = None
+        for p in self.parameters():  # frozen extras (WIRE's omega_0 / scale_0) are ordinary tensors
+            if not any(p is q for q in self._flat_params):
+                p.data = fn(p.data)
+        self._flat = new_flat
+        self._eng = None
+        return self
+
+    def _make_engine(self, input_mode: int, enc_size: int) -> MLPEngine:
+        raise NotImplementedError
+
+    def _engine(self) -> MLPEngine:
+        if not self._flat.is_cuda:
+            raise RuntimeError("inr_mi355x models run on an MI355X only: call .to('cuda') first (no CPU fallback)")
+        if self._eng is None:
+            self._eng = self._make_engine(L.INPUT_X, 0)
+            self._eng.bind(self._flat)
+        return self._eng
+
+    def fused_engine(self, enc_size: int) -> MLPEngine:
+        """Tier-2 engine over the SAME flat parameters with the gauss encoder fused into layer 0."""
+        if not self._flat.is_cuda:
+            raise RuntimeError("inr_mi355x models run on an MI355X only: call .to('cuda') first (no CPU fallback)")
+        eng = self._make_engine(L.INPUT_GAUSS, enc_size)
+        eng.bind(self._flat)
+        return eng
+
+    def forward(self, x):
+        return _MLPFunction.apply(self, x, *self._flat_params)
+
+
+class _FlatMLP(_FlatModel):
     _kind = L.KIND_SIREN
 
     def _build(self, dims: List[int], init_fn, key_modules, last_act: int):
@@ -102,55 +163,16 @@ class _FlatMLP(nn.Module):
         in the reference's order."""
         self._dims = dims
         self._last_act = last_act
-        tensors = [init_fn(k, dims[k], dims[k + 1]) for k in range(len(dims) - 1)]
-        P = sum(w.numel() + b.numel() for w, b in tensors)
-        flat = torch.empty(P)
-        self._layout = []
-        off = 0
-        for w, b in tensors:
-            for t in (w, b):
-                flat[off:off + t.numel()] = t.reshape(-1)
-                self._layout.append((off, t.numel(), tuple(t.shape)))
-                off += t.numel()
-        self._flat = flat
-        self._eng: Optional[MLPEngine] = None
-        holders = []
+        tensors = []
         for k in range(len(dims) - 1):
-            ow, nw, sw = self._layout[2 * k]
-            ob, nb_, sb = self._layout[2 * k + 1]
-            holders.append(_Holder(nn.Parameter(flat[ow:ow + nw].view(sw)), nn.Parameter(flat[ob:ob + nb_].view(sb))))
+            tensors += list(init_fn(k, dims[k], dims[k + 1]))
+        ps = self._flatten(tensors)
+        holders = [_Holder(ps[2 * k], ps[2 * k + 1]) for k in range(len(dims) - 1)]
         self.model = key_modules(holders)
 
-    # moving the module re-points every parameter at a view of the moved flat buffer
-    def _apply(self, fn, recurse=True):
-        new_flat = fn(self._flat)
-        params = list(self.parameters())
-        for p, (o, n, s) in zip(params, self._layout):
-            p.data = new_flat[o:o + n].view(s)
-            if p.grad is not None:
-                p.grad = None
-        self._flat = new_flat
-        self._eng = None
-        return self
-
-    def _engine(self) -> MLPEngine:
-        if not self._flat.is_cuda:
-            raise RuntimeError("inr_mi355x models run on an MI355X only: call .to('cuda') first (no CPU fallback)")
-        if self._eng is None:
-            d = self._dims
-            self._eng = MLPEngine(self._kind, d[0], d[1], len(d) - 1, d[-1], self._last_act, L.INPUT_X, 0, SIREN_W0)
-            self._eng.bind(self._flat)
-        return self._eng
-
-    def fused_engine(self, enc_size: int) -> MLPEngine:
-        """Tier-2 engine over the SAME flat parameters with the gauss encoder fused into layer 0."""
+    def _make_engine(self, input_mode: int, enc_size: int) -> MLPEngine:
         d = self._dims
-        eng = MLPEngine(self._kind, d[0], d[1], len(d) - 1, d[-1], self._last_act, L.INPUT_GAUSS, enc_size, SIREN_W0)
-        eng.bind(self._flat)
-        return eng
-
-    def forward(self, x):
-        return _MLPFunction.apply(self, x, *self.parameters())
+        return MLPEngine(self._kind, d[0], d[1], len(d) - 1, d[-1], self._last_act, input_mode, enc_size, SIREN_W0)
 
 
 class SIREN(_FlatMLP):
@@ -206,3 +228,52 @@ class FFN(_FlatMLP):
             return nn.Sequential(*mods)
 
         self._build(dims, init_fn, seq, L.ACT_SIGMOID)
+
+
+class _GaborLayerShell(nn.Module):
+    """ComplexGaborLayer's parameter set (networks.py:191-197): frozen omega_0, scale_0, then linear."""
+
+    def __init__(self, omega0: float, sigma0: float, holder: _Holder):
+        super().__init__()
+        self.omega_0 = nn.Parameter(omega0 * torch.ones(1), False)
+        self.scale_0 = nn.Parameter(sigma0 * torch.ones(1), False)
+        self.linear = holder
+
+
+class WIRE(_FlatModel):
+    """networks.py:206-260.  Complex64 layers; ``hidden = int(network_width / sqrt(2))`` (:228);
+    ``network_depth`` counts the hidden complex layers (:241-245); output is the real part (:257-258)
+    -- returned here as a contiguous [B,2] tensor (the reference returns the strided ``.real`` view)."""
+
+    def __init__(self, params):
+        super().__init__()
+        self.hidden_layers = params["network_depth"]
+        in_features = params["network_input_size"]
+        out_features = params["network_output_size"]
+        self.first_omega_0 = params["first_omega_0"]
+        self.hidden_omega_0 = params["hidden_omega_0"]
+        self.scale = params["scale"]
+        self.hidden_features = int(params["network_width"] / np.sqrt(2))
+        self.in_features, self.out_features = in_features, out_features
+        hid = self.hidden_features
+        tensors = []
+        lin = nn.Linear(in_features, hid, dtype=torch.float)  # is_first: real weights (networks.py:185-197)
+        tensors += [lin.weight.detach(), lin.bias.detach()]
+        for _ in range(self.hidden_layers):
+            lin = nn.Linear(hid, hid, dtype=torch.cfloat)
+            tensors += [lin.weight.detach(), lin.bias.detach()]
+        lin = nn.Linear(hid, out_features, dtype=torch.cfloat)  # final_linear (networks.py:247-250)
+        tensors += [lin.weight.detach(), lin.bias.detach()]
+        ps = self._flatten(tensors)
+        mods = [_GaborLayerShell(self.first_omega_0, self.scale, _Holder(ps[0], ps[1]))]
+        for k in range(self.hidden_layers):
+            mods.append(_GaborLayerShell(self.hidden_omega_0, self.scale, _Holder(ps[2 + 2 * k], ps[3 + 2 * k])))
+        mods.append(_Holder(ps[-2], ps[-1]))
+        self.net = nn.Sequential(*mods)
+
+    def _make_engine(self, input_mode: int, enc_size: int) -> MLPEngine:
+        if input_mode != L.INPUT_X:
+            raise NotImplementedError("WIRE takes raw coordinates (encoder.embedding: none)")
+        return MLPEngine(L.KIND_WIRE, self.in_features, self.hidden_features, self.hidden_layers, self.out_features,
+                         L.ACT_ID, L.INPUT_X, 0, 0.0, float(self.first_omega_0), float(self.hidden_omega_0),
+                         float(self.scale))

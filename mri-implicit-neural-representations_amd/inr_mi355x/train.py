@@ -27,10 +27,10 @@ import yaml
 from . import _lib as L
 from .engine import LossSpec
 from .evalchain import psnr, reconstruct
-from .networks import FFN, SIREN, Positional_Encoder
+from .networks import FFN, SIREN, WIRE, Positional_Encoder
 from .synthetic import make_kspace
 
-MODELS = {"SIREN": SIREN, "FFN": FFN}
+MODELS = {"SIREN": SIREN, "FFN": FFN, "WIRE": WIRE}
 
 
 def get_config(path: str) -> dict:
@@ -186,7 +186,7 @@ class INRTrainer:
         """Same dict as train.py:247-250 ('opt' in torch.optim.Adam.state_dict() layout)."""
         sd = self.model.state_dict()
         state, o = {}, 0
-        for i, (off, n, shp) in enumerate(self.model._layout):
+        for i, (off, n, shp, _c) in enumerate(self.model._layout):
             state[i] = {"step": torch.tensor(float(self.engine.step)),
                         "exp_avg": self.engine.exp_avg[off:off + n].view(shp).clone(),
                         "exp_avg_sq": self.engine.exp_avg_sq[off:off + n].view(shp).clone()}

@@ -136,7 +136,7 @@ def test_tier2_fused_golden(dev, name):
             if step == 1 and wd_tag == "wd0":
                 torch.testing.assert_close(loss.cpu(), _t(arrs["loss"]), rtol=1e-5, atol=0)
                 flat = eng.grads.cpu()
-                for (off, n, shp), (k, _) in zip(model._layout, model.named_parameters()):
+                for (off, n, shp, _c), (k, _) in zip(model._layout, model.named_parameters()):
                     ref = _t(arrs["grad/" + k])
                     torch.testing.assert_close(flat[off:off + n].view(shp), ref, rtol=1e-4, atol=1e-7,
                                                msg=lambda m: f"{k}: {m}")

@@ -77,7 +77,7 @@ def test_dropin_init_bit_exact(name):
     assert sum(p.numel() for p in model.parameters()) == ent["n_params"]
     # parameters are views of one flat buffer, in state_dict order
     flat = model._flat
-    for p, (o, n, s) in zip(model.parameters(), model._layout):
+    for p, (o, n, s, _c) in zip(model.parameters(), model._layout):
         assert p.data_ptr() == flat.data_ptr() + 4 * o and tuple(p.shape) == s
 
 

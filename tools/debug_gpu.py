@@ -26,6 +26,6 @@ for name in sys.argv[1:] or ["SIREN"]:
         l = eng.train_step(coords, enc.B.contiguous(), gt, M.LossSpec(L.LOSS_L2_HALF))
         print(name, "fused loss", float(l))
         flat = eng.grads.cpu()
-        for (off, n, shp), (k, _) in zip(model._layout, model.named_parameters()):
+        for (off, n, shp, _c), (k, _) in zip(model._layout, model.named_parameters()):
             ref = _t(arrs["grad/"+k]); g = flat[off:off+n].view(shp)
             print("  fused", k, "rel", rel(g, ref), "|g|", float(g.abs().max()))
