@@ -12,7 +12,14 @@ for p in (ROOT, PKG):
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def _usable_cores() -> int:
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return max(1, min(n, 16))  # a GPU box exposes 256 cores but gives one job a 16-core share
+
+
 def pytest_configure(config):
+    import torch
+    torch.set_num_threads(_usable_cores())
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 

@@ -218,7 +218,6 @@ def test_persistent_blocks_and_determinism(dev):
     g_a = eng.grads.clone()
     l_b = eng.train_step(coords.to(dev), enc.B.contiguous(), gt.to(dev), spec).clone()
     assert torch.equal(g_a, eng.grads) and torch.equal(l_a, l_b)
-    torch.set_num_threads(os.cpu_count() or 8)
     _, ref_loss, ref_grad = _oracle_grads(sd, enc.B.cpu(), coords, gt, FULL_NET)
     torch.testing.assert_close(l_a.cpu(), ref_loss, rtol=1e-5, atol=0)
     assert rel_l2(g_a.cpu(), ref_grad) < 1e-5

@@ -10,7 +10,15 @@ import torch
 
 import oracle as O
 
-torch.set_num_threads(1)
+
+
+@pytest.fixture(autouse=True)
+def _single_thread():
+    """The golden vectors were generated single-threaded (fixed reduction order)."""
+    n = torch.get_num_threads()
+    torch.set_num_threads(1)
+    yield
+    torch.set_num_threads(n)
 
 
 def _load(golden_dir, name):
