@@ -7,6 +7,7 @@ namespace inr {
 
 struct AdamArgs {
   int do_update;      // 0: pack only
+  int all_real;       // set by the launcher: every layer is LT_REAL (fast scatter path)
   float step_size;    // lr / (1 - beta1^t), computed in double on the host like torch does
   float bc2_sqrt;     // sqrt(1 - beta2^t)
   float omb1;         // float(1 - beta1): the lerp weight torch passes to exp_avg.lerp_

@@ -106,10 +106,56 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const NetDesc nd, con
   }
 }
 
+// Fast path when a slab has the flat-parameter layout (every layer LT_REAL).  A workgroup owns 256
+// consecutive gradient entries (64 lanes x 16 B); its four waves each sum a contiguous quarter of
+// the slabs (8 independent 16-byte loads in flight per lane) and the quarters are combined through
+// LDS in wave order -- a fixed summation tree, so results are bitwise reproducible.
+__global__ __launch_bounds__(256) void reduce_slabs_real_kernel(const float* __restrict__ slabs, int n_blocks,
+                                                                int slab_floats, int P, int loss_off,
+                                                                float* __restrict__ grads,
+                                                                float* __restrict__ loss_out) {
+  __shared__ f32x4 part[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i4 = (blockIdx.x * 64 + lane) * 4;
+  const int per = (n_blocks + 3) / 4;
+  const int b0 = w * per, b1 = (b0 + per < n_blocks) ? b0 + per : n_blocks;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (i4 < P) {
+    int b = b0;
+    for (; b + 8 <= b1; b += 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(slabs + (size_t)(b + u) * slab_floats + i4);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; b < b1; ++b) s += *reinterpret_cast<const f32x4*>(slabs + (size_t)b * slab_floats + i4);
+  }
+  part[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && i4 < P) {
+    const f32x4 t = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+    for (int j = 0; j < 4 && i4 + j < P; ++j) grads[i4 + j] = t[j];
+  }
+  if (loss_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+    float lsum = 0.f;
+    for (int b = 0; b < n_blocks; ++b) lsum += slabs[(size_t)b * slab_floats + loss_off];
+    loss_out[0] = lsum;
+  }
+}
+
 hipError_t launch_reduce_slabs(const NetDesc& nd, const float* slabs, int n_blocks, float* grads, float* loss_out,
                                hipStream_t st) {
-  const int grid = (nd.P + 255) / 256;
-  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(grid), dim3(256), 0, st, nd, slabs, n_blocks, grads, loss_out);
+  bool all_real = true;
+  for (int l = 0; l < nd.D; ++l) all_real = all_real && nd.L[l].ltype == LT_REAL;
+  if (all_real) {  // slab offsets == flat offsets; slab_floats % 64 == 0 keeps every slab 16-byte aligned
+    const int grid = (nd.P + 255) / 256;
+    hipLaunchKernelGGL(reduce_slabs_real_kernel, dim3(grid), dim3(256), 0, st, slabs, n_blocks, nd.slab_floats, nd.P,
+                       nd.slab_loss_off, grads, loss_out);
+  } else {
+    const int grid = (nd.P + 255) / 256;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(grid), dim3(256), 0, st, nd, slabs, n_blocks, grads, loss_out);
+  }
   return hipGetLastError();
 }
 
@@ -157,6 +203,24 @@ __global__ __launch_bounds__(256) void adam_pack_kernel(const NetDesc nd, float*
     m2[i] = v;
     params[i] = p;
   }
+  if (aa.all_real) {  // SIREN / FFN: one weight entry or one bias entry, no sign, no pair
+    for (int l = 0; l < nd.D; ++l) {
+      const LayerDesc& L = nd.L[l];
+      const int off = i - L.w_off;
+      if (off >= 0 && off < L.wn) {
+        const int row = off / L.K, k = off - row * L.K;
+        put_fwd(nd, L, l, packed, row, k, p);
+        if (l >= 1) put_tr(L, packed, row, k, p);
+        return;
+      }
+      const int ob = i - L.b_off;
+      if (ob >= 0 && ob < L.bn) {
+        packed[L.pbias_off + ob] = p;
+        return;
+      }
+    }
+    return;
+  }
   int l;
   VirtualPos vp;
   if (!locate(nd, i, l, vp)) return;
@@ -169,7 +233,10 @@ __global__ __launch_bounds__(256) void adam_pack_kernel(const NetDesc nd, float*
 }
 
 hipError_t launch_adam_pack(const NetDesc& nd, float* params, const float* grads, float* m1, float* m2,
-                            float* packed, const AdamArgs& aa, hipStream_t st) {
+                            float* packed, const AdamArgs& aa_in, hipStream_t st) {
+  AdamArgs aa = aa_in;
+  aa.all_real = 1;
+  for (int l = 0; l < nd.D; ++l) aa.all_real = aa.all_real && nd.L[l].ltype == LT_REAL;
   const int grid = (nd.P + 255) / 256;
   hipLaunchKernelGGL(adam_pack_kernel, dim3(grid), dim3(256), 0, st, nd, params, grads, m1, m2, packed, aa);
   return hipGetLastError();

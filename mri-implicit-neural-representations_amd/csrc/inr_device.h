@@ -78,7 +78,12 @@ __device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (
 // Padded [feature][33] LDS image of one wave's 32 coordinates: conflict-free both for
 // "lane = coord" accesses (forward / dX B operand, epilogue stores) and for "lane = feature"
 // reads (dW A operand), and every address is  lane-part + compile-time immediate.
-#define INR_LDS_LD 33
+// Row stride (floats) of the image.  36 where the workgroup's images fit 160 KB (16-byte aligned rows:
+// the dW A operand is then ONE ds_read_b128 per 4 k-steps, conflict-free because 36*i mod 64 walks all
+// 16 four-bank slots); 33 for the 12-block WIRE shape (3 x 384 x 36 x 4 B would be 166 KB).
+#ifndef INR_LDS_LD
+#define INR_LDS_LD 36
+#endif
 __device__ __forceinline__ int swz(int feat, int col) { return feat * INR_LDS_LD + col; }
 
 // Branch-free sincos for |x| <= 2^16: three-constant Cody-Waite reduction by pi/2 with FMA, then

@@ -470,32 +470,42 @@ struct BSrcX {  // x [B,K0] row-major
   __device__ __forceinline__ f32x4 finish(const Raw& r) const { return r.v; }
 };
 
-template <int MT, class BSrc>
-__device__ __forceinline__ void dw_group(f32x16 (&acc)[MT], float (&bsum)[MT], const float (&a_use)[4][MT],
-                                         float (&a_load)[4][MT], const f32x4& b_use, f32x4& b_load, BSrc& bsrc,
+// the 4 k-steps of one row block: A[coord 8q+4h+e][feature 32m+li], e = 0..3 (contiguous in the image row)
+template <int MT>
+__device__ __forceinline__ void load_dw_a(f32x4 (&a)[MT], const float* Rq) {
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    if ((INR_LDS_LD & 3) == 0) {
+      a[m] = *reinterpret_cast<const f32x4*>(Rq + 32 * m * INR_LDS_LD);  // ds_read_b128
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[m][e] = Rq[32 * m * INR_LDS_LD + e];
+    }
+  }
+}
+
+template <int MT, bool BIAS, class BSrc>
+__device__ __forceinline__ void dw_group(f32x16 (&acc)[MT], float (&bsum)[MT], const f32x4 (&a_use)[MT],
+                                         f32x4 (&a_load)[MT], const f32x4& b_use, f32x4& b_load, BSrc& bsrc,
                                          int n, int q_next, const float* Rq_next, int lane) {
   const typename BSrc::Raw raw = bsrc.fetch(n, q_next, lane);
-#pragma unroll
-  for (int e = 0; e < 4; ++e)
-#pragma unroll
-    for (int m = 0; m < MT; ++m) a_load[e][m] = Rq_next[32 * m * INR_LDS_LD + e];
+  load_dw_a<MT>(a_load, Rq_next);
   __builtin_amdgcn_sched_barrier(0);
   b_load = bsrc.finish(raw);
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-      bsum[m] += a_use[e][m];
-      acc[m] = mfma32(a_use[e][m], b_use[e], acc[m]);
+      if (BIAS) bsum[m] += a_use[m][e];
+      acc[m] = mfma32(a_use[m][e], b_use[e], acc[m]);
     }
   }
-  if (MT >= 4) interleave_mfma_valu<4 * MT, 1>();
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int MT, int TL, bool FULLM, class BSrc>
-__device__ __forceinline__ void dw_pass(const float* Rall, int region_stride, BSrc& bsrc, int n, float* slab_w,
-                                        float* slab_b, int M, int K, bool first, bool do_bias, int lane) {
+template <int MT, int TL, bool FULLM, bool BIAS, class BSrc>
+__device__ __forceinline__ void dw_pass_impl(const float* Rall, int region_stride, BSrc& bsrc, int n, float* slab_w,
+                                             float* slab_b, int M, int K, bool first, int lane) {
   const int half = lane >> 5, li = lane & 31;
   f32x16 acc[MT];
   float bsum[MT];
@@ -521,17 +531,15 @@ __device__ __forceinline__ void dw_pass(const float* Rall, int region_stride, BS
   // software pipeline over groups q of 8 coordinates: operands of group q+1 are fetched while
   // group q is multiplied; coordinate 8q + 4*half + e lives in wave image q>>2, column 8(q&3)+4*half+e
   f32x4 B0 = bsrc.finish(bsrc.fetch(n, 0, lane)), B1;
-  float A0[4][MT], A1[4][MT];
-#pragma unroll
-  for (int e = 0; e < 4; ++e)
-#pragma unroll
-    for (int m = 0; m < MT; ++m) A0[e][m] = Rl[32 * m * INR_LDS_LD + e];
+  f32x4 A0[MT], A1[MT];
+  load_dw_a<MT>(A0, Rl);
 #pragma unroll 1
   for (int q = 0; q < TL / 8; q += 2) {
     const int q2 = (q + 2 < TL / 8) ? q + 2 : q;
-    dw_group<MT, BSrc>(acc, bsum, A0, A1, B0, B1, bsrc, n, q + 1, Rl + ((q + 1) >> 2) * region_stride + 8 * ((q + 1) & 3),
-                       lane);
-    dw_group<MT, BSrc>(acc, bsum, A1, A0, B1, B0, bsrc, n, q2, Rl + (q2 >> 2) * region_stride + 8 * (q2 & 3), lane);
+    dw_group<MT, BIAS, BSrc>(acc, bsum, A0, A1, B0, B1, bsrc, n, q + 1,
+                             Rl + ((q + 1) >> 2) * region_stride + 8 * ((q + 1) & 3), lane);
+    dw_group<MT, BIAS, BSrc>(acc, bsum, A1, A0, B1, B0, bsrc, n, q2, Rl + (q2 >> 2) * region_stride + 8 * (q2 & 3),
+                             lane);
   }
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
@@ -550,12 +558,22 @@ __device__ __forceinline__ void dw_pass(const float* Rall, int region_stride, BS
         if (colok && rowu + 4 * half < M) slab_w[(size_t)rowu * K + lane_off] = acc[m][r];
       }
     }
-    if (do_bias) {
+    if (BIAS) {
       const float tot = bsum[m] + __shfl_xor(bsum[m], 32);
       const int row = 32 * m + li;
       if (half == 0 && (FULLM || row < M)) slab_b[row] = first ? tot : slab_b[row] + tot;
     }
   }
+}
+
+// the column-block-0 pass also produces db (the row sums of dZ), the others skip that VALU work
+template <int MT, int TL, bool FULLM, class BSrc>
+__device__ __forceinline__ void dw_pass(const float* Rall, int region_stride, BSrc& bsrc, int n, float* slab_w,
+                                        float* slab_b, int M, int K, bool first, bool do_bias, int lane) {
+  if (do_bias)
+    dw_pass_impl<MT, TL, FULLM, true, BSrc>(Rall, region_stride, bsrc, n, slab_w, slab_b, M, K, first, lane);
+  else
+    dw_pass_impl<MT, TL, FULLM, false, BSrc>(Rall, region_stride, bsrc, n, slab_w, slab_b, M, K, first, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
