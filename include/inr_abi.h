@@ -43,7 +43,11 @@ extern "C" {
 enum inr_kind {
   INR_KIND_SIREN = 0, /* models/networks.py:99-124  SIREN / SirenLayer :74-96 */
   INR_KIND_FFN = 1,   /* models/networks.py:48-69   FFN (ReLU hidden, Sigmoid output) */
-  INR_KIND_WIRE = 2   /* models/networks.py:206-260 WIRE / ComplexGaborLayer :160-204 (complex64 layers) */
+  INR_KIND_WIRE = 2,  /* models/networks.py:206-260 WIRE / ComplexGaborLayer :160-204 (complex64 layers) */
+  INR_KIND_FOURIER = 3,   /* models/mfn.py:61-94    FourierNet (one output_linear after the last stage) */
+  INR_KIND_MSFOURIER = 4  /* models/mfn.py:206-267  MultiscaleKFourier: heads output_linear[i], i in [1,3,5,7];
+                             the unused last stage / heads exist in flat params but are never evaluated or
+                             stepped (the reference leaves their .grad = None) */
 };
 
 /* activation of the last layer */
@@ -97,7 +101,13 @@ typedef struct inr_loss_desc {
   float factor;       /* loss_opts.hdr_ff_factor */
   float inv_count;    /* 1 / (number of rows entering the mean, summed over all ranks) */
   float hdr_A;        /* mean_i((1-f_i)^2) over the batch's kcoords (HDR only) */
-  int32_t reserved[2];
+  float scale;        /* multiplies the pointwise loss; 0 means 1.  The multiscale loop uses 0.5*loss_fn
+                         (train_kspace_multiscale.py:188-190): 0.5 for LogSpace, 1 for the *_HALF kinds */
+  /* ConsistencyLoss between consecutive heads (metrics/losses.py:315-324; multiscale kinds only) */
+  float cons_w;       /* 0.1 (train_kspace_multiscale.py:179); 0 disables */
+  int32_t cons_chan;  /* 2: dist is [B] (rows compared); 1: per-coil dist [B,1] -> channel 0 only */
+  float cons_lo[4], cons_hi[4]; /* bounds[i] of pair i: rows with dist < lo or dist > hi are compared */
+  float cons_inv[4];  /* 1 / (number of compared elements of pair i over all ranks); 0 when the pair is empty */
 } inr_loss_desc;
 
 typedef struct inr_plan inr_plan;
@@ -159,6 +169,21 @@ int inr_train_step(const inr_plan* plan, const inr_loss_desc* loss, const float*
                    const float* packed, const float* x, const float* enc_B, const float* gt,
                    const uint8_t* mask, int64_t B, float* save, float* slabs, float* grads,
                    float* loss_out, void* stream);
+
+/* Multi-head networks (MultiscaleKFourier.forward returns a list, mfn.py:255-267): `out` / `dout` are
+ * [n_heads][B][out_features]; `dist` [B] = dist_to_center (nerp_datasets.py:385), read by the
+ * consistency term; `save` is always required (it also carries the encoder features between stages;
+ * pass n_blocks slots and by_block = 1 for a no_grad sweep, n_tiles slots and 0 before inr_backward_multi). */
+int inr_forward_multi(const inr_plan* plan, const float* params, const float* packed, const float* coords,
+                      const float* enc_B, int64_t B, float* out, float* save, int32_t by_block, void* stream);
+int inr_backward_multi(const inr_plan* plan, const float* params, const float* packed, const float* coords,
+                       const float* enc_B, int64_t B, const float* dout, const float* save, float* slabs,
+                       float* grads, void* stream);
+int inr_train_step_multi(const inr_plan* plan, const inr_loss_desc* loss, const float* params,
+                         const float* packed, const float* coords, const float* enc_B, const float* gt,
+                         const float* dist, const uint8_t* mask, int64_t B, float* save, float* slabs,
+                         float* grads, float* loss_out, void* stream);
+int inr_plan_heads(const inr_plan* plan, int32_t* n_heads);
 
 /* Replaces torch.optim.Adam.step (train.py:76,190; eps 1e-8, amsgrad False, L2-style
  * weight_decay) plus the L1/L2 "regularization" gradient terms (models/regularization.py:21-36),

@@ -43,6 +43,120 @@ struct inr_plan {
   int64_t packed_floats;
 };
 
+// Multiplicative filter networks (models/mfn.py).  L[] = filters 0..n | linears 0..n-1 | heads; flat
+// parameters keep the state_dict order  linear.* , output_linear(.k).* , filters.*  (SURVEY Appendix B).
+static int create_mfn_plan(const inr_net_desc* d, inr_plan** out) {
+  const bool multi = d->kind == INR_KIND_MSFOURIER;
+  const int n = d->depth, W = d->width;
+  if (n < 1 || 2 * n + 1 + (multi ? n + 1 : 1) > INR_MAX_LAYERS)
+    return fail(INR_ERR_INVALID, "inr_plan_create: MFN depth %d", n);
+  if (W != 32 && W != 256 && W != 512)
+    return fail(INR_ERR_UNSUPPORTED, "inr_plan_create: MFN width %d (kernels are built for 32, 256 and 512)", W);
+  if (d->input != INR_INPUT_GAUSS || d->enc_size < 8 || (d->enc_size % 8) != 0 || d->in_features != 2 * d->enc_size)
+    return fail(INR_ERR_UNSUPPORTED, "inr_plan_create: MFN kernels need the fused gauss encoder (in_features == 2*enc_size, "
+                "enc_size %% 8 == 0)");
+  if (d->out_features < 1 || d->out_features > 4)
+    return fail(INR_ERR_UNSUPPORTED, "inr_plan_create: out_features %d outside [1,4]", d->out_features);
+  inr_plan* p = new (std::nothrow) inr_plan();
+  if (p == nullptr) return fail(INR_ERR_INVALID, "inr_plan_create: out of host memory");
+  p->desc = *d;
+  NetDesc& nd = p->nd;
+  memset(&nd, 0, sizeof(nd));
+  const int NB = W / 32;
+  nd.NB = NB;
+  nd.NW = NB == 16 ? 2 : 4;
+  nd.hact = ACT_SIN;
+  nd.last_act = ACT_ID;
+  nd.input = IN_GAUSS;
+  nd.E = d->enc_size;
+  nd.out_f = d->out_features;
+  nd.mfn_n = n;
+  // heads: FourierNet -> output_linear after the last stage (mfn.py:85-94); multiscale -> output_linear[i]
+  // for i in output_layers = [1,3,5,7] (mfn.py:223,262-263), those beyond depth do not exist
+  if (multi) {
+    const int stages[4] = {1, 3, 5, 7};
+    for (int k = 0; k < 4; ++k)
+      if (stages[k] <= n) nd.head_stage[nd.n_heads++] = stages[k];
+    if (nd.n_heads == 0) {
+      delete p;
+      return fail(INR_ERR_INVALID, "inr_plan_create: multiscale MFN of depth %d has no output layer", n);
+    }
+  } else {
+    nd.n_heads = 1;
+    nd.head_stage[0] = n;
+  }
+  nd.mfn_stages = nd.head_stage[nd.n_heads - 1] + 1;
+  const int n_head_layers = multi ? n + 1 : 1;
+  nd.D = (n + 1) + n + n_head_layers;
+  const int TL = 32 * nd.NW;
+  auto fill = [&](LayerDesc& L, int K, int M, bool filter, bool head) {
+    L.K = K;
+    L.M = M;
+    L.Kpad8 = filter ? round_up(K, 8) : NB * 32;
+    L.Kblk = (K + 31) / 32;
+    L.Mblk = (M + 31) / 32;
+    L.Mpad8 = head ? round_up(M, 8) : NB * 32;
+    L.ltype = LT_REAL;
+    L.wn = M * K;
+    L.bn = M;
+    L.korder = filter ? 1 : 0;
+  };
+  for (int i = 0; i <= n; ++i) {
+    fill(nd.L[i], d->in_features, W, true, false);
+    nd.L[i].live = i < nd.mfn_stages;
+  }
+  for (int i = 0; i < n; ++i) {
+    fill(nd.L[n + 1 + i], W, W, false, false);
+    nd.L[n + 1 + i].live = i < nd.mfn_stages - 1;
+  }
+  for (int i = 0; i < n_head_layers; ++i) {
+    fill(nd.L[2 * n + 1 + i], W, d->out_features, false, true);
+    nd.L[2 * n + 1 + i].live = 0;
+  }
+  for (int k = 0; k < nd.n_heads; ++k) {
+    nd.head_layer[k] = 2 * n + 1 + (multi ? nd.head_stage[k] : 0);
+    nd.L[nd.head_layer[k]].live = 1;
+  }
+  // flat offsets in state_dict order: linears, heads, filters
+  int poff = 0;
+  auto place = [&](LayerDesc& L) {
+    L.w_off = poff;
+    poff += L.wn;
+    L.b_off = poff;
+    poff += L.bn;
+  };
+  for (int i = 0; i < n; ++i) place(nd.L[n + 1 + i]);
+  for (int i = 0; i < n_head_layers; ++i) place(nd.L[2 * n + 1 + i]);
+  for (int i = 0; i <= n; ++i) place(nd.L[i]);
+  nd.P = poff;
+  int goff = 0;
+  int64_t pk = 0;
+  for (int l = 0; l < nd.D; ++l) {
+    LayerDesc& L = nd.L[l];
+    const bool filter = l <= n;
+    L.gw_off = goff;
+    goff += L.M * L.K;
+    L.gb_off = goff;
+    goff += L.M;
+    L.pf_off = (int)pk;
+    pk += (int64_t)L.Kpad8 * L.Mblk * 32;
+    if (!filter) {
+      L.pb_off = (int)pk;
+      pk += (int64_t)L.Mpad8 * L.Kblk * 32;
+    } else {
+      L.pb_off = -1;
+    }
+    L.pbias_off = (int)pk;
+    pk += L.Mblk * 32;
+  }
+  nd.slab_loss_off = goff;
+  nd.slab_floats = round_up(goff + 4, 64);
+  nd.save_floats_per_tile = 3 * nd.mfn_stages * NB * 32 * TL + nd.L[0].Kblk * 32 * TL;
+  p->packed_floats = pk;
+  *out = p;
+  return INR_OK;
+}
+
 extern "C" {
 
 int inr_abi_version(void) { return INR_ABI_VERSION; }
@@ -60,6 +174,7 @@ int inr_last_error(char* buf, size_t cap) {
 int inr_plan_create(const inr_net_desc* d, inr_plan** out) {
   if (d == nullptr || out == nullptr) return fail(INR_ERR_INVALID, "inr_plan_create: null argument");
   *out = nullptr;
+  if (d->kind == INR_KIND_FOURIER || d->kind == INR_KIND_MSFOURIER) return create_mfn_plan(d, out);
   if (d->kind != INR_KIND_SIREN && d->kind != INR_KIND_FFN && d->kind != INR_KIND_WIRE)
     return fail(INR_ERR_UNSUPPORTED, "inr_plan_create: kind %d has no kernel yet", d->kind);
   const bool wire = d->kind == INR_KIND_WIRE;
@@ -166,9 +281,13 @@ int inr_plan_create(const inr_net_desc* d, inr_plan** out) {
     if (l >= 1) {
       L.pb_off = (int)pk;
       pk += (int64_t)L.Mpad8 * L.Kblk * 32;
+    } else {
+      L.pb_off = -1;
     }
     L.pbias_off = (int)pk;
     pk += L.Mblk * 32;
+    L.live = 1;
+    L.korder = (first && d->input == INR_INPUT_GAUSS) ? 1 : 0;
   }
   nd.P = poff;
   nd.slab_loss_off = goff;
@@ -211,7 +330,10 @@ static int launch(const inr_plan* plan, const LossDesc& ld, const inr::MlpArgs& 
                   hipStream_t st) {
   hipError_t e;
   const NetDesc& nd = plan->nd;
-  if (nd.hact == ACT_GABOR)
+  if (nd.mfn_n > 0)
+    e = nd.NB == 1 ? inr::launch_mfn_nb1(nd, ld, a, mode, grid, st)
+                   : (nd.NB == 8 ? inr::launch_mfn_nb8(nd, ld, a, mode, grid, st) : inr::launch_mfn_nb16(nd, ld, a, mode, grid, st));
+  else if (nd.hact == ACT_GABOR)
     e = nd.NB == 12 ? inr::launch_wire_nb12(nd, ld, a, mode, grid, st) : inr::launch_wire_nb2(nd, ld, a, mode, grid, st);
   else if (nd.NB == 1)
     e = inr::launch_mlp_nb1(nd, ld, a, mode, grid, st);
@@ -246,6 +368,7 @@ int inr_forward(const inr_plan* plan, const float* params, const float* packed, 
                 const float* enc_B, int64_t B, float* out, float* save, void* stream) {
   if (plan == nullptr || params == nullptr || packed == nullptr || x == nullptr || out == nullptr)
     return fail(INR_ERR_INVALID, "inr_forward: null argument");
+  if (plan->nd.mfn_n > 0) return fail(INR_ERR_INVALID, "inr_forward: multiplicative-filter plans use inr_forward_multi");
   if (plan->nd.input == IN_GAUSS && enc_B == nullptr) return fail(INR_ERR_INVALID, "inr_forward: enc_B is null");
   if (B <= 0) return fail(INR_ERR_INVALID, "inr_forward: B = %lld", (long long)B);
   int64_t nt, nb;
@@ -272,6 +395,7 @@ int inr_backward(const inr_plan* plan, const float* params, const float* packed,
   if (plan == nullptr || params == nullptr || packed == nullptr || x == nullptr || dout == nullptr ||
       save == nullptr || slabs == nullptr || grads == nullptr)
     return fail(INR_ERR_INVALID, "inr_backward: null argument");
+  if (plan->nd.mfn_n > 0) return fail(INR_ERR_INVALID, "inr_backward: multiplicative-filter plans use inr_backward_multi");
   if (plan->nd.input == IN_GAUSS && enc_B == nullptr) return fail(INR_ERR_INVALID, "inr_backward: enc_B is null");
   if (B <= 0) return fail(INR_ERR_INVALID, "inr_backward: B = %lld", (long long)B);
   int64_t nt, nb;
@@ -299,6 +423,15 @@ int inr_backward(const inr_plan* plan, const float* params, const float* packed,
 }
 
 static void to_loss_desc(const inr_loss_desc* l, LossDesc* o) {
+  memset(o, 0, sizeof(*o));
+  o->scale = l->scale == 0.f ? 1.f : l->scale;
+  o->cons_w = l->cons_w;
+  o->cons_chan = l->cons_chan == 1 ? 1 : 2;
+  for (int i = 0; i < INR_MAX_HEADS; ++i) {
+    o->cons_lo[i] = l->cons_lo[i];
+    o->cons_hi[i] = l->cons_hi[i];
+    o->cons_inv[i] = l->cons_inv[i];
+  }
   o->kind = l->kind;
   o->eps = l->eps;
   o->sigma = l->sigma;
@@ -327,6 +460,8 @@ int inr_train_step(const inr_plan* plan, const inr_loss_desc* loss, const float*
   if (plan == nullptr || loss == nullptr || params == nullptr || packed == nullptr || x == nullptr ||
       gt == nullptr || save == nullptr || slabs == nullptr || loss_out == nullptr)
     return fail(INR_ERR_INVALID, "inr_train_step: null argument");
+  if (plan->nd.mfn_n > 0)
+    return fail(INR_ERR_INVALID, "inr_train_step: multiplicative-filter plans use inr_train_step_multi");
   if (plan->nd.input == IN_GAUSS && enc_B == nullptr) return fail(INR_ERR_INVALID, "inr_train_step: enc_B is null");
   if (loss->kind < INR_LOSS_L2_HALF || loss->kind > INR_LOSS_HDR)
     return fail(INR_ERR_INVALID, "inr_train_step: loss kind %d", loss->kind);
@@ -359,6 +494,107 @@ int inr_train_step(const inr_plan* plan, const inr_loss_desc* loss, const float*
   hipError_t e = inr::launch_reduce_slabs(plan->nd, slabs, (int)nb, grads, loss_out,
                                           (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "inr_train_step: slab reduction");
+  return INR_OK;
+}
+
+int inr_plan_heads(const inr_plan* plan, int32_t* n_heads) {
+  if (plan == nullptr || n_heads == nullptr) return fail(INR_ERR_INVALID, "inr_plan_heads: null argument");
+  *n_heads = plan->nd.mfn_n > 0 ? plan->nd.n_heads : 1;
+  return INR_OK;
+}
+
+int inr_forward_multi(const inr_plan* plan, const float* params, const float* packed, const float* coords,
+                      const float* enc_B, int64_t B, float* out, float* save, int32_t by_block, void* stream) {
+  if (plan == nullptr || params == nullptr || packed == nullptr || coords == nullptr || enc_B == nullptr ||
+      out == nullptr || save == nullptr)
+    return fail(INR_ERR_INVALID, "inr_forward_multi: null argument");
+  if (plan->nd.mfn_n == 0) return fail(INR_ERR_INVALID, "inr_forward_multi: not a multiplicative-filter plan");
+  if (B <= 0) return fail(INR_ERR_INVALID, "inr_forward_multi: B = %lld", (long long)B);
+  int64_t nt, nb;
+  inr_plan_launch_dims(plan, B, &nt, &nb);
+  inr::MlpArgs a;
+  memset(&a, 0, sizeof(a));
+  a.params = params;
+  a.packed = packed;
+  a.x = coords;
+  a.encB = enc_B;
+  a.out = out;
+  a.save = save;
+  a.B = B;
+  a.n_tiles = (int)nt;
+  a.save_by_block = by_block ? 1 : 0;
+  LossDesc ld;
+  memset(&ld, 0, sizeof(ld));
+  return launch(plan, ld, a, 0, (int)nb, (hipStream_t)stream);
+}
+
+int inr_backward_multi(const inr_plan* plan, const float* params, const float* packed, const float* coords,
+                       const float* enc_B, int64_t B, const float* dout, const float* save, float* slabs,
+                       float* grads, void* stream) {
+  if (plan == nullptr || params == nullptr || packed == nullptr || coords == nullptr || enc_B == nullptr ||
+      dout == nullptr || save == nullptr || slabs == nullptr || grads == nullptr)
+    return fail(INR_ERR_INVALID, "inr_backward_multi: null argument");
+  if (plan->nd.mfn_n == 0) return fail(INR_ERR_INVALID, "inr_backward_multi: not a multiplicative-filter plan");
+  if (B <= 0) return fail(INR_ERR_INVALID, "inr_backward_multi: B = %lld", (long long)B);
+  int64_t nt, nb;
+  inr_plan_launch_dims(plan, B, &nt, &nb);
+  inr::MlpArgs a;
+  memset(&a, 0, sizeof(a));
+  a.params = params;
+  a.packed = packed;
+  a.x = coords;
+  a.encB = enc_B;
+  a.dout = dout;
+  a.save = const_cast<float*>(save);
+  a.slabs = slabs;
+  a.B = B;
+  a.n_tiles = (int)nt;
+  a.save_by_block = 0;
+  LossDesc ld;
+  memset(&ld, 0, sizeof(ld));
+  int rc = launch(plan, ld, a, 1, (int)nb, (hipStream_t)stream);
+  if (rc != INR_OK) return rc;
+  hipError_t e = inr::launch_reduce_slabs(plan->nd, slabs, (int)nb, grads, nullptr, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "inr_backward_multi: slab reduction");
+  return INR_OK;
+}
+
+int inr_train_step_multi(const inr_plan* plan, const inr_loss_desc* loss, const float* params, const float* packed,
+                         const float* coords, const float* enc_B, const float* gt, const float* dist,
+                         const uint8_t* mask, int64_t B, float* save, float* slabs, float* grads, float* loss_out,
+                         void* stream) {
+  if (plan == nullptr || loss == nullptr || params == nullptr || packed == nullptr || coords == nullptr ||
+      enc_B == nullptr || gt == nullptr || save == nullptr || slabs == nullptr || loss_out == nullptr)
+    return fail(INR_ERR_INVALID, "inr_train_step_multi: null argument");
+  if (plan->nd.mfn_n == 0) return fail(INR_ERR_INVALID, "inr_train_step_multi: not a multiplicative-filter plan");
+  if (loss->kind < INR_LOSS_L2_HALF || loss->kind > INR_LOSS_HDR)
+    return fail(INR_ERR_INVALID, "inr_train_step_multi: loss kind %d", loss->kind);
+  if (loss->cons_w != 0.f && dist == nullptr)
+    return fail(INR_ERR_INVALID, "inr_train_step_multi: the consistency term needs dist");
+  if (B <= 0) return fail(INR_ERR_INVALID, "inr_train_step_multi: B = %lld", (long long)B);
+  int64_t nt, nb;
+  inr_plan_launch_dims(plan, B, &nt, &nb);
+  inr::MlpArgs a;
+  memset(&a, 0, sizeof(a));
+  a.params = params;
+  a.packed = packed;
+  a.x = coords;
+  a.encB = enc_B;
+  a.gt = gt;
+  a.dist = dist;
+  a.mask = mask;
+  a.save = save;
+  a.slabs = slabs;
+  a.B = B;
+  a.n_tiles = (int)nt;
+  a.save_by_block = 1;
+  LossDesc ld;
+  to_loss_desc(loss, &ld);
+  int rc = launch(plan, ld, a, 2, (int)nb, (hipStream_t)stream);
+  if (rc != INR_OK) return rc;
+  if (grads == nullptr) return INR_OK;
+  hipError_t e = inr::launch_reduce_slabs(plan->nd, slabs, (int)nb, grads, loss_out, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "inr_train_step_multi: slab reduction");
   return INR_OK;
 }
 

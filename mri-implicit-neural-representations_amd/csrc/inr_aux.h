@@ -8,6 +8,7 @@ namespace inr {
 struct AdamArgs {
   int do_update;      // 0: pack only
   int all_real;       // set by the launcher: every layer is LT_REAL (fast scatter path)
+  int has_dead;       // set by the launcher: some layer has live == 0
   float step_size;    // lr / (1 - beta1^t), computed in double on the host like torch does
   float bc2_sqrt;     // sqrt(1 - beta2^t)
   float omb1;         // float(1 - beta1): the lerp weight torch passes to exp_avg.lerp_
@@ -30,5 +31,8 @@ hipError_t launch_mlp_nb1(const NetDesc& nd, const LossDesc& ld, const MlpArgs& 
 hipError_t launch_mlp_nb8(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int mode, int grid, hipStream_t st);
 hipError_t launch_wire_nb2(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int mode, int grid, hipStream_t st);
 hipError_t launch_wire_nb12(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int mode, int grid, hipStream_t st);
+hipError_t launch_mfn_nb1(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int mode, int grid, hipStream_t st);
+hipError_t launch_mfn_nb8(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int mode, int grid, hipStream_t st);
+hipError_t launch_mfn_nb16(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int mode, int grid, hipStream_t st);
 
 }  // namespace inr

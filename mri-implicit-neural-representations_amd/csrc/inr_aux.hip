@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const NetDesc nd, con
     int l;
     VirtualPos vp;
     float s = 0.f;
-    if (locate(nd, i, l, vp)) {
+    if (locate(nd, i, l, vp) && nd.L[l].live != 0) {  // dead layers: slab region never written -> 0
       const LayerDesc& L = nd.L[l];
       if (vp.n >= 1) {
         const size_t o0 = (size_t)L.gw_off + (size_t)vp.row[0] * L.K + vp.col[0];
@@ -146,8 +146,8 @@ __global__ __launch_bounds__(256) void reduce_slabs_real_kernel(const float* __r
 
 hipError_t launch_reduce_slabs(const NetDesc& nd, const float* slabs, int n_blocks, float* grads, float* loss_out,
                                hipStream_t st) {
-  bool all_real = true;
-  for (int l = 0; l < nd.D; ++l) all_real = all_real && nd.L[l].ltype == LT_REAL;
+  bool all_real = true;  // ... and slab layout == flat layout (not the case for MFN: L[] order != flat order)
+  for (int l = 0; l < nd.D; ++l) all_real = all_real && nd.L[l].ltype == LT_REAL && nd.L[l].gw_off == nd.L[l].w_off;
   if (all_real) {  // slab offsets == flat offsets; slab_floats % 64 == 0 keeps every slab 16-byte aligned
     const int grid = (nd.P + 255) / 256;
     hipLaunchKernelGGL(reduce_slabs_real_kernel, dim3(grid), dim3(256), 0, st, slabs, n_blocks, nd.slab_floats, nd.P,
@@ -167,7 +167,7 @@ hipError_t launch_reduce_slabs(const NetDesc& nd, const float* slabs, int n_bloc
 __device__ __forceinline__ void put_fwd(const NetDesc& nd, const LayerDesc& L, int l, float* packed, int row, int k,
                                         float v) {
   int h, s;
-  if (l == 0 && nd.input == IN_GAUSS) {
+  if (L.korder == 1) {
     h = k >= nd.E;
     s = h ? k - nd.E : k;
   } else {
@@ -189,7 +189,14 @@ __global__ __launch_bounds__(256) void adam_pack_kernel(const NetDesc nd, float*
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= nd.P) return;
   float p = params[i];
-  if (aa.do_update) {
+  bool live = true;
+  if (aa.has_dead) {
+    for (int l = 0; l < nd.D; ++l) {
+      const LayerDesc& L = nd.L[l];
+      if ((i >= L.w_off && i < L.w_off + L.wn) || (i >= L.b_off && i < L.b_off + L.bn)) live = L.live != 0;
+    }
+  }
+  if (aa.do_update && live) {
     float g = grads[i];
     if (aa.weight_decay != 0.f) g = fmaf(aa.weight_decay, p, g);
     if (aa.l1 != 0.f) g += aa.l1 * (p > 0.f ? 1.f : (p < 0.f ? -1.f : 0.f));  // d/dp lambda*sum|p|
@@ -210,7 +217,7 @@ __global__ __launch_bounds__(256) void adam_pack_kernel(const NetDesc nd, float*
       if (off >= 0 && off < L.wn) {
         const int row = off / L.K, k = off - row * L.K;
         put_fwd(nd, L, l, packed, row, k, p);
-        if (l >= 1) put_tr(L, packed, row, k, p);
+        if (L.pb_off >= 0) put_tr(L, packed, row, k, p);
         return;
       }
       const int ob = i - L.b_off;
@@ -227,7 +234,7 @@ __global__ __launch_bounds__(256) void adam_pack_kernel(const NetDesc nd, float*
   const LayerDesc& L = nd.L[l];
   for (int t = 0; t < vp.n; ++t) {
     put_fwd(nd, L, l, packed, vp.row[t], vp.col[t], vp.sign[t] * p);
-    if (l >= 1) put_tr(L, packed, vp.row[t], vp.col[t], vp.sign[t] * p);
+    if (L.pb_off >= 0) put_tr(L, packed, vp.row[t], vp.col[t], vp.sign[t] * p);
   }
   if (vp.bias_row >= 0) packed[L.pbias_off + vp.bias_row] = p;
 }
@@ -236,7 +243,11 @@ hipError_t launch_adam_pack(const NetDesc& nd, float* params, const float* grads
                             float* packed, const AdamArgs& aa_in, hipStream_t st) {
   AdamArgs aa = aa_in;
   aa.all_real = 1;
-  for (int l = 0; l < nd.D; ++l) aa.all_real = aa.all_real && nd.L[l].ltype == LT_REAL;
+  aa.has_dead = 0;
+  for (int l = 0; l < nd.D; ++l) {
+    aa.all_real = aa.all_real && nd.L[l].ltype == LT_REAL;
+    aa.has_dead = aa.has_dead || nd.L[l].live == 0;
+  }
   const int grid = (nd.P + 255) / 256;
   hipLaunchKernelGGL(adam_pack_kernel, dim3(grid), dim3(256), 0, st, nd, params, grads, m1, m2, packed, aa);
   return hipGetLastError();

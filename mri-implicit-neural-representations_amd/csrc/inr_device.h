@@ -4,7 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define INR_MAX_LAYERS 16
+#define INR_MAX_LAYERS 32
+#define INR_MAX_HEADS 4
 #define INR_MAX_WAVES 4   // waves per workgroup (tile = 32 coordinates per wave)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -47,6 +48,8 @@ struct LayerDesc {
   int pb_off;        // offset into packed: transposed image A[i=in][k=out] (unused for layer 0)
   int pbias_off;     // offset into packed: bias image, Mblk*32 entries, zero padded
   float omega, s0;   // activation constants of this layer's OUTPUT (SIREN w0 / WIRE omega_0, scale_0)
+  int live;          // 0: dead layer of MultiscaleKFourier (never gets a gradient; Adam skips it)
+  int korder;        // k order of the forward image: 0 natural (k = 2s+half), 1 gauss split (half ? E+s : s)
 };
 
 struct NetDesc {
@@ -63,12 +66,26 @@ struct NetDesc {
   int slab_floats;   // floats per gradient slab (virtual dW/db of every layer + loss word, padded to 64)
   int slab_loss_off; // position of the block's loss partial inside its slab
   int save_floats_per_tile;
+  // multiplicative filter networks (models/mfn.py): L[] = filters 0..n | linears 0..n-1 | heads
+  int mfn_n;                      // network_depth n (n+1 filters, n linears)
+  int mfn_stages;                 // stages actually evaluated: 1 + last stage that feeds a head
+  int n_heads;                    // 1 (FourierNet) or 4 (multiscale)
+  int head_stage[INR_MAX_HEADS];  // stage whose h feeds head k
+  int head_layer[INR_MAX_HEADS];  // index into L[] of head k
+  int bounded;                    // MultiscaleBoundedFourier: linears see h only where lo <= dist <= hi
+  float bound_lo[INR_MAX_LAYERS / 2], bound_hi[INR_MAX_LAYERS / 2];  // per linear
   LayerDesc L[INR_MAX_LAYERS];
 };
 
 struct LossDesc {
   int kind;
   float eps, sigma, factor, inv_count, hdr_A;
+  float scale;        // multiplies the pointwise loss (0.5 for the multiscale loop's 0.5*loss_fn, else 1)
+  // ConsistencyLoss between consecutive heads (metrics/losses.py:315-324), multiscale only
+  float cons_w;       // 0.1 (train_kspace_multiscale.py:179); 0 disables
+  int cons_chan;      // channels compared: 2 (dist [B]) or 1 (per-coil dist [B,1]: channel 0 only, A.4 #4)
+  float cons_lo[INR_MAX_HEADS], cons_hi[INR_MAX_HEADS];
+  float cons_inv[INR_MAX_HEADS];  // 1 / (number of compared elements of pair i, over all ranks); 0: empty
 };
 
 // Row of a 32x32 MFMA accumulator held in register r by lane-half h (guide section 3:

@@ -1,0 +1,450 @@
+// inr_mfn_impl.h -- fused kernel for the multiplicative filter networks of models/mfn.py
+// (FourierNet :61-94, MultiscaleKFourier :206-267, MultiscaleBoundedFourier :288-355), fp32-exact.
+//
+//   f_i = sin(F_i x + c_i)                      x = gauss Fourier features of the coordinate (K0 = 2E)
+//   h_0 = f_0,  l_i = L_{i-1} h_{i-1} + d_{i-1},  h_i = f_i * l_i,   head k: o_k = W_k h_{s_k} + b_k
+//
+// Same machine mapping as inr_mlp_impl.h (one wave = 32 coordinates through every stage, activations
+// transposed, exact-fp32 MFMA, per-wave LDS image, private gradient slabs) with two GEMMs per stage:
+//   V = L h      B operand streamed from the wave's LDS image (h of the previous stage),
+//   U = F x      B operand streamed from the stash of encoder features written once in stage 0
+// executed one after the other on ONE accumulator set (l is parked in the LDS image while U runs), so
+// the 512-wide BASELINE shape fits the register file.  Stash per stage: f_i, l_i*cos(u_i), h_i.
+// Backward: g_l = g_h*f, g_u = g_h*l*cos(u); the image keeps g_h and the dW passes
+// multiply the A operand by the stashed factor on the fly, so ONE image serves dW_L, dW_F and dX.
+// MultiscaleKFourier's dead stage / dead heads (A.4 #3) are neither evaluated nor updated.
+#pragma once
+#include "inr_mlp_impl.h"
+
+namespace inr {
+
+// ---------------------------------------------------------------------------------------------
+// U += F . X^T with X^T rows read from the encoder-feature stash [2E rows][TL] (gauss k order:
+// k-step s -> half 0: row s, half 1: row E+s), prefetched one group of 4 k-steps ahead.
+// ---------------------------------------------------------------------------------------------
+template <int NB, int TL>
+__device__ __forceinline__ void stash_group(f32x16 (&acc)[NB], const f32x4 (&a_use)[NB], f32x4 (&a_load)[NB],
+                                            const f32x4* p_next, const float (&b_use)[4], float (&b_load)[4],
+                                            const float* svl_next) {
+  load_afrag<NB>(a_load, p_next);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) b_load[e] = svl_next[e * TL];
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+#pragma unroll
+    for (int m = 0; m < NB; ++m) acc[m] = mfma32(a_use[m][e], b_use[e], acc[m]);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int NB, int TL>
+__device__ __forceinline__ void gemm_enc_stash(f32x16 (&acc)[NB], const float* __restrict__ wp,
+                                               const float* __restrict__ sv_enc, int E, int wcol, int lane) {
+  const int half = lane >> 5;
+  const float* svl = sv_enc + (half ? E : 0) * TL + wcol;
+  const f32x4* p = reinterpret_cast<const f32x4*>(wp) + lane;
+  const int n4 = E >> 2;  // even
+  f32x4 A0[NB], A1[NB];
+  float B0[4], B1[4];
+  load_afrag<NB>(A0, p);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) B0[e] = svl[e * TL];
+#pragma unroll 1
+  for (int s4 = 0; s4 < n4; s4 += 2) {
+    const int n2 = (s4 + 2 < n4) ? (s4 + 2) : s4;
+    stash_group<NB, TL>(acc, A0, A1, p + (size_t)(s4 + 1) * NB * 64, B0, B1, svl + 4 * (s4 + 1) * TL);
+    stash_group<NB, TL>(acc, A1, A0, p + (size_t)n2 * NB * 64, B1, B0, svl + 4 * n2 * TL);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// stage epilogue: u = acc + c (bias image), f = sin u, fc = cos u;
+//   FIRST: h = f                         image <- h;  stash f, fc, h
+//   else : l = image (parked), h = f*l   image <- h;  stash f, l*fc, h
+// All accesses use this lane's own accumulator positions (row = 32m + (r&3) + 8(r>>2) + 4*half).
+// ---------------------------------------------------------------------------------------------
+template <int NB, int TL, bool FIRST, bool SAVE>
+__device__ __forceinline__ void mfn_epilogue(const f32x16 (&acc)[NB], float* R, const float* __restrict__ cbias,
+                                             float* __restrict__ sv, int wcol, int lane) {
+  const int half = lane >> 5, col = lane & 31;
+  constexpr int hsz = NB * 32 * TL;
+  float* Rl = R + (4 * half) * INR_LDS_LD + col;
+  float* svl = SAVE ? sv + (4 * half) * TL + wcol : nullptr;
+  const float* bl = cbias + 4 * half;
+#pragma unroll
+  for (int m = 0; m < NB; ++m) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 c4 = *reinterpret_cast<const f32x4*>(bl + 32 * m + 8 * g);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = 32 * m + 8 * g + j;  // + 4*half folded into Rl / svl
+        float sn, cs;
+        sincos_cw(acc[m][4 * g + j] + c4[j], sn, cs);
+        float h = sn, lc = cs;
+        if (!FIRST) {
+          const float l = Rl[row * INR_LDS_LD];
+          h = sn * l;
+          lc = l * cs;
+        }
+        Rl[row * INR_LDS_LD] = h;
+        if (SAVE) {
+          svl[row * TL] = sn;
+          svl[hsz + row * TL] = lc;
+          svl[2 * hsz + row * TL] = h;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// dW pass whose A operand is (image value) * (stashed factor): g_l = g_h*f or g_u = g_h*(l cos u).
+// Factor rows are read "feature on lane", 4 coordinates per float4, like the B operand.
+// ---------------------------------------------------------------------------------------------
+template <int MT, int TL>
+__device__ __forceinline__ void load_fac(f32x4 (&f)[MT], const float* __restrict__ fac, int m0, int q, int lane) {
+  const int li = lane & 31;
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+    f[m] = *reinterpret_cast<const f32x4*>(fac + (32 * (m0 + m) + li) * TL + 8 * q + 4 * (lane >> 5));
+}
+
+template <int MT, int TL, bool BIAS, class BSrc>
+__device__ __forceinline__ void dwf_group(f32x16 (&acc)[MT], float (&bsum)[MT], const f32x4 (&a_use)[MT],
+                                          const f32x4 (&f_use)[MT], f32x4 (&a_load)[MT], f32x4 (&f_load)[MT],
+                                          const f32x4& b_use, f32x4& b_load, BSrc& bsrc, const float* fac, int m0,
+                                          int n, int q_next, const float* Rq_next, int lane) {
+  const typename BSrc::Raw raw = bsrc.fetch(n, q_next, lane);
+  load_fac<MT, TL>(f_load, fac, m0, q_next, lane);
+  load_dw_a<MT>(a_load, Rq_next);
+  __builtin_amdgcn_sched_barrier(0);
+  b_load = bsrc.finish(raw);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const float a = a_use[m][e] * f_use[m][e];
+      if (BIAS) bsum[m] += a;
+      acc[m] = mfma32(a, b_use[e], acc[m]);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// rows [32*m0, 32*(m0+MT)) x column block n of dW = (G*fac)^T . B over the tile's TL coordinates
+template <int MT, int TL, bool BIAS, class BSrc>
+__device__ __forceinline__ void dwf_pass_impl(const float* Rall, int region_stride, const float* fac, BSrc& bsrc,
+                                              int m0, int n, float* slab_w, float* slab_b, int M, int K, bool first,
+                                              int lane) {
+  const int half = lane >> 5, li = lane & 31;
+  f32x16 acc[MT];
+  float bsum[MT];
+  const int jcol = 32 * n + li;
+  const bool colok = jcol < K;
+  const int lane_off = 4 * half * K + jcol;
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    bsum[m] = 0.f;
+    acc[m] = zero16();
+    if (!first) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rowu = 32 * (m0 + m) + (r & 3) + 8 * (r >> 2);
+        const bool ok = colok && rowu + 4 * half < M;
+        const float v = slab_w[ok ? (size_t)rowu * K + lane_off : 0];
+        acc[m][r] = ok ? v : 0.f;
+      }
+    }
+  }
+  const float* Rl = Rall + (32 * m0 + li) * INR_LDS_LD + 4 * half;
+  f32x4 B0 = bsrc.finish(bsrc.fetch(n, 0, lane)), B1;
+  f32x4 A0[MT], A1[MT], F0[MT], F1[MT];
+  load_dw_a<MT>(A0, Rl);
+  load_fac<MT, TL>(F0, fac, m0, 0, lane);
+#pragma unroll 1
+  for (int q = 0; q < TL / 8; q += 2) {
+    const int q2 = (q + 2 < TL / 8) ? q + 2 : q;
+    dwf_group<MT, TL, BIAS, BSrc>(acc, bsum, A0, F0, A1, F1, B0, B1, bsrc, fac, m0, n, q + 1,
+                                  Rl + ((q + 1) >> 2) * region_stride + 8 * ((q + 1) & 3), lane);
+    dwf_group<MT, TL, BIAS, BSrc>(acc, bsum, A1, F1, A0, F0, B1, B0, bsrc, fac, m0, n, q2,
+                                  Rl + (q2 >> 2) * region_stride + 8 * (q2 & 3), lane);
+  }
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rowu = 32 * (m0 + m) + (r & 3) + 8 * (r >> 2);
+      if (colok && rowu + 4 * half < M) slab_w[(size_t)rowu * K + lane_off] = acc[m][r];
+    }
+    if (BIAS) {
+      const float tot = bsum[m] + __shfl_xor(bsum[m], 32);
+      const int row = 32 * (m0 + m) + li;
+      if (half == 0 && row < M) slab_b[row] = first ? tot : slab_b[row] + tot;
+    }
+  }
+}
+
+template <int NB, int TL, class BSrc>
+__device__ __forceinline__ void dwf_layer(const float* lds, int RS, const float* fac, BSrc& bsrc, const LayerDesc& L,
+                                          float* slab, bool first, int w, int nw, int lane) {
+  constexpr int MT = NB > 8 ? 8 : NB;  // 16-block rows go in two halves (accumulators + operands <= 512 regs)
+  for (int n = w; n < L.Kblk; n += nw) {
+#pragma unroll
+    for (int m0 = 0; m0 < NB; m0 += MT) {
+      if (n == 0)
+        dwf_pass_impl<MT, TL, true, BSrc>(lds, RS, fac, bsrc, m0, n, slab + L.gw_off, slab + L.gb_off, L.M, L.K, first,
+                                          lane);
+      else
+        dwf_pass_impl<MT, TL, false, BSrc>(lds, RS, fac, bsrc, m0, n, slab + L.gw_off, slab + L.gb_off, L.M, L.K,
+                                           first, lane);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// multiscale loss of one coordinate (train_kspace_multiscale.py:164-195): sum over heads of
+// scale * loss_fn(o_k, gt) + cons_w * ConsistencyLoss (losses.py:315-324).  y[k][o] in, g[k][o] out.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float mfn_loss_row(const LossDesc& ld, int n_heads, int out_f, const float (&y)[INR_MAX_HEADS][4],
+                                              const float* t, float dist, float (&g)[INR_MAX_HEADS][4]) {
+  float loss = 0.f;
+#pragma unroll
+  for (int k = 0; k < INR_MAX_HEADS; ++k) {
+    if (k < n_heads) {
+      float gk[4] = {0.f, 0.f, 0.f, 0.f};
+      loss += ld.scale * loss_row(ld, out_f, y[k], t, gk);
+#pragma unroll
+      for (int o = 0; o < 4; ++o) g[k][o] = ld.scale * gk[o];
+    }
+  }
+  if (ld.cons_w != 0.f) {
+#pragma unroll
+    for (int i = 0; i + 1 < INR_MAX_HEADS; ++i) {
+      if (i + 1 < n_heads && ld.cons_inv[i] != 0.f && (dist < ld.cons_lo[i] || dist > ld.cons_hi[i])) {
+        for (int o = 0; o < ld.cons_chan; ++o) {
+          const float e = y[i + 1][o] - y[i][o];  // first tensor is detached: gradient to head i+1 only
+          loss += ld.cons_w * e * e * ld.cons_inv[i];
+          g[i + 1][o] += ld.cons_w * 2.f * e * ld.cons_inv[i];
+        }
+      }
+    }
+  }
+  return loss;
+}
+
+// ---------------------------------------------------------------------------------------------
+// the kernel
+// ---------------------------------------------------------------------------------------------
+template <int NB, int NW, int MODE>
+__global__ __launch_bounds__(NW * 64) void inr_mfn_kernel(const NetDesc nd, const LossDesc ld, const MlpArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int TL = NW * 32;
+  constexpr int RS = NB * 32 * INR_LDS_LD;   // floats per wave image
+  constexpr int HS = 32 * INR_LDS_LD;        // floats per wave head-gradient image
+  constexpr int HSZ = NB * 32 * TL;          // floats per stashed tensor
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, w = tid >> 6;
+  const int half = lane >> 5, col = lane & 31;
+  const int wcol = w * 32 + col;
+  float* R = lds + w * RS;
+  float* HGall = lds + NW * RS;
+  float* HG = HGall + w * HS;
+  float* encB_lds = HGall + NW * HS;
+  for (int i = tid; i < 3 * nd.E; i += NW * 64) encB_lds[i] = a.encB[i];
+  __syncthreads();
+  const int n = nd.mfn_n, S = nd.mfn_stages, NH = nd.n_heads;
+  const LayerDesc* Fl = nd.L;           // filters 0..n
+  const LayerDesc* Ll = nd.L + n + 1;   // linears 0..n-1
+  float* slab = (MODE != MODE_FWD) ? a.slabs + (size_t)blockIdx.x * nd.slab_floats : nullptr;
+  float loss_acc = 0.f;
+  bool first = true;
+
+  for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+    const long long row0 = (long long)tile * TL;
+    const long long crow = row0 + wcol;
+    const bool valid = crow < a.B;
+    const bool saving = (MODE != MODE_FWD) || (a.save != nullptr);
+    float* sv = a.save;
+    if (saving) sv += (size_t)(a.save_by_block ? blockIdx.x : tile) * nd.save_floats_per_tile;
+    // stash: stage i -> [f_i | l_i cos u_i | h_i] ; then encoder features; without a save buffer the
+    // encoder features still need a home for stages >= 1: the caller always passes one for MFN
+    float* sv_enc = sv + (size_t)3 * S * HSZ;
+    float keep = 1.f;  // bounded linears: per-coordinate 0/1 (recomputed per stage)
+    const float dist = (a.dist != nullptr && valid) ? a.dist[crow] : 0.f;
+    float y[INR_MAX_HEADS][4], g[INR_MAX_HEADS][4];
+#pragma unroll
+    for (int k = 0; k < INR_MAX_HEADS; ++k)
+#pragma unroll
+      for (int o = 0; o < 4; ++o) y[k][o] = g[k][o] = 0.f;
+
+    // ================================ forward =================================
+    if (MODE != MODE_BWD) {
+      {
+        f32x16 acc[NB];
+#pragma unroll
+        for (int m = 0; m < NB; ++m) acc[m] = zero16();
+        float x0 = 0.f, x1 = 0.f, x2 = 0.f;
+        if (valid) {
+          x0 = a.x[3 * crow + 0];
+          x1 = a.x[3 * crow + 1];
+          x2 = a.x[3 * crow + 2];
+        }
+        const float two_pi = 6.283185307179586f;
+        fwd_layer0_gauss<NB, TL, true>(acc, a.packed + Fl[0].pf_off, encB_lds, nd.E, two_pi * x0, two_pi * x1,
+                                       two_pi * x2, sv_enc, wcol, lane);
+        mfn_epilogue<NB, TL, true, true>(acc, R, a.packed + Fl[0].pbias_off, sv, wcol, lane);
+      }
+      for (int i = 1; i < S; ++i) {
+        f32x16 acc[NB];
+#pragma unroll
+        for (int m = 0; m < NB; ++m) acc[m] = zero16();
+        if (nd.bounded) {  // BoundedLinear: rows outside [lo,hi] are zeroed before the Linear (mfn.py:281-286)
+          keep = (dist < nd.bound_lo[i - 1] || dist > nd.bound_hi[i - 1]) ? 0.f : 1.f;
+          if (keep == 0.f) {
+            for (int r = half; r < NB * 32; r += 2) R[swz(r, col)] = 0.f;  // own column only
+          }
+        }
+        bwd_dx<NB, TL, false, false>(acc, R, a.packed + Ll[i - 1].pf_off, NB * 32, nullptr, wcol, lane);  // V = L h
+        acc_to_lds<NB, true>(acc, R, a.packed + Ll[i - 1].pbias_off, lane);                               // park l
+#pragma unroll
+        for (int m = 0; m < NB; ++m) acc[m] = zero16();
+        gemm_enc_stash<NB, TL>(acc, a.packed + Fl[i].pf_off, sv_enc, nd.E, wcol, lane);                   // U = F x
+        mfn_epilogue<NB, TL, false, true>(acc, R, a.packed + Fl[i].pbias_off, sv + (size_t)3 * i * HSZ, wcol, lane);
+        // heads fed by this stage (explicit instances: y[k] must keep compile-time indices)
+#define INR_HEAD_FWD(k)                                                                                        \
+  if ((k) < NH && nd.head_stage[k] == i) {                                                                     \
+    const LayerDesc& Hd = nd.L[nd.head_layer[k]];                                                              \
+    f32x16 accH[1];                                                                                            \
+    accH[0] = zero16();                                                                                        \
+    bwd_dx<1, TL, false, false>(accH, R, a.packed + Hd.pf_off, NB * 32, nullptr, wcol, lane);                  \
+    _Pragma("unroll") for (int o = 0; o < 4; ++o) {                                                            \
+      float z = accH[0][o];                                                                                    \
+      if (o < nd.out_f) z += a.packed[Hd.pbias_off + o];                                                       \
+      y[k][o] = z;                                                                                             \
+      if (half == 0 && valid && o < nd.out_f && a.out != nullptr)                                              \
+        a.out[((size_t)(k) * a.B + crow) * nd.out_f + o] = z;                                                  \
+    }                                                                                                          \
+  }
+        INR_HEAD_FWD(0)
+        INR_HEAD_FWD(1)
+        INR_HEAD_FWD(2)
+        INR_HEAD_FWD(3)
+#undef INR_HEAD_FWD
+      }
+      if (MODE == MODE_FUSED) {
+        if (half == 0 && valid && (a.mask == nullptr || a.mask[crow] != 0)) {
+          float t[4] = {0.f, 0.f, 0.f, 0.f};
+          for (int o = 0; o < nd.out_f; ++o) t[o] = a.gt[crow * nd.out_f + o];
+          loss_acc += mfn_loss_row(ld, NH, nd.out_f, y, t, dist, g);
+        }
+      }
+    }
+
+    // ================================ backward ================================
+    if (MODE != MODE_FWD) {
+      if (MODE == MODE_BWD) {
+#pragma unroll
+        for (int k = 0; k < INR_MAX_HEADS; ++k)
+#pragma unroll
+          for (int o = 0; o < 4; ++o)
+            if (k < NH && half == 0 && valid && o < nd.out_f) g[k][o] = a.dout[((size_t)k * a.B + crow) * nd.out_f + o];
+      }
+      f32x16 gacc[NB];
+#pragma unroll
+      for (int m = 0; m < NB; ++m) gacc[m] = zero16();
+      for (int i = S - 1; i >= 1; --i) {
+        float* svi = sv + (size_t)3 * i * HSZ;
+        // ---- heads fed by stage i: dW_head, and their contribution W_k^T g_k to g_h_i
+#define INR_HEAD_BWD(k)                                                                                        \
+  if ((k) < NH && nd.head_stage[k] == i) {                                                                     \
+    const LayerDesc& Hd = nd.L[nd.head_layer[k]];                                                              \
+    __syncthreads(); /* previous readers of the head-gradient images are done */                               \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                           \
+      float v = 0.f;                                                                                           \
+      if (r < 4 && half == 0 && r < nd.out_f) v = g[k][r & 3];                                                 \
+      HG[swz(acc_row(r, half), col)] = v;                                                                      \
+    }                                                                                                          \
+    __syncthreads();                                                                                           \
+    {                                                                                                          \
+      BSrcStash<TL> bs{svi + (size_t)2 * HSZ}; /* h_i */                                                       \
+      for (int nn = w; nn < Hd.Kblk; nn += NW)                                                                 \
+        dw_pass<1, TL, false, BSrcStash<TL>>(HGall, HS, bs, nn, slab + Hd.gw_off, slab + Hd.gb_off, Hd.M, Hd.K, \
+                                             first, nn == 0, lane);                                            \
+    }                                                                                                          \
+    bwd_dx<NB, TL, false, false>(gacc, HG, a.packed + Hd.pb_off, Hd.Mpad8, nullptr, wcol, lane);               \
+  }
+        INR_HEAD_BWD(0)
+        INR_HEAD_BWD(1)
+        INR_HEAD_BWD(2)
+        INR_HEAD_BWD(3)
+#undef INR_HEAD_BWD
+        __syncthreads();  // readers of the main images (previous stage's dW / dX) are done
+        acc_to_lds<NB, false>(gacc, R, nullptr, lane);  // image <- g_h_i
+        __syncthreads();
+        // ---- dL_{i-1} = (g_h*f_i)^T h_{i-1} (+ db), dF_i = (g_h*l_i cos u_i)^T x (+ dc)
+        {
+          BSrcStash<TL> bh{sv + (size_t)(3 * (i - 1) + 2) * HSZ};
+          dwf_layer<NB, TL, BSrcStash<TL>>(lds, RS, svi, bh, Ll[i - 1], slab, first, w, NW, lane);
+          BSrcStash<TL> bx{sv_enc};
+          dwf_layer<NB, TL, BSrcStash<TL>>(lds, RS, svi + HSZ, bx, Fl[i], slab, first, w, NW, lane);
+        }
+        __syncthreads();
+        // ---- g_h_{i-1} = L_{i-1}^T (g_h_i * f_i)   (in place on the image, which is dead afterwards)
+#pragma unroll
+        for (int m = 0; m < NB; ++m) gacc[m] = zero16();
+        bwd_dx<NB, TL, false, true>(gacc, R, a.packed + Ll[i - 1].pb_off, NB * 32, svi, wcol, lane);
+        if (nd.bounded) {
+          keep = (dist < nd.bound_lo[i - 1] || dist > nd.bound_hi[i - 1]) ? 0.f : 1.f;
+#pragma unroll
+          for (int m = 0; m < NB; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gacc[m][r] *= keep;
+        }
+      }
+      // ---- stage 0: dF_0 = (g_h_0 * cos u_0)^T x
+      __syncthreads();
+      acc_to_lds<NB, false>(gacc, R, nullptr, lane);
+      __syncthreads();
+      {
+        BSrcStash<TL> bx{sv_enc};
+        dwf_layer<NB, TL, BSrcStash<TL>>(lds, RS, sv + HSZ, bx, Fl[0], slab, first, w, NW, lane);
+      }
+      __syncthreads();
+      first = false;
+    }
+  }
+
+  if (MODE == MODE_FUSED) {
+    float v = loss_acc;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    __syncthreads();
+    if (lane == 0) lds[w] = v;
+    __syncthreads();
+    if (tid == 0) {
+      float t = 0.f;
+      for (int i = 0; i < NW; ++i) t += lds[i];
+      slab[nd.slab_loss_off] = t;
+    }
+  }
+}
+
+template <int NB, int NW, int MODE>
+inline hipError_t launch_mfn(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int grid, hipStream_t st) {
+  const size_t lds_bytes = ((size_t)NW * (NB + 1) * 32 * INR_LDS_LD + 3 * (size_t)nd.E) * sizeof(float);
+  auto k = inr_mfn_kernel<NB, NW, MODE>;
+  static thread_local bool attr_set = false;
+  if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k, dim3(grid), dim3(NW * 64), lds_bytes, st, nd, ld, a);
+  return hipGetLastError();
+}
+
+}  // namespace inr

@@ -1,0 +1,17 @@
+// inr_mfn_inst.h -- instantiates the MFN kernel for one width (INR_NB blocks) / workgroup shape.
+#include "inr_mfn_impl.h"
+#include "inr_aux.h"
+
+namespace inr {
+
+hipError_t INR_LAUNCH_NAME(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int mode, int grid,
+                           hipStream_t st) {
+  if (nd.input != IN_GAUSS) return hipErrorInvalidValue;
+  switch (mode) {
+    case MODE_FWD: return launch_mfn<INR_NB, INR_NW, MODE_FWD>(nd, ld, a, grid, st);
+    case MODE_BWD: return launch_mfn<INR_NB, INR_NW, MODE_BWD>(nd, ld, a, grid, st);
+    default: return launch_mfn<INR_NB, INR_NW, MODE_FUSED>(nd, ld, a, grid, st);
+  }
+}
+
+}  // namespace inr

@@ -15,8 +15,9 @@ struct MlpArgs {
   const float* encB;   // [E,3]
   const float* gt;     // [B,out_f]   (fused)
   const uint8_t* mask; // [B] or null (fused)
-  const float* dout;   // [B,out_f]   (bwd)
-  float* out;          // [B,out_f]   (fwd; fused writes it when non-null)
+  const float* dout;   // [B,out_f]   (bwd); MFN: [n_heads][B,out_f]
+  const float* dist;   // [B] distance to the k-space centre (multiscale consistency / bounded linears)
+  float* out;          // [B,out_f]   (fwd; fused writes it when non-null); MFN: [n_heads][B,out_f]
   float* save;         // stash
   float* slabs;        // [grid][slab_floats]
   long long B;

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("INR_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "lib", "libinr_mi355x.so")
 
 # enums (include/inr_abi.h)
-KIND_SIREN, KIND_FFN, KIND_WIRE = 0, 1, 2
+KIND_SIREN, KIND_FFN, KIND_WIRE, KIND_FOURIER, KIND_MSFOURIER = 0, 1, 2, 3, 4
 ACT_ID, ACT_SIN, ACT_TANH, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3, 4
 INPUT_X, INPUT_GAUSS = 0, 1
 LOSS_L2_HALF, LOSS_L1_HALF, LOSS_TANH, LOSS_LOGSPACE, LOSS_HDR = 0, 1, 2, 3, 4
@@ -28,7 +28,9 @@ class NetDesc(C.Structure):
 
 class LossDesc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("eps", C.c_float), ("sigma", C.c_float), ("factor", C.c_float),
-                ("inv_count", C.c_float), ("hdr_A", C.c_float), ("reserved", C.c_int32 * 2)]
+                ("inv_count", C.c_float), ("hdr_A", C.c_float), ("scale", C.c_float), ("cons_w", C.c_float),
+                ("cons_chan", C.c_int32), ("cons_lo", C.c_float * 4), ("cons_hi", C.c_float * 4),
+                ("cons_inv", C.c_float * 4)]
 
 
 class Sizes(C.Structure):
@@ -51,6 +53,11 @@ SYMBOLS = {
     "inr_backward": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, _P, _P, _P, _P, _P]),
     "inr_loss_grad": (C.c_int, [C.POINTER(LossDesc), _P, _P, _P, _P, C.c_int64, _P, _P, _P]),
     "inr_train_step": (C.c_int, [_P, C.POINTER(LossDesc), _P, _P, _P, _P, _P, _P, C.c_int64, _P, _P, _P, _P, _P]),
+    "inr_plan_heads": (C.c_int, [_P, C.POINTER(C.c_int32)]),
+    "inr_forward_multi": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, _P, _P, C.c_int32, _P]),
+    "inr_backward_multi": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, _P, _P, _P, _P, _P]),
+    "inr_train_step_multi": (C.c_int, [_P, C.POINTER(LossDesc), _P, _P, _P, _P, _P, _P, _P, C.c_int64, _P, _P, _P,
+                                       _P, _P]),
     "inr_adam_step": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_double, C.c_double, C.c_double, C.c_double,
                                 C.c_double, C.c_double, C.c_double, C.c_int32, _P]),
 }

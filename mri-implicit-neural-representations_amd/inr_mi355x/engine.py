@@ -192,3 +192,66 @@ def encode_gauss(coords: torch.Tensor, enc_B: torch.Tensor) -> torch.Tensor:
     L.check(lib.inr_encode_gauss(_ptr(coords, "coords"), _ptr(enc_B, "enc_B"), B, E, _ptr(out, "out"),
                                  torch.cuda.current_stream(coords.device).cuda_stream))
     return out
+
+
+@dataclass
+class ConsistencySpec:
+    """ConsistencyLoss(pairs) of train_kspace_multiscale.py:122,179 for one batch."""
+    weight: float            # 0.1
+    bounds: list             # [(lo, hi)] * n_heads  (create_pairs(radii, 1))
+    inv_counts: list         # 1 / number of compared ELEMENTS of pair i over the global batch (0 if empty)
+    channels: int = 2        # 1 in per-coil mode (dist [B,1] selects channel 0 only, SURVEY A.4 #4)
+
+
+class MFNEngine(MLPEngine):
+    """Plan + buffers for the multiplicative filter networks (models/mfn.py: FourierNet,
+    MultiscaleKFourier).  Heads come back as one [n_heads, B, out] tensor."""
+
+    def __init__(self, multiscale: bool, in_features: int, width: int, depth: int, out_features: int, enc_size: int):
+        super().__init__(L.KIND_MSFOURIER if multiscale else L.KIND_FOURIER, in_features, width, depth, out_features,
+                         L.ACT_ID, L.INPUT_GAUSS, enc_size, 0.0)
+        nh = C.c_int32()
+        L.check(self.lib.inr_plan_heads(self.plan, C.byref(nh)))
+        self.n_heads = int(nh.value)
+
+    def forward(self, coords: torch.Tensor, enc_B: torch.Tensor, save: bool = False) -> torch.Tensor:
+        B = coords.shape[0]
+        nt, nb = self.launch_dims(B)
+        out = torch.empty(self.n_heads, B, self.out_features, device=coords.device)
+        sv = self._ws_save(nt if save else nb)
+        L.check(self.lib.inr_forward_multi(self.plan, _ptr(self.params, "params"), _ptr(self.packed, "packed"),
+                                           _ptr(coords, "coords"), _ptr(enc_B, "enc_B"), B, _ptr(out, "out"),
+                                           _ptr(sv, "save"), 0 if save else 1, self._stream()))
+        return out
+
+    def backward(self, coords: torch.Tensor, enc_B: torch.Tensor, dout: torch.Tensor) -> torch.Tensor:
+        B = coords.shape[0]
+        nt, nb = self.launch_dims(B)
+        L.check(self.lib.inr_backward_multi(self.plan, _ptr(self.params, "params"), _ptr(self.packed, "packed"),
+                                            _ptr(coords, "coords"), _ptr(enc_B, "enc_B"), B, _ptr(dout, "dout"),
+                                            _ptr(self._ws_save(nt), "save"), _ptr(self._ws_slabs(nb), "slabs"),
+                                            _ptr(self.grads, "grads"), self._stream()))
+        return self.grads
+
+    def train_step(self, coords: torch.Tensor, enc_B: torch.Tensor, gt: torch.Tensor, spec: LossSpec,
+                   count: Optional[int] = None, mask: Optional[torch.Tensor] = None, hdr_A: float = 0.0,
+                   dist: Optional[torch.Tensor] = None, scale: float = 1.0,
+                   cons: Optional[ConsistencySpec] = None):
+        B = coords.shape[0]
+        _, nb = self.launch_dims(B)
+        ld = self.loss_desc(spec, B if count is None else count, hdr_A)
+        ld.scale = scale
+        if cons is not None:
+            ld.cons_w = cons.weight
+            ld.cons_chan = cons.channels
+            for i, (lo, hi) in enumerate(cons.bounds[:4]):
+                ld.cons_lo[i], ld.cons_hi[i] = float(lo), float(hi)
+            for i, v in enumerate(cons.inv_counts[:4]):
+                ld.cons_inv[i] = float(v)
+        L.check(self.lib.inr_train_step_multi(self.plan, C.byref(ld), _ptr(self.params, "params"),
+                                              _ptr(self.packed, "packed"), _ptr(coords, "coords"),
+                                              _ptr(enc_B, "enc_B"), _ptr(gt, "gt"), _ptr(dist, "dist"),
+                                              _ptr(mask, "mask", torch.uint8), B, _ptr(self._ws_save(nb), "save"),
+                                              _ptr(self._ws_slabs(nb), "slabs"), _ptr(self.grads, "grads"),
+                                              _ptr(self._loss, "loss"), self._stream()))
+        return self._loss[0]

@@ -1,0 +1,158 @@
+"""Drop-in mirrors of the reference's multiplicative filter networks (models/mfn.py):
+``FourierNet`` (:61-94) and ``MultiscaleKFourier`` (:206-267).  Same constructor signature, RNG
+order, state_dict keys / order (``linear.*``, ``output_linear(.k).*``, ``filters.k.linear.*``).
+
+The MI355X kernel fuses the gauss encoder into every filter (the encoded [B,2E] input is never
+materialised), so the model is called on RAW coordinates after ``bind_encoder(encoder)``:
+
+    enc = Positional_Encoder(config['encoder'], device)      # consumes the RNG first, like train.py:52
+    model = MultiscaleKFourier(config['net']).to(device).bind_encoder(enc)
+    outs = model(coords, dist_to_center)                      # list of 4 [B,2] tensors (heads 1,3,5,7)
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .engine import MFNEngine
+from .networks import _FlatModel, _Holder, _view
+
+
+class _MFNFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, coords, *params):
+        eng = module._engine()
+        eng.pack()
+        need_grad = any(ctx.needs_input_grad[2:])
+        coords = coords.contiguous()
+        out = eng.forward(coords, module._enc_B, save=need_grad)
+        ctx.module = module
+        ctx.save_for_backward(coords)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (coords,) = ctx.saved_tensors
+        module = ctx.module
+        eng = module._engine()
+        flat_grad = eng.backward(coords, module._enc_B, dout.contiguous())
+        grads = []
+        for (o, n, s, c), live in zip(module._layout, module._live):
+            grads.append(_view(flat_grad, o, n, s, c) if live else None)  # dead layers: grad None, like autograd
+        return (None, None, *grads)
+
+
+class _FilterShell(nn.Module):
+    def __init__(self, holder: _Holder):
+        super().__init__()
+        self.linear = holder  # filters.k.linear.weight / bias
+
+
+class _MFNBase(_FlatModel):
+    _multiscale = False
+
+    def _build_mfn(self, params, filter_scale: float, weight_scale: float):
+        n = params["network_depth"]
+        W = params["network_width"]
+        in_size = params["network_input_size"]
+        out_size = params["network_output_size"]
+        self._n, self._W, self._in, self._out = n, W, in_size, out_size
+        self._enc_B = None
+        # MFNBase.__init__ (mfn.py:15-32): n hidden Linear, output Linear, then uniform_ on every hidden weight
+        lin = [nn.Linear(W, W) for _ in range(n)]
+        out_lin = nn.Linear(W, out_size)
+        b = np.sqrt(weight_scale / W)
+        for m in lin:
+            m.weight.data.uniform_(-b, b)
+        # child: n+1 FourierLayer (mfn.py:50-55): default init, weight *= scale, bias ~ U(-pi, pi)
+        filt = []
+        for _ in range(n + 1):
+            m = nn.Linear(in_size, W)
+            m.weight.data *= filter_scale
+            m.bias.data.uniform_(-np.pi, np.pi)
+            filt.append(m)
+        heads = [out_lin]
+        if self._multiscale:  # mfn.py:247: output_linear replaced by n+1 fresh heads (after the filters)
+            heads = [nn.Linear(W, out_size) for _ in range(n + 1)]
+        tensors = []
+        for m in lin + heads + filt:  # state_dict order: linear, output_linear, filters
+            tensors += [m.weight.detach(), m.bias.detach()]
+        ps = self._flatten(tensors)
+        k = 0
+        self.linear = nn.ModuleList([_Holder(ps[2 * i], ps[2 * i + 1]) for i in range(n)])
+        k = 2 * n
+        if self._multiscale:
+            self.output_linear = nn.ModuleList([_Holder(ps[k + 2 * i], ps[k + 2 * i + 1]) for i in range(n + 1)])
+            k += 2 * (n + 1)
+        else:
+            self.output_linear = _Holder(ps[k], ps[k + 1])
+            k += 2
+        self.filters = nn.ModuleList([_FilterShell(_Holder(ps[k + 2 * i], ps[k + 2 * i + 1])) for i in range(n + 1)])
+        # which parameter tensors are live
+        if self._multiscale:
+            head_stages = [s for s in (1, 3, 5, 7) if s <= n]
+            S = max(head_stages) + 1
+            live = [i < S - 1 for i in range(n) for _ in (0, 1)]
+            live += [i in head_stages for i in range(n + 1) for _ in (0, 1)]
+            live += [i < S for i in range(n + 1) for _ in (0, 1)]
+            self.output_layers = head_stages
+        else:
+            live = [True] * len(ps)
+        self._live = live
+
+    def bind_encoder(self, encoder) -> "_MFNBase":
+        if encoder.embedding_type != "gauss":
+            raise NotImplementedError("the MFN kernels fuse the 'gauss' Positional_Encoder")
+        self._enc_B = encoder.B.contiguous()
+        self._eng = None
+        return self
+
+    def _engine(self) -> MFNEngine:
+        if not self._flat.is_cuda:
+            raise RuntimeError("inr_mi355x models run on an MI355X only: call .to('cuda') first (no CPU fallback)")
+        if self._enc_B is None:
+            raise RuntimeError("call bind_encoder(Positional_Encoder(...)) first: the gauss encoder is fused into the "
+                               "filters and the model is evaluated on raw coordinates")
+        if self._eng is None:
+            self._eng = MFNEngine(self._multiscale, self._in, self._W, self._n, self._out, self._enc_B.shape[0])
+            self._eng.bind(self._flat)
+        return self._eng
+
+    def fused_engine(self, enc_size: int) -> MFNEngine:
+        return self._engine()
+
+    def _heads(self, coords):
+        return _MFNFunction.apply(self, coords, *self._flat_params)
+
+
+class FourierNet(_MFNBase):
+    """mfn.py:61-94."""
+
+    def __init__(self, params, out_size=1.0, input_scale=2.0, weight_scale=1.0, bias=True, output_act=False):
+        super().__init__()
+        if output_act:
+            raise NotImplementedError("output_act")
+        self._build_mfn(params, input_scale / np.sqrt(params["network_depth"] + 1), weight_scale)
+
+    def forward(self, x, dist_to_center=None):
+        return self._heads(x)[0]
+
+
+class MultiscaleKFourier(_MFNBase):
+    """mfn.py:206-267: heads output_linear[i] for i in [1,3,5,7]; returns a list of [B,out] tensors."""
+
+    _multiscale = True
+
+    def __init__(self, params, weight_scale=1.0, bias=True, output_act=False, centered=True,
+                 output_layers=(1, 3, 5, 7), reuse_filters=False):
+        super().__init__()
+        if tuple(output_layers) != (1, 3, 5, 7):
+            raise NotImplementedError("output_layers other than [1,3,5,7]")
+        self._build_mfn(params, weight_scale / np.sqrt(params["network_depth"] + 1), weight_scale)
+
+    def forward(self, coords, dist_to_center=None, **kw):
+        h = self._heads(coords)
+        return [h[k] for k in range(h.shape[0])]

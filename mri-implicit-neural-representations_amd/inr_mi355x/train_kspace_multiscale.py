@@ -1,0 +1,110 @@
+"""Multi-scale fitting driver: the loop of the reference's src/train_kspace_multiscale.py:161-201 over
+the fused MFN kernel (MultiscaleKFourier, 4 heads) with optional data parallelism over coordinates.
+
+Per step (reference lines 164-195):  outs = model(enc(coords), dist);  loss = 0.1*ConsistencyLoss(outs,
+dist) + sum_k 0.5*loss_fn(out_k, gt)  (limit_kspace is a no-op, SURVEY A.4 #2: every head sees the full
+gt);  Adam;  per-epoch LambdaLR.  Radii of the nested discs come from the k-means ring partition
+(clustering.py, out of the hot path) and are an input here.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib as L
+from .engine import ConsistencySpec, LossSpec
+from .evalchain import psnr, reconstruct
+from .mfn import MultiscaleKFourier
+from .networks import Positional_Encoder
+from .train import allreduce_step_outputs, lr_factor, set_default_configs, shard_rows
+
+
+def create_pairs(values: Sequence[float], multiplication_factor: int):
+    """train_kspace_multiscale.py:42-47."""
+    pairs = [(values[0], values[i + 1]) for i in range(len(values) - 1)]
+    return [(p[0], p[1]) for p in pairs for _ in range(multiplication_factor)]
+
+
+class MultiscaleTrainer:
+    def __init__(self, config: dict, image: torch.Tensor, coords: torch.Tensor, dist: torch.Tensor,
+                 radii: Sequence[float], shape, device, seed: int = 0, rank: int = 0, world: int = 1,
+                 process_group=None):
+        config = set_default_configs(dict(config))
+        self.config = config
+        self.device = torch.device(device)
+        self.rank, self.world, self.pg = rank, world, process_group
+        self.shape = shape
+        if config["model"] == "BoundedFourier":
+            raise NotImplementedError("MultiscaleBoundedFourier has no MI355X kernel yet")
+        kinds = {"L2": (L.LOSS_L2_HALF, 1.0), "L1": (L.LOSS_L1_HALF, 1.0), "LSL": (L.LOSS_LOGSPACE, 0.5)}
+        if config["loss"] not in kinds:
+            # HDR / FFL / tanh crash in the reference's multiscale script
+            raise NotImplementedError(f"loss {config['loss']!r} in the multiscale loop")
+        kind, self.scale = kinds[config["loss"]]
+        opts = config.get("loss_opts", {}) or {}
+        self.loss = LossSpec(kind, float(opts.get("hdr_eps", 1e-3)), float(opts.get("hdr_ff_sigma", 2.0)),
+                             float(opts.get("hdr_ff_factor", 0.5)))
+        torch.manual_seed(seed)
+        self.encoder = Positional_Encoder(config["encoder"], device=self.device)  # train_kspace_multiscale.py:90
+        self.model = MultiscaleKFourier(config["net"]).to(self.device).bind_encoder(self.encoder)
+        self.engine = self.model._engine()
+        self.enc_B = self.encoder.B.contiguous()
+        self.pairs = create_pairs(list(radii), 1)
+        self.n = coords.shape[0]
+        self.coords = coords.to(self.device).contiguous()
+        self.image = image.to(self.device).contiguous()
+        self.dist_cpu = dist.reshape(-1).contiguous()
+        self.dist = self.dist_cpu.to(self.device)
+        self.bs = int(config["batch_size"])
+        self.steps_per_epoch = math.ceil(self.n / self.bs)
+        self.global_step = 0
+        self._cons = {}
+
+    def _cons_spec(self, it: int, lo: int, hi: int) -> ConsistencySpec:
+        if it not in self._cons:
+            d = self.dist_cpu[lo:hi]
+            inv = []
+            for (blo, bhi) in self.pairs[:-1]:
+                n_rows = int(((d < blo) | (d > bhi)).sum())
+                inv.append(1.0 / (2.0 * n_rows) if n_rows else 0.0)  # mse_loss mean over rows x 2 channels
+            self._cons[it] = ConsistencySpec(0.1, self.pairs, inv + [0.0], 2)
+        return self._cons[it]
+
+    def step(self, epoch: int, it: int) -> torch.Tensor:
+        lo, hi = it * self.bs, min((it + 1) * self.bs, self.n)
+        slo, shi = shard_rows(lo, hi, self.rank, self.world)
+        loss = self.engine.train_step(self.coords[slo:shi], self.enc_B, self.image[slo:shi], self.loss,
+                                      count=hi - lo, dist=self.dist[slo:shi], scale=self.scale,
+                                      cons=self._cons_spec(it, lo, hi))
+        loss = allreduce_step_outputs(self.engine.grads, loss, self.world, self.pg)
+        lr = self.config["lr"] * lr_factor(epoch, self.config["max_epoch"])
+        self.engine.adam_step(lr, self.config["beta1"], self.config["beta2"], 1e-8, self.config["weight_decay"])
+        self.global_step += 1
+        return loss
+
+    def fit(self, max_steps: Optional[int] = None, log_every: int = 0):
+        logged = []
+        for epoch in range(self.config["max_epoch"]):
+            for it in range(self.steps_per_epoch):
+                if max_steps is not None and self.global_step >= max_steps:
+                    return logged
+                loss = self.step(epoch, it)
+                if log_every and self.global_step % log_every == 0:
+                    logged.append((self.global_step, float(loss)))
+        return logged
+
+    @torch.no_grad()
+    def predict_all(self, chunk: int = 1 << 18) -> torch.Tensor:
+        """outs[-1] is the reconstruction (train_kspace_multiscale.py:225)."""
+        outs = []
+        for lo in range(0, self.n, chunk):
+            hi = min(lo + chunk, self.n)
+            outs.append(self.engine.forward(self.coords[lo:hi], self.enc_B, save=False)[-1])
+        return torch.cat(outs, 0)
+
+    @torch.no_grad()
+    def evaluate(self) -> float:
+        ref = reconstruct(self.image, self.shape, False)
+        return float(psnr(ref, reconstruct(self.predict_all(), self.shape, False)))

@@ -1,0 +1,169 @@
+"""Multiplicative filter networks (models/mfn.py: FourierNet, MultiscaleKFourier) on the HIP path."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import oracle as O  # noqa: E402  (checker only)
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+META = json.load(open(os.path.join(GOLD, "model_meta.json")))
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def _load(name):
+    return dict(np.load(os.path.join(GOLD, name)))
+
+
+def rel_l2(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _classes():
+    from inr_mi355x.mfn import FourierNet, MultiscaleKFourier
+    return {"Fourier": FourierNet, "MultiscaleKFourier": MultiscaleKFourier}
+
+
+@pytest.mark.parametrize("name", ["Fourier", "MultiscaleKFourier"])
+def test_mfn_tier1_golden(dev, name):
+    """Drop-in class on raw coordinates (encoder fused) + stock torch.optim.Adam vs the reference's vectors;
+    dead layers of the multiscale net keep grad None and are not stepped."""
+    import inr_mi355x as M
+    meta = META[name]
+    arrs = _load(f"model_{name}.npz")
+    coords, gt = _t(arrs["coords"]).to(dev), _t(arrs["gt"]).to(dev)
+    gold_keys = [k[3:] for k in arrs if k.startswith("sd/")]
+    for wd_tag, wd in (("wd0", 0.0), ("wd1", meta["wd1"])):
+        torch.manual_seed(meta["seed"])
+        enc = M.Positional_Encoder(meta["encoder"], device=dev)
+        model = _classes()[name](meta["net"])
+        sd = model.state_dict()
+        assert list(sd.keys()) == gold_keys
+        for k in gold_keys:
+            assert torch.equal(sd[k], _t(arrs["sd/" + k])), k
+        model = model.to(dev).bind_encoder(enc)
+        optim = torch.optim.Adam(model.parameters(), lr=meta["lr"], betas=(0.9, 0.999), weight_decay=wd)
+        for step in range(1, 4):
+            out = model(coords)
+            optim.zero_grad()
+            outs = out if isinstance(out, list) else [out]
+            loss = sum(0.5 * torch.nn.functional.mse_loss(o, gt) for o in outs)
+            loss.backward()
+            if step == 1 and wd_tag == "wd0":
+                if isinstance(out, list):
+                    for i, o in enumerate(out):
+                        torch.testing.assert_close(o.detach().cpu(), _t(arrs[f"out/{i}"]), rtol=1e-5, atol=2e-6)
+                else:
+                    torch.testing.assert_close(out.detach().cpu(), _t(arrs["out"]), rtol=1e-5, atol=2e-6)
+                torch.testing.assert_close(loss.detach().cpu(), _t(arrs["loss"]), rtol=1e-5, atol=0)
+                gold_grad = {k[5:] for k in arrs if k.startswith("grad/")}
+                for k, p in model.named_parameters():
+                    if k in gold_grad:
+                        ref = _t(arrs["grad/" + k])
+                        assert rel_l2(p.grad.cpu(), ref) < 1e-5, (k, rel_l2(p.grad.cpu(), ref))
+                    else:
+                        assert p.grad is None, k
+            optim.step()
+            if step in (1, 3):
+                for k, v in model.state_dict().items():
+                    ref = _t(arrs[f"{wd_tag}/step{step}/" + k])
+                    torch.testing.assert_close(v.cpu(), ref, rtol=1e-5, atol=2e-6,
+                                               msg=lambda m: f"{wd_tag} step{step} {k}: {m}")
+
+
+@pytest.mark.parametrize("name", ["Fourier", "MultiscaleKFourier"])
+def test_mfn_tier2_fused_golden(dev, name):
+    import inr_mi355x as M
+    from inr_mi355x import _lib as L
+    meta = META[name]
+    arrs = _load(f"model_{name}.npz")
+    coords, gt = _t(arrs["coords"]).to(dev), _t(arrs["gt"]).to(dev)
+    for wd_tag, wd in (("wd0", 0.0), ("wd1", meta["wd1"])):
+        torch.manual_seed(meta["seed"])
+        enc = M.Positional_Encoder(meta["encoder"], device=dev)
+        model = _classes()[name](meta["net"]).to(dev).bind_encoder(enc)
+        eng = model._engine()
+        for step in range(1, 4):
+            loss = eng.train_step(coords, enc.B.contiguous(), gt, M.LossSpec(L.LOSS_L2_HALF))
+            if step == 1 and wd_tag == "wd0":
+                torch.testing.assert_close(loss.cpu(), _t(arrs["loss"]), rtol=1e-5, atol=0)
+            eng.adam_step(meta["lr"], 0.9, 0.999, 1e-8, wd)
+            if step in (1, 3):
+                for k, v in model.state_dict().items():
+                    ref = _t(arrs[f"{wd_tag}/step{step}/" + k])
+                    torch.testing.assert_close(v.cpu(), ref, rtol=1e-5, atol=2e-6,
+                                               msg=lambda m: f"{wd_tag} step{step} {k}: {m}")
+
+
+def test_multiscale_trajectory_golden(dev):
+    """LogSpace (x0.5) + 0.1*Consistency over sequential batches: train_kspace_multiscale.py:164-195."""
+    from inr_mi355x.train_kspace_multiscale import MultiscaleTrainer
+    arrs = _load("trajectory_ms.npz")
+    meta = json.load(open(os.path.join(GOLD, "trajectory_ms_meta.json")))
+    coords, image, dist = _t(arrs["coords"]), _t(arrs["image"]), _t(arrs["dist"])
+    cfg = meta["cases"]["MS_LSL"]
+    tr = MultiscaleTrainer(cfg, image, coords, dist, meta["radii"], tuple(meta["shape"]), dev, seed=meta["seed"])
+    got = np.array([s[1] for s in tr.fit(meta["steps"], log_every=1)])
+    np.testing.assert_allclose(got, arrs["MS_LSL/losses"], rtol=5e-4)
+    out = tr.predict_all().cpu()
+    torch.testing.assert_close(out, _t(arrs["MS_LSL/final_out"]), rtol=2e-3, atol=5e-5)
+
+
+@pytest.mark.parametrize("shape", ["fourier_4x256", "multiscale_8x512"])
+def test_mfn_full_size_vs_oracle(dev, shape):
+    """Widths of the shipped configs (remote/config_fourier_kspace.yaml; BASELINE config 4:
+    MultiscaleKFourier 8x512, 64-coordinate tiles).  Criterion: as close to a float64 evaluation as the
+    reference's own fp32 CPU path (x10), see tests/test_gpu_wire.py."""
+    import inr_mi355x as M
+    from inr_mi355x import _lib as L
+    from inr_mi355x.mfn import FourierNet, MultiscaleKFourier
+    multi = shape.startswith("multi")
+    net = dict(network_input_size=512, network_output_size=2, network_depth=8 if multi else 4,
+               network_width=512 if multi else 256)
+    enc_cfg = dict(embedding="gauss", scale=4, embedding_size=256, coordinates_size=3)
+    torch.manual_seed(0)
+    enc = M.Positional_Encoder(enc_cfg, device=dev)
+    model = (MultiscaleKFourier if multi else FourierNet)(net)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.to(dev).bind_encoder(enc)
+    B = 333
+    g = torch.Generator().manual_seed(1)
+    coords = torch.rand(B, 3, generator=g) * 2 - 1
+    gt = torch.randn(B, 2, generator=g) * 0.2
+    kind = "MultiscaleKFourier" if multi else "Fourier"
+    keys = O.trainable_keys(kind, sd)
+
+    def ref(dtype):
+        params = {k: (v.to(dtype).clone().requires_grad_(True) if k in keys else v.to(dtype)) for k, v in sd.items()}
+        x = O.encode(coords.to(dtype), enc.B.cpu().to(dtype), "gauss")
+        outs = O.model_forward(kind, params, x, net)
+        outs = outs if isinstance(outs, list) else [outs]
+        loss = sum(O.loss_l2_half(o, gt.to(dtype)) for o in outs)
+        grads = torch.autograd.grad(loss, [params[k] for k in keys])
+        return torch.stack([o.detach() for o in outs]), loss.detach(), torch.cat([x_.reshape(-1) for x_ in grads])
+
+    o32, l32, g32 = ref(torch.float32)
+    o64, l64, g64 = ref(torch.float64)
+    eng = model._engine()
+    out = eng.forward(coords.to(dev), enc.B.contiguous(), save=False).cpu()
+    loss = eng.train_step(coords.to(dev), enc.B.contiguous(), gt.to(dev), M.LossSpec(L.LOSS_L2_HALF))
+    flat = eng.grads.cpu()
+    live = torch.cat([flat[o:o + n] for (o, n, s, c), lv in zip(model._layout, model._live) if lv])
+    for name, got, r32, r64 in (("out", out, o32, o64), ("grad", live, g32, g64)):
+        e_gpu, e_cpu = rel_l2(got, r64), rel_l2(r32, r64)
+        assert e_gpu <= max(10 * e_cpu, 2e-5), (name, e_gpu, e_cpu)
+    assert abs(float(loss) - float(l64)) <= max(10 * abs(float(l32) - float(l64)), 2e-5 * abs(float(l64)))
