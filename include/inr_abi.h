@@ -45,9 +45,11 @@ enum inr_kind {
   INR_KIND_FFN = 1,   /* models/networks.py:48-69   FFN (ReLU hidden, Sigmoid output) */
   INR_KIND_WIRE = 2,  /* models/networks.py:206-260 WIRE / ComplexGaborLayer :160-204 (complex64 layers) */
   INR_KIND_FOURIER = 3,   /* models/mfn.py:61-94    FourierNet (one output_linear after the last stage) */
-  INR_KIND_MSFOURIER = 4  /* models/mfn.py:206-267  MultiscaleKFourier: heads output_linear[i], i in [1,3,5,7];
+  INR_KIND_MSFOURIER = 4, /* models/mfn.py:206-267  MultiscaleKFourier: heads output_linear[i], i in [1,3,5,7];
                              the unused last stage / heads exist in flat params but are never evaluated or
                              stepped (the reference leaves their .grad = None) */
+  INR_KIND_MSBOUNDED = 5  /* models/mfn.py:288-355  MultiscaleBoundedFourier: BoundedLinear (:269-286) zeroes the rows
+                             of h whose dist lies outside [lo,hi] before each hidden Linear */
 };
 
 /* activation of the last layer */
@@ -175,10 +177,14 @@ int inr_train_step(const inr_plan* plan, const inr_loss_desc* loss, const float*
  * consistency term; `save` is always required (it also carries the encoder features between stages;
  * pass n_blocks slots and by_block = 1 for a no_grad sweep, n_tiles slots and 0 before inr_backward_multi). */
 int inr_forward_multi(const inr_plan* plan, const float* params, const float* packed, const float* coords,
-                      const float* enc_B, int64_t B, float* out, float* save, int32_t by_block, void* stream);
+                      const float* enc_B, const float* dist, int64_t B, float* out, float* save,
+                      int32_t by_block, void* stream);
 int inr_backward_multi(const inr_plan* plan, const float* params, const float* packed, const float* coords,
-                       const float* enc_B, int64_t B, const float* dout, const float* save, float* slabs,
-                       float* grads, void* stream);
+                       const float* enc_B, const float* dist, int64_t B, const float* dout, const float* save,
+                       float* slabs, float* grads, void* stream);
+/* MultiscaleBoundedFourier(boundaries=pairs_model) (train_kspace_multiscale.py:85,95): one (lo,hi) per hidden
+ * Linear; must be called before the plan is used (dist may be NULL for the other kinds above). */
+int inr_plan_set_bounds(inr_plan* plan, const float* lo, const float* hi, int32_t n);
 int inr_train_step_multi(const inr_plan* plan, const inr_loss_desc* loss, const float* params,
                          const float* packed, const float* coords, const float* enc_B, const float* gt,
                          const float* dist, const uint8_t* mask, int64_t B, float* save, float* slabs,

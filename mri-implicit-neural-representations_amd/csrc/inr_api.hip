@@ -46,7 +46,7 @@ struct inr_plan {
 // Multiplicative filter networks (models/mfn.py).  L[] = filters 0..n | linears 0..n-1 | heads; flat
 // parameters keep the state_dict order  linear.* , output_linear(.k).* , filters.*  (SURVEY Appendix B).
 static int create_mfn_plan(const inr_net_desc* d, inr_plan** out) {
-  const bool multi = d->kind == INR_KIND_MSFOURIER;
+  const bool multi = d->kind == INR_KIND_MSFOURIER || d->kind == INR_KIND_MSBOUNDED;
   const int n = d->depth, W = d->width;
   if (n < 1 || 2 * n + 1 + (multi ? n + 1 : 1) > INR_MAX_LAYERS)
     return fail(INR_ERR_INVALID, "inr_plan_create: MFN depth %d", n);
@@ -71,6 +71,13 @@ static int create_mfn_plan(const inr_net_desc* d, inr_plan** out) {
   nd.E = d->enc_size;
   nd.out_f = d->out_features;
   nd.mfn_n = n;
+  if (d->kind == INR_KIND_MSBOUNDED) {
+    nd.bounded = 1;  // bounds default to "everything" until inr_plan_set_bounds is called
+    for (int i = 0; i < INR_MAX_LAYERS / 2; ++i) {
+      nd.bound_lo[i] = -1e30f;
+      nd.bound_hi[i] = 1e30f;
+    }
+  }
   // heads: FourierNet -> output_linear after the last stage (mfn.py:85-94); multiscale -> output_linear[i]
   // for i in output_layers = [1,3,5,7] (mfn.py:223,262-263), those beyond depth do not exist
   if (multi) {
@@ -174,7 +181,8 @@ int inr_last_error(char* buf, size_t cap) {
 int inr_plan_create(const inr_net_desc* d, inr_plan** out) {
   if (d == nullptr || out == nullptr) return fail(INR_ERR_INVALID, "inr_plan_create: null argument");
   *out = nullptr;
-  if (d->kind == INR_KIND_FOURIER || d->kind == INR_KIND_MSFOURIER) return create_mfn_plan(d, out);
+  if (d->kind == INR_KIND_FOURIER || d->kind == INR_KIND_MSFOURIER || d->kind == INR_KIND_MSBOUNDED)
+    return create_mfn_plan(d, out);
   if (d->kind != INR_KIND_SIREN && d->kind != INR_KIND_FFN && d->kind != INR_KIND_WIRE)
     return fail(INR_ERR_UNSUPPORTED, "inr_plan_create: kind %d has no kernel yet", d->kind);
   const bool wire = d->kind == INR_KIND_WIRE;
@@ -497,6 +505,17 @@ int inr_train_step(const inr_plan* plan, const inr_loss_desc* loss, const float*
   return INR_OK;
 }
 
+int inr_plan_set_bounds(inr_plan* plan, const float* lo, const float* hi, int32_t n) {
+  if (plan == nullptr || lo == nullptr || hi == nullptr) return fail(INR_ERR_INVALID, "inr_plan_set_bounds: null argument");
+  if (!plan->nd.bounded) return fail(INR_ERR_INVALID, "inr_plan_set_bounds: not a MultiscaleBoundedFourier plan");
+  if (n != plan->nd.mfn_n) return fail(INR_ERR_INVALID, "inr_plan_set_bounds: %d bounds for %d linears", n, plan->nd.mfn_n);
+  for (int i = 0; i < n; ++i) {
+    plan->nd.bound_lo[i] = lo[i];
+    plan->nd.bound_hi[i] = hi[i];
+  }
+  return INR_OK;
+}
+
 int inr_plan_heads(const inr_plan* plan, int32_t* n_heads) {
   if (plan == nullptr || n_heads == nullptr) return fail(INR_ERR_INVALID, "inr_plan_heads: null argument");
   *n_heads = plan->nd.mfn_n > 0 ? plan->nd.n_heads : 1;
@@ -504,10 +523,12 @@ int inr_plan_heads(const inr_plan* plan, int32_t* n_heads) {
 }
 
 int inr_forward_multi(const inr_plan* plan, const float* params, const float* packed, const float* coords,
-                      const float* enc_B, int64_t B, float* out, float* save, int32_t by_block, void* stream) {
+                      const float* enc_B, const float* dist, int64_t B, float* out, float* save, int32_t by_block,
+                      void* stream) {
   if (plan == nullptr || params == nullptr || packed == nullptr || coords == nullptr || enc_B == nullptr ||
       out == nullptr || save == nullptr)
     return fail(INR_ERR_INVALID, "inr_forward_multi: null argument");
+  if (plan->nd.bounded && dist == nullptr) return fail(INR_ERR_INVALID, "inr_forward_multi: bounded model needs dist");
   if (plan->nd.mfn_n == 0) return fail(INR_ERR_INVALID, "inr_forward_multi: not a multiplicative-filter plan");
   if (B <= 0) return fail(INR_ERR_INVALID, "inr_forward_multi: B = %lld", (long long)B);
   int64_t nt, nb;
@@ -519,6 +540,7 @@ int inr_forward_multi(const inr_plan* plan, const float* params, const float* pa
   a.x = coords;
   a.encB = enc_B;
   a.out = out;
+  a.dist = dist;
   a.save = save;
   a.B = B;
   a.n_tiles = (int)nt;
@@ -529,11 +551,12 @@ int inr_forward_multi(const inr_plan* plan, const float* params, const float* pa
 }
 
 int inr_backward_multi(const inr_plan* plan, const float* params, const float* packed, const float* coords,
-                       const float* enc_B, int64_t B, const float* dout, const float* save, float* slabs,
-                       float* grads, void* stream) {
+                       const float* enc_B, const float* dist, int64_t B, const float* dout, const float* save,
+                       float* slabs, float* grads, void* stream) {
   if (plan == nullptr || params == nullptr || packed == nullptr || coords == nullptr || enc_B == nullptr ||
       dout == nullptr || save == nullptr || slabs == nullptr || grads == nullptr)
     return fail(INR_ERR_INVALID, "inr_backward_multi: null argument");
+  if (plan->nd.bounded && dist == nullptr) return fail(INR_ERR_INVALID, "inr_backward_multi: bounded model needs dist");
   if (plan->nd.mfn_n == 0) return fail(INR_ERR_INVALID, "inr_backward_multi: not a multiplicative-filter plan");
   if (B <= 0) return fail(INR_ERR_INVALID, "inr_backward_multi: B = %lld", (long long)B);
   int64_t nt, nb;
@@ -545,6 +568,7 @@ int inr_backward_multi(const inr_plan* plan, const float* params, const float* p
   a.x = coords;
   a.encB = enc_B;
   a.dout = dout;
+  a.dist = dist;
   a.save = const_cast<float*>(save);
   a.slabs = slabs;
   a.B = B;
@@ -569,8 +593,8 @@ int inr_train_step_multi(const inr_plan* plan, const inr_loss_desc* loss, const 
   if (plan->nd.mfn_n == 0) return fail(INR_ERR_INVALID, "inr_train_step_multi: not a multiplicative-filter plan");
   if (loss->kind < INR_LOSS_L2_HALF || loss->kind > INR_LOSS_HDR)
     return fail(INR_ERR_INVALID, "inr_train_step_multi: loss kind %d", loss->kind);
-  if (loss->cons_w != 0.f && dist == nullptr)
-    return fail(INR_ERR_INVALID, "inr_train_step_multi: the consistency term needs dist");
+  if ((loss->cons_w != 0.f || plan->nd.bounded) && dist == nullptr)
+    return fail(INR_ERR_INVALID, "inr_train_step_multi: the consistency term / bounded linears need dist");
   if (B <= 0) return fail(INR_ERR_INVALID, "inr_train_step_multi: B = %lld", (long long)B);
   int64_t nt, nb;
   inr_plan_launch_dims(plan, B, &nt, &nb);

@@ -103,6 +103,36 @@ __device__ __forceinline__ void mfn_epilogue(const f32x16 (&acc)[NB], float* R, 
 // dW pass whose A operand is (image value) * (stashed factor): g_l = g_h*f or g_u = g_h*(l cos u).
 // Factor rows are read "feature on lane", 4 coordinates per float4, like the B operand.
 // ---------------------------------------------------------------------------------------------
+// h_{i-1} stash rows with BoundedLinear's row mask (mfn.py:281-286): coordinates whose distance to the
+// k-space centre lies outside [lo, hi] contribute nothing to dW of the inner Linear (its bias still does).
+template <int TL>
+struct BSrcStashKeep {
+  const float* __restrict__ h;
+  const float* __restrict__ dist;  // [B]
+  long long row0, B;
+  float lo, hi;
+  struct Raw {
+    f32x4 v, d;
+  };
+  __device__ __forceinline__ Raw fetch(int n, int q, int lane) const {
+    const int j = 32 * n + (lane & 31);
+    Raw r;
+    r.v = *reinterpret_cast<const f32x4*>(h + j * TL + 8 * q + 4 * (lane >> 5));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const long long row = row0 + 8 * q + 4 * (lane >> 5) + e;
+      r.d[e] = dist[row < B ? row : 0];
+    }
+    return r;
+  }
+  __device__ __forceinline__ f32x4 finish(const Raw& r) const {
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (r.d[e] < lo || r.d[e] > hi) ? 0.f : r.v[e];
+    return o;
+  }
+};
+
 template <int MT, int TL>
 __device__ __forceinline__ void load_fac(f32x4 (&f)[MT], const float* __restrict__ fac, int m0, int q, int lane) {
   const int li = lane & 31;
@@ -385,8 +415,14 @@ __global__ __launch_bounds__(NW * 64) void inr_mfn_kernel(const NetDesc nd, cons
         __syncthreads();
         // ---- dL_{i-1} = (g_h*f_i)^T h_{i-1} (+ db), dF_i = (g_h*l_i cos u_i)^T x (+ dc)
         {
-          BSrcStash<TL> bh{sv + (size_t)(3 * (i - 1) + 2) * HSZ};
-          dwf_layer<NB, TL, BSrcStash<TL>>(lds, RS, svi, bh, Ll[i - 1], slab, first, w, NW, lane);
+          if (nd.bounded) {
+            BSrcStashKeep<TL> bh{sv + (size_t)(3 * (i - 1) + 2) * HSZ, a.dist, row0, a.B, nd.bound_lo[i - 1],
+                                 nd.bound_hi[i - 1]};
+            dwf_layer<NB, TL, BSrcStashKeep<TL>>(lds, RS, svi, bh, Ll[i - 1], slab, first, w, NW, lane);
+          } else {
+            BSrcStash<TL> bh{sv + (size_t)(3 * (i - 1) + 2) * HSZ};
+            dwf_layer<NB, TL, BSrcStash<TL>>(lds, RS, svi, bh, Ll[i - 1], slab, first, w, NW, lane);
+          }
           BSrcStash<TL> bx{sv_enc};
           dwf_layer<NB, TL, BSrcStash<TL>>(lds, RS, svi + HSZ, bx, Fl[i], slab, first, w, NW, lane);
         }

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("INR_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "lib", "libinr_mi355x.so")
 
 # enums (include/inr_abi.h)
-KIND_SIREN, KIND_FFN, KIND_WIRE, KIND_FOURIER, KIND_MSFOURIER = 0, 1, 2, 3, 4
+KIND_SIREN, KIND_FFN, KIND_WIRE, KIND_FOURIER, KIND_MSFOURIER, KIND_MSBOUNDED = 0, 1, 2, 3, 4, 5
 ACT_ID, ACT_SIN, ACT_TANH, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3, 4
 INPUT_X, INPUT_GAUSS = 0, 1
 LOSS_L2_HALF, LOSS_L1_HALF, LOSS_TANH, LOSS_LOGSPACE, LOSS_HDR = 0, 1, 2, 3, 4
@@ -54,8 +54,9 @@ SYMBOLS = {
     "inr_loss_grad": (C.c_int, [C.POINTER(LossDesc), _P, _P, _P, _P, C.c_int64, _P, _P, _P]),
     "inr_train_step": (C.c_int, [_P, C.POINTER(LossDesc), _P, _P, _P, _P, _P, _P, C.c_int64, _P, _P, _P, _P, _P]),
     "inr_plan_heads": (C.c_int, [_P, C.POINTER(C.c_int32)]),
-    "inr_forward_multi": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, _P, _P, C.c_int32, _P]),
-    "inr_backward_multi": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, _P, _P, _P, _P, _P]),
+    "inr_plan_set_bounds": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int32]),
+    "inr_forward_multi": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, _P, _P, C.c_int32, _P]),
+    "inr_backward_multi": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, _P, _P, _P, _P, _P]),
     "inr_train_step_multi": (C.c_int, [_P, C.POINTER(LossDesc), _P, _P, _P, _P, _P, _P, _P, C.c_int64, _P, _P, _P,
                                        _P, _P]),
     "inr_adam_step": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_double, C.c_double, C.c_double, C.c_double,

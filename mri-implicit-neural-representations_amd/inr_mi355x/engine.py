@@ -207,28 +207,35 @@ class MFNEngine(MLPEngine):
     """Plan + buffers for the multiplicative filter networks (models/mfn.py: FourierNet,
     MultiscaleKFourier).  Heads come back as one [n_heads, B, out] tensor."""
 
-    def __init__(self, multiscale: bool, in_features: int, width: int, depth: int, out_features: int, enc_size: int):
-        super().__init__(L.KIND_MSFOURIER if multiscale else L.KIND_FOURIER, in_features, width, depth, out_features,
-                         L.ACT_ID, L.INPUT_GAUSS, enc_size, 0.0)
+    def __init__(self, kind: int, in_features: int, width: int, depth: int, out_features: int, enc_size: int,
+                 bounds=None):
+        super().__init__(kind, in_features, width, depth, out_features, L.ACT_ID, L.INPUT_GAUSS, enc_size, 0.0)
         nh = C.c_int32()
         L.check(self.lib.inr_plan_heads(self.plan, C.byref(nh)))
         self.n_heads = int(nh.value)
+        if kind == L.KIND_MSBOUNDED:
+            lo = (C.c_float * depth)(*[float(b[0]) for b in bounds])
+            hi = (C.c_float * depth)(*[float(b[1]) for b in bounds])
+            L.check(self.lib.inr_plan_set_bounds(self.plan, lo, hi, depth))
 
-    def forward(self, coords: torch.Tensor, enc_B: torch.Tensor, save: bool = False) -> torch.Tensor:
+    def forward(self, coords: torch.Tensor, enc_B: torch.Tensor, save: bool = False,
+                dist: Optional[torch.Tensor] = None) -> torch.Tensor:
         B = coords.shape[0]
         nt, nb = self.launch_dims(B)
         out = torch.empty(self.n_heads, B, self.out_features, device=coords.device)
         sv = self._ws_save(nt if save else nb)
         L.check(self.lib.inr_forward_multi(self.plan, _ptr(self.params, "params"), _ptr(self.packed, "packed"),
-                                           _ptr(coords, "coords"), _ptr(enc_B, "enc_B"), B, _ptr(out, "out"),
-                                           _ptr(sv, "save"), 0 if save else 1, self._stream()))
+                                           _ptr(coords, "coords"), _ptr(enc_B, "enc_B"), _ptr(dist, "dist"), B,
+                                           _ptr(out, "out"), _ptr(sv, "save"), 0 if save else 1, self._stream()))
         return out
 
-    def backward(self, coords: torch.Tensor, enc_B: torch.Tensor, dout: torch.Tensor) -> torch.Tensor:
+    def backward(self, coords: torch.Tensor, enc_B: torch.Tensor, dout: torch.Tensor,
+                 dist: Optional[torch.Tensor] = None) -> torch.Tensor:
         B = coords.shape[0]
         nt, nb = self.launch_dims(B)
         L.check(self.lib.inr_backward_multi(self.plan, _ptr(self.params, "params"), _ptr(self.packed, "packed"),
-                                            _ptr(coords, "coords"), _ptr(enc_B, "enc_B"), B, _ptr(dout, "dout"),
+                                            _ptr(coords, "coords"), _ptr(enc_B, "enc_B"), _ptr(dist, "dist"), B,
+                                            _ptr(dout, "dout"),
                                             _ptr(self._ws_save(nt), "save"), _ptr(self._ws_slabs(nb), "slabs"),
                                             _ptr(self.grads, "grads"), self._stream()))
         return self.grads

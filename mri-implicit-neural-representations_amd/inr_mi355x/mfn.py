@@ -23,13 +23,15 @@ from .networks import _FlatModel, _Holder, _view
 
 class _MFNFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, module, coords, *params):
+    def forward(ctx, module, coords, dist, *params):
         eng = module._engine()
         eng.pack()
-        need_grad = any(ctx.needs_input_grad[2:])
+        need_grad = any(ctx.needs_input_grad[3:])
         coords = coords.contiguous()
-        out = eng.forward(coords, module._enc_B, save=need_grad)
+        dist = dist.reshape(-1).contiguous() if dist is not None else None
+        out = eng.forward(coords, module._enc_B, save=need_grad, dist=dist)
         ctx.module = module
+        ctx.dist = dist
         ctx.save_for_backward(coords)
         return out
 
@@ -38,11 +40,11 @@ class _MFNFunction(torch.autograd.Function):
         (coords,) = ctx.saved_tensors
         module = ctx.module
         eng = module._engine()
-        flat_grad = eng.backward(coords, module._enc_B, dout.contiguous())
+        flat_grad = eng.backward(coords, module._enc_B, dout.contiguous(), dist=ctx.dist)
         grads = []
         for (o, n, s, c), live in zip(module._layout, module._live):
             grads.append(_view(flat_grad, o, n, s, c) if live else None)  # dead layers: grad None, like autograd
-        return (None, None, *grads)
+        return (None, None, None, *grads)
 
 
 class _FilterShell(nn.Module):
@@ -51,8 +53,16 @@ class _FilterShell(nn.Module):
         self.linear = holder  # filters.k.linear.weight / bias
 
 
+class _BoundedShell(nn.Module):
+    def __init__(self, holder: _Holder, bounds):
+        super().__init__()
+        self.linear = holder  # linear.k.linear.weight / bias (BoundedLinear wraps a Linear, mfn.py:277-279)
+        self.bounds = bounds
+
+
 class _MFNBase(_FlatModel):
     _multiscale = False
+    _bounds = None
 
     def _build_mfn(self, params, filter_scale: float, weight_scale: float):
         n = params["network_depth"]
@@ -67,6 +77,8 @@ class _MFNBase(_FlatModel):
         b = np.sqrt(weight_scale / W)
         for m in lin:
             m.weight.data.uniform_(-b, b)
+        if self._bounds is not None:  # mfn.py:319-321: a fresh list of BoundedLinear (default init) replaces it
+            lin = [nn.Linear(W, W) for _ in range(n)]
         # child: n+1 FourierLayer (mfn.py:50-55): default init, weight *= scale, bias ~ U(-pi, pi)
         filt = []
         for _ in range(n + 1):
@@ -82,7 +94,11 @@ class _MFNBase(_FlatModel):
             tensors += [m.weight.detach(), m.bias.detach()]
         ps = self._flatten(tensors)
         k = 0
-        self.linear = nn.ModuleList([_Holder(ps[2 * i], ps[2 * i + 1]) for i in range(n)])
+        if self._bounds is not None:
+            self.linear = nn.ModuleList([_BoundedShell(_Holder(ps[2 * i], ps[2 * i + 1]), self._bounds[i])
+                                         for i in range(n)])
+        else:
+            self.linear = nn.ModuleList([_Holder(ps[2 * i], ps[2 * i + 1]) for i in range(n)])
         k = 2 * n
         if self._multiscale:
             self.output_linear = nn.ModuleList([_Holder(ps[k + 2 * i], ps[k + 2 * i + 1]) for i in range(n + 1)])
@@ -117,15 +133,17 @@ class _MFNBase(_FlatModel):
             raise RuntimeError("call bind_encoder(Positional_Encoder(...)) first: the gauss encoder is fused into the "
                                "filters and the model is evaluated on raw coordinates")
         if self._eng is None:
-            self._eng = MFNEngine(self._multiscale, self._in, self._W, self._n, self._out, self._enc_B.shape[0])
+            from . import _lib as L
+            kind = L.KIND_MSBOUNDED if self._bounds is not None else (L.KIND_MSFOURIER if self._multiscale else L.KIND_FOURIER)
+            self._eng = MFNEngine(kind, self._in, self._W, self._n, self._out, self._enc_B.shape[0], self._bounds)
             self._eng.bind(self._flat)
         return self._eng
 
     def fused_engine(self, enc_size: int) -> MFNEngine:
         return self._engine()
 
-    def _heads(self, coords):
-        return _MFNFunction.apply(self, coords, *self._flat_params)
+    def _heads(self, coords, dist=None):
+        return _MFNFunction.apply(self, coords, dist, *self._flat_params)
 
 
 class FourierNet(_MFNBase):
@@ -155,4 +173,23 @@ class MultiscaleKFourier(_MFNBase):
 
     def forward(self, coords, dist_to_center=None, **kw):
         h = self._heads(coords)
+        return [h[k] for k in range(h.shape[0])]
+
+
+class MultiscaleBoundedFourier(_MFNBase):
+    """mfn.py:288-355: MultiscaleKFourier whose hidden Linears are BoundedLinear(bounds[i]) -- rows of h with
+    dist outside [lo, hi] are zeroed before the Linear (the bias still reaches them)."""
+
+    _multiscale = True
+
+    def __init__(self, params, weight_scale=1.0, bias=True, output_act=False, centered=True,
+                 output_layers=(1, 3, 5, 7), reuse_filters=False, boundaries=None):
+        super().__init__()
+        if tuple(output_layers) != (1, 3, 5, 7):
+            raise NotImplementedError("output_layers other than [1,3,5,7]")
+        self._bounds = [tuple(b) for b in boundaries][:params["network_depth"]]
+        self._build_mfn(params, weight_scale / np.sqrt(params["network_depth"] + 1), weight_scale)
+
+    def forward(self, coords, dist_to_center=None):
+        h = self._heads(coords, dist_to_center)
         return [h[k] for k in range(h.shape[0])]

@@ -16,7 +16,7 @@ import torch
 from . import _lib as L
 from .engine import ConsistencySpec, LossSpec
 from .evalchain import psnr, reconstruct
-from .mfn import MultiscaleKFourier
+from .mfn import MultiscaleBoundedFourier, MultiscaleKFourier
 from .networks import Positional_Encoder
 from .train import allreduce_step_outputs, lr_factor, set_default_configs, shard_rows
 
@@ -36,8 +36,6 @@ class MultiscaleTrainer:
         self.device = torch.device(device)
         self.rank, self.world, self.pg = rank, world, process_group
         self.shape = shape
-        if config["model"] == "BoundedFourier":
-            raise NotImplementedError("MultiscaleBoundedFourier has no MI355X kernel yet")
         kinds = {"L2": (L.LOSS_L2_HALF, 1.0), "L1": (L.LOSS_L1_HALF, 1.0), "LSL": (L.LOSS_LOGSPACE, 0.5)}
         if config["loss"] not in kinds:
             # HDR / FFL / tanh crash in the reference's multiscale script
@@ -48,7 +46,11 @@ class MultiscaleTrainer:
                              float(opts.get("hdr_ff_factor", 0.5)))
         torch.manual_seed(seed)
         self.encoder = Positional_Encoder(config["encoder"], device=self.device)  # train_kspace_multiscale.py:90
-        self.model = MultiscaleKFourier(config["net"]).to(self.device).bind_encoder(self.encoder)
+        if config["model"] == "BoundedFourier":  # train_kspace_multiscale.py:93-95
+            self.model = MultiscaleBoundedFourier(config["net"], boundaries=create_pairs(list(radii), 2))
+        else:
+            self.model = MultiscaleKFourier(config["net"])
+        self.model = self.model.to(self.device).bind_encoder(self.encoder)
         self.engine = self.model._engine()
         self.enc_B = self.encoder.B.contiguous()
         self.pairs = create_pairs(list(radii), 1)
@@ -101,7 +103,7 @@ class MultiscaleTrainer:
         outs = []
         for lo in range(0, self.n, chunk):
             hi = min(lo + chunk, self.n)
-            outs.append(self.engine.forward(self.coords[lo:hi], self.enc_B, save=False)[-1])
+            outs.append(self.engine.forward(self.coords[lo:hi], self.enc_B, save=False, dist=self.dist[lo:hi])[-1])
         return torch.cat(outs, 0)
 
     @torch.no_grad()

@@ -34,11 +34,13 @@ def dev():
 
 
 def _classes():
-    from inr_mi355x.mfn import FourierNet, MultiscaleKFourier
-    return {"Fourier": FourierNet, "MultiscaleKFourier": MultiscaleKFourier}
+    from inr_mi355x.mfn import FourierNet, MultiscaleBoundedFourier, MultiscaleKFourier
+    b8 = META["BoundedFourier"]["bounds8"]
+    return {"Fourier": FourierNet, "MultiscaleKFourier": MultiscaleKFourier,
+            "BoundedFourier": lambda net: MultiscaleBoundedFourier(net, boundaries=b8)}
 
 
-@pytest.mark.parametrize("name", ["Fourier", "MultiscaleKFourier"])
+@pytest.mark.parametrize("name", ["Fourier", "MultiscaleKFourier", "BoundedFourier"])
 def test_mfn_tier1_golden(dev, name):
     """Drop-in class on raw coordinates (encoder fused) + stock torch.optim.Adam vs the reference's vectors;
     dead layers of the multiscale net keep grad None and are not stepped (SURVEY A.4 #3)."""
@@ -46,6 +48,7 @@ def test_mfn_tier1_golden(dev, name):
     meta = META[name]
     arrs = _load(f"model_{name}.npz")
     coords, gt = _t(arrs["coords"]).to(dev), _t(arrs["gt"]).to(dev)
+    dist = torch.sqrt(coords[:, 1] ** 2 + coords[:, 2] ** 2).contiguous()
     gold_keys = [k[3:] for k in arrs if k.startswith("sd/")]
     for wd_tag, wd in (("wd0", 0.0), ("wd1", meta["wd1"])):
         torch.manual_seed(meta["seed"])
@@ -58,7 +61,7 @@ def test_mfn_tier1_golden(dev, name):
         model = model.to(dev).bind_encoder(enc)
         optim = torch.optim.Adam(model.parameters(), lr=meta["lr"], betas=(0.9, 0.999), weight_decay=wd)
         for step in range(1, 4):
-            out = model(coords)
+            out = model(coords, dist)
             optim.zero_grad()
             outs = out if isinstance(out, list) else [out]
             loss = sum(0.5 * torch.nn.functional.mse_loss(o, gt) for o in outs)
@@ -85,20 +88,21 @@ def test_mfn_tier1_golden(dev, name):
                                                msg=lambda m: f"{wd_tag} step{step} {k}: {m}")
 
 
-@pytest.mark.parametrize("name", ["Fourier", "MultiscaleKFourier"])
+@pytest.mark.parametrize("name", ["Fourier", "MultiscaleKFourier", "BoundedFourier"])
 def test_mfn_tier2_fused_golden(dev, name):
     import inr_mi355x as M
     from inr_mi355x import _lib as L
     meta = META[name]
     arrs = _load(f"model_{name}.npz")
     coords, gt = _t(arrs["coords"]).to(dev), _t(arrs["gt"]).to(dev)
+    dist = torch.sqrt(coords[:, 1] ** 2 + coords[:, 2] ** 2).contiguous()
     for wd_tag, wd in (("wd0", 0.0), ("wd1", meta["wd1"])):
         torch.manual_seed(meta["seed"])
         enc = M.Positional_Encoder(meta["encoder"], device=dev)
         model = _classes()[name](meta["net"]).to(dev).bind_encoder(enc)
         eng = model._engine()
         for step in range(1, 4):
-            loss = eng.train_step(coords, enc.B.contiguous(), gt, M.LossSpec(L.LOSS_L2_HALF))
+            loss = eng.train_step(coords, enc.B.contiguous(), gt, M.LossSpec(L.LOSS_L2_HALF), dist=dist)
             if step == 1 and wd_tag == "wd0":
                 torch.testing.assert_close(loss.cpu(), _t(arrs["loss"]), rtol=1e-5, atol=0)
             eng.adam_step(meta["lr"], 0.9, 0.999, 1e-8, wd)
@@ -107,6 +111,18 @@ def test_mfn_tier2_fused_golden(dev, name):
                     ref = _t(arrs[f"{wd_tag}/step{step}/" + k])
                     torch.testing.assert_close(v.cpu(), ref, rtol=1e-5, atol=2e-6,
                                                msg=lambda m: f"{wd_tag} step{step} {k}: {m}")
+
+
+def test_bounded_trajectory_golden(dev):
+    from inr_mi355x.train_kspace_multiscale import MultiscaleTrainer
+    arrs = _load("trajectory_ms.npz")
+    meta = json.load(open(os.path.join(GOLD, "trajectory_ms_meta.json")))
+    coords, image, dist = _t(arrs["coords"]), _t(arrs["image"]), _t(arrs["dist"])
+    cfg = meta["cases"]["Bounded_L2"]
+    tr = MultiscaleTrainer(cfg, image, coords, dist, meta["radii"], tuple(meta["shape"]), dev, seed=meta["seed"])
+    got = np.array([s[1] for s in tr.fit(meta["steps"], log_every=1)])
+    np.testing.assert_allclose(got, arrs["Bounded_L2/losses"], rtol=5e-4)
+    torch.testing.assert_close(tr.predict_all().cpu(), _t(arrs["Bounded_L2/final_out"]), rtol=2e-3, atol=5e-5)
 
 
 def test_multiscale_trajectory_golden(dev):
