@@ -163,6 +163,19 @@ int inr_backward(const inr_plan* plan, const float* params, const float* packed,
 int inr_loss_grad(const inr_loss_desc* loss, const float* out, const float* gt, const float* kcoords,
                   const uint8_t* mask, int64_t B, float* loss_out, float* dout, void* stream);
 
+/* Replaces tv_loss (metrics/losses.py:326-343) + its autograd on one coil's predicted k-space
+ * (train.py:173-175, train_kspace_multiscale.py:173-175; per-coil batches from
+ * MRICoilWrapperDataset, data/nerp_datasets.py:397-441):
+ *   weight * ( mean|img[:, :-1] - img[:, 1:]| + mean|img[:-1] - img[1:]| ),  img [H][W][2].
+ * `out` [R][W][2] holds R consecutive image rows of which the first R_own belong to the caller;
+ * a data-parallel rank passes its rows plus one halo row (R = R_own + 1) so that every vertical
+ * pair is counted by exactly one rank, and the single-GPU call passes R = R_own = H.  The means
+ * are over the whole image (H), so per-rank losses and gradients sum to the reference's.
+ * ADDS the gradient into dout [R][W][2] and the loss into loss_out[0]; loss_out[1..64] is scratch
+ * (same layout as inr_loss_grad, which is normally called first on the same buffers). */
+int inr_tv_grad(const float* out, int64_t R, int64_t R_own, int64_t W, int64_t H, float weight,
+                float* loss_out, float* dout, void* stream);
+
 /* Fused tier-2 step, stages 1-3 of train.py:163-189 in one launch: encode -> forward -> pointwise
  * loss -> backward, then the fixed-order slab reduction.  Leaves grads [P] and loss_out[0];
  * the caller all-reduces grads across ranks (if any) and calls inr_adam_step.  `grads` may be

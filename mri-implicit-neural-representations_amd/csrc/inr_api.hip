@@ -462,6 +462,19 @@ int inr_loss_grad(const inr_loss_desc* loss, const float* out, const float* gt, 
   return INR_OK;
 }
 
+int inr_tv_grad(const float* out, int64_t R, int64_t R_own, int64_t W, int64_t H, float weight,
+                float* loss_out, float* dout, void* stream) {
+  if (out == nullptr || loss_out == nullptr || dout == nullptr) return fail(INR_ERR_INVALID, "inr_tv_grad: null argument");
+  if (R <= 0 || R_own <= 0 || R_own > R || R > R_own + 1 || W < 2 || H < 2 || R > H)
+    return fail(INR_ERR_INVALID, "inr_tv_grad: R %lld R_own %lld W %lld H %lld", (long long)R, (long long)R_own,
+                (long long)W, (long long)H);
+  const float cw = (float)((double)weight / ((double)H * (double)(W - 1) * 2.0));
+  const float ch = (float)((double)weight / ((double)(H - 1) * (double)W * 2.0));
+  hipError_t e = inr::launch_tv_grad(out, R, R_own, W, cw, ch, loss_out, dout, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "inr_tv_grad");
+  return INR_OK;
+}
+
 int inr_train_step(const inr_plan* plan, const inr_loss_desc* loss, const float* params, const float* packed,
                    const float* x, const float* enc_B, const float* gt, const uint8_t* mask, int64_t B,
                    float* save, float* slabs, float* grads, float* loss_out, void* stream) {

@@ -25,6 +25,8 @@ hipError_t launch_encode_gauss(const float* coords, const float* encB, long long
                                hipStream_t st);
 hipError_t launch_loss_grad(const LossDesc& ld, const float* out, const float* gt, const float* kcoords,
                             const uint8_t* mask, long long B, float* loss_out, float* dout, hipStream_t st);
+hipError_t launch_tv_grad(const float* out, long long R, long long R_own, long long W, float cw, float ch,
+                          float* loss_out, float* dout, hipStream_t st);
 
 // per-NB dispatchers (one translation unit each): mode 0 fwd, 1 bwd, 2 fused
 hipError_t launch_mlp_nb1(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int mode, int grid, hipStream_t st);

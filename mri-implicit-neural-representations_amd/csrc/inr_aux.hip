@@ -332,4 +332,68 @@ hipError_t launch_loss_grad(const LossDesc& ld_in, const float* out, const float
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Total-variation regulariser on one coil's predicted k-space image (metrics/losses.py tv_loss;
+// train.py:172-175):  w * ( mean|img[:, :-1] - img[:, 1:]| + mean|img[:-1] - img[1:]| ) over
+// img [H][W][2].  `out` holds rows [y0, y0 + R) of the image; the first R_own rows are this
+// caller's (a trailing halo row lets the vertical pair (y0+R_own-1, y0+R_own) be evaluated by the
+// rank that owns its upper row).  Gather form: every element sums the sign terms of the <= 4 pairs
+// it belongs to, so there are no atomics and the result is deterministic.  Adds into dout and
+// loss_out[0].
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sgn(float d) { return d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f); }
+
+__global__ __launch_bounds__(256) void tv_grad_kernel(const float* __restrict__ out, long long R, long long R_own,
+                                                      long long W, float cw, float ch,
+                                                      float* __restrict__ loss_out, float* __restrict__ dout) {
+  __shared__ float red[256];
+  const long long n = R * W * 2;
+  const long long per = (n + LOSS_BLOCKS - 1) / LOSS_BLOCKS;
+  const long long lo = (long long)blockIdx.x * per;
+  const long long hi = lo + per < n ? lo + per : n;
+  const long long rs = W * 2;  // row stride
+  float acc = 0.f;
+  for (long long i = lo + threadIdx.x; i < hi; i += 256) {
+    const long long r = i / rs;
+    const long long x = (i - r * rs) >> 1;
+    const float v = out[i];
+    float g = 0.f;
+    if (r < R_own) {
+      if (x + 1 < W) {
+        const float d = v - out[i + 2];
+        acc += fabsf(d) * cw;
+        g += cw * sgn(d);
+      }
+      if (x > 0) g -= cw * sgn(out[i - 2] - v);
+      if (r + 1 < R) {
+        const float d = v - out[i + rs];
+        acc += fabsf(d) * ch;
+        g += ch * sgn(d);
+      }
+    }
+    if (r > 0 && r - 1 < R_own) g -= ch * sgn(out[i - rs] - v);
+    dout[i] += g;
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s >= 1; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss_out[1 + blockIdx.x] = red[0];
+}
+
+__global__ void loss_fold_add_kernel(float* loss_out) {
+  float s = 0.f;
+  for (int b = 0; b < LOSS_BLOCKS; ++b) s += loss_out[1 + b];
+  loss_out[0] += s;
+}
+
+hipError_t launch_tv_grad(const float* out, long long R, long long R_own, long long W, float cw, float ch,
+                          float* loss_out, float* dout, hipStream_t st) {
+  hipLaunchKernelGGL(tv_grad_kernel, dim3(LOSS_BLOCKS), dim3(256), 0, st, out, R, R_own, W, cw, ch, loss_out, dout);
+  hipLaunchKernelGGL(loss_fold_add_kernel, dim3(1), dim3(1), 0, st, loss_out);
+  return hipGetLastError();
+}
+
 }  // namespace inr

@@ -160,6 +160,17 @@ class MLPEngine:
                                        _ptr(dout, "dout"), self._stream()))
         return self._loss[0], dout
 
+    def tv_grad(self, out: torch.Tensor, dout: torch.Tensor, rows_own: int, W: int, H: int,
+                weight: float = 1e-4):
+        """tv_loss (losses.py:326-343) on out [R*W,2] = R image rows of width W (first rows_own owned,
+        see inr_tv_grad): adds its gradient into dout and its value into the loss scalar of the
+        preceding loss_grad call.  Returns the loss scalar (device)."""
+        R = out.shape[0] // W
+        assert R * W == out.shape[0] and out.shape[1] == 2 and dout.shape == out.shape
+        L.check(self.lib.inr_tv_grad(_ptr(out, "out"), R, rows_own, W, H, C.c_float(weight),
+                                     _ptr(self._loss, "loss"), _ptr(dout, "dout"), self._stream()))
+        return self._loss[0]
+
     def train_step(self, x: torch.Tensor, enc_B: Optional[torch.Tensor], gt: torch.Tensor, spec: LossSpec,
                    count: Optional[int] = None, mask: Optional[torch.Tensor] = None, hdr_A: float = 0.0):
         """Fused encode -> forward -> loss -> backward (stages of train.py:163-189).  Leaves the

@@ -29,6 +29,7 @@ from .engine import LossSpec
 from .evalchain import psnr, reconstruct
 from .networks import FFN, SIREN, WIRE, Positional_Encoder
 from .synthetic import make_kspace
+from .undersampling import Undersampler, parse_undersampling_argument
 
 MODELS = {"SIREN": SIREN, "FFN": FFN, "WIRE": WIRE}
 
@@ -80,7 +81,7 @@ def allreduce_step_outputs(grads: torch.Tensor, loss: torch.Tensor, world: int, 
 class INRTrainer:
     def __init__(self, config: dict, image: torch.Tensor, coords: torch.Tensor, shape, device,
                  seed: int = 0, mask: Optional[torch.Tensor] = None, rank: int = 0, world: int = 1,
-                 process_group=None):
+                 process_group=None, mask_seed: Optional[int] = None):
         config = set_default_configs(dict(config))
         self.config = config
         self.device = torch.device(device)
@@ -107,13 +108,28 @@ class INRTrainer:
         self.l2 = float(reg["strenght"]) if reg["type"] == "L2" else 0.0
         if reg["type"] not in ("none", "L1", "L2"):
             raise NotImplementedError(f"regularization {reg['type']!r}")
+        # undersampled fit (models/utils.py:102-123): train on the zero-filled k-space with the loss on
+        # sampled rows only; validation still compares with the full k-space (val_loader, utils.py:131-137)
+        self.image_full = image.to(self.device).contiguous()
+        method, uparams = parse_undersampling_argument(config["undersampling"])
+        if mask is None and method is not None and method.lower() != "none":
+            C, H, W = shape[0], shape[1], shape[2]
+            us = Undersampler(method, seed=mask_seed)
+            masked, _, gm = us.apply(image.reshape(C, H, W, 2).cpu(), uparams)
+            image, mask = masked.reshape(-1, 2), gm[:, 0].contiguous()
         # data resident in HBM for the whole fit
         self.n = coords.shape[0]
         self.coords = coords.to(self.device).contiguous()
         self.image = image.to(self.device).contiguous()
         self.mask_cpu = mask
         self.mask = mask.to(torch.uint8).to(self.device).contiguous() if mask is not None else None
-        self.bs = int(config["batch_size"])
+        # per-coil batches (MRICoilWrapperDataset, nerp_datasets.py:397-441; loader batch_size 1 = one coil,
+        # models/utils.py:65-66) so that TV can see a whole coil grid
+        self.per_coil = bool(config["per_coil"])
+        self.bs = int(shape[1] * shape[2]) if self.per_coil else int(config["batch_size"])
+        self.use_tv = bool(config["use_tv"]) and self.mask is not None  # train.py:172-175: only inside the mask branch
+        if self.use_tv and not self.per_coil:
+            raise ValueError("use_tv needs per_coil batches: tv_loss views the batch as one [H,W,2] coil (train.py:175)")
         self.steps_per_epoch = math.ceil(self.n / self.bs)
         self.global_step = 0
         self._hdr_A = {}
@@ -143,15 +159,41 @@ class INRTrainer:
         else:
             count = hi - lo
         A = self._batch_hdr_A(it, lo, hi)
-        slo, shi = shard_rows(lo, hi, self.rank, self.world)
-        m = self.mask[slo:shi] if self.mask is not None else None
-        loss = self.engine.train_step(self._inputs(slo, shi), self.enc_B, self.image[slo:shi], self.loss,
-                                      count=count, mask=m, hdr_A=A)
+        if self.use_tv:
+            loss = self._tv_step(lo, count, A)
+        else:
+            slo, shi = shard_rows(lo, hi, self.rank, self.world)
+            m = self.mask[slo:shi] if self.mask is not None else None
+            loss = self._fused(slo, shi, count, m, A)
         loss = allreduce_step_outputs(self.engine.grads, loss, self.world, self.pg)
         lr = self.config["lr"] * lr_factor(epoch, self.config["max_epoch"])
         self.engine.adam_step(lr, self.config["beta1"], self.config["beta2"], 1e-8, self.config["weight_decay"],
                               self.l1, self.l2)
         self.global_step += 1
+        return loss
+
+    def _fused(self, slo, shi, count, m, A):
+        return self.engine.train_step(self._inputs(slo, shi), self.enc_B, self.image[slo:shi], self.loss,
+                                      count=count, mask=m, hdr_A=A)
+
+    def _tv_step(self, lo: int, count: int, A: float) -> torch.Tensor:
+        """Per-coil step with total variation (train.py:163-189 with use_tv): forward (stashing) ->
+        masked pointwise loss -> TV added on the whole coil grid -> backward.  Data parallel: image rows
+        are split over ranks; each rank also evaluates one halo row below its slab so that every vertical
+        TV pair is owned by exactly one rank (the halo row's pointwise loss stays with its owner)."""
+        H, W = int(self.shape[1]), int(self.shape[2])
+        y0, y1 = shard_rows(0, H, self.rank, self.world)
+        if y1 == y0:  # more ranks than image rows: nothing to contribute
+            self.engine.grads.zero_()
+            return torch.zeros((), device=self.device)
+        ye = min(y1 + 1, H)
+        slo, sown, shi = lo + y0 * W, lo + y1 * W, lo + ye * W
+        out = self.engine.forward(self._inputs(slo, shi), self.enc_B, save=True)
+        m = self.mask[slo:shi].clone()
+        m[sown - slo:] = 0
+        loss, dout = self.engine.loss_grad(self.loss, out, self.image[slo:shi], count, mask=m, hdr_A=A)
+        loss = self.engine.tv_grad(out, dout, y1 - y0, W, H)
+        self.engine.backward(self._inputs(slo, shi), self.enc_B, dout)
         return loss
 
     def fit(self, max_steps: Optional[int] = None, log_every: int = 0):
@@ -178,7 +220,7 @@ class INRTrainer:
     @torch.no_grad()
     def evaluate(self) -> float:
         in_image_space = bool(self.config.get("transform", False))
-        ref = reconstruct(self.image, self.shape, in_image_space)
+        ref = reconstruct(self.image_full, self.shape, in_image_space)
         rec = reconstruct(self.predict_all(), self.shape, in_image_space)
         return float(psnr(ref, rec))
 

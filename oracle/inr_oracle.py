@@ -673,11 +673,14 @@ def _batches(n: int, bs: int):
 
 
 def train_single_scale(config: dict, sd, enc_B, coords: Tensor, image: Tensor, max_steps: int,
-                       mask: Optional[Tensor] = None, record=None):
+                       mask: Optional[Tensor] = None, record=None, grid_hw=None):
     """The per-step loop of train.py:158-192 on pre-built tensors (the DataLoader contract of
     SURVEY 3.1: batch i = rows [i*bs,(i+1)*bs) of the C-major flattened grid).  Mutates ``sd``.
     ``mask`` [N] bool = undersampling mask (forward on all rows, loss on masked rows,
-    train.py:172-177).  Returns the list of per-step loss values."""
+    train.py:172-177).  ``config['per_coil']`` with ``grid_hw=(H, W)``: one coil per step
+    (MRICoilWrapperDataset, nerp_datasets.py:397-441; loader batch_size 1, models/utils.py:65-66),
+    plus tv_loss on the coil grid when ``config['use_tv']`` and a mask is given (train.py:173-175).
+    Returns the list of per-step loss values."""
     model = config["model"]
     net = config["net"]
     keys = trainable_keys(model, sd)
@@ -686,6 +689,8 @@ def train_single_scale(config: dict, sd, enc_B, coords: Tensor, image: Tensor, m
     loss_fn = make_loss(config)
     reg = config.get("regularization", {"type": "none"})
     n, bs = coords.shape[0], config["batch_size"]
+    if config.get("per_coil", False):
+        bs = grid_hw[0] * grid_hw[1]
     losses, step = [], 0
     for epoch in range(config["max_epoch"]):  # train.py:155 / train_kspace_multiscale.py:161
         if step >= max_steps:
@@ -697,10 +702,15 @@ def train_single_scale(config: dict, sd, enc_B, coords: Tensor, image: Tensor, m
             kc, gt = coords[lo:hi], image[lo:hi]
             x = encode(kc, enc_B, config["encoder"]["embedding"])
             out = model_forward(model, sd, x, net)
+            tv = None
             if mask is not None:
+                if config.get("use_tv", False):
+                    tv = loss_tv(out.view(grid_hw[0], grid_hw[1], 2))
                 m = mask[lo:hi]
                 out, gt = out[m], gt[m]
             loss = loss_fn(out, gt, kc)
+            if tv is not None:
+                loss = tv + loss
             if reg["type"] == "L1":
                 loss = loss + reg_l1(list(params.values()), reg["strenght"])
             elif reg["type"] == "L2":
@@ -741,6 +751,8 @@ def train_multiscale(config: dict, sd, enc_B, coords: Tensor, image: Tensor, dis
     opts = config.get("loss_opts", {})
     kind = config["loss"]
     n, bs = coords.shape[0], config["batch_size"]
+    if config.get("per_coil", False):
+        bs = grid_hw[0] * grid_hw[1]
     losses, step = [], 0
     for epoch in range(config["max_epoch"]):  # train.py:155 / train_kspace_multiscale.py:161
         if step >= max_steps:

@@ -129,3 +129,60 @@ def test_synthetic_kspace_contract():
     k = O.complex_abs(image.reshape(3, 32, 24, 2))[0]
     py, px = np.unravel_index(int(k.argmax()), k.shape)
     assert abs(py - 16) <= 3 and abs(px - 12) <= 3
+
+
+# ---- undersampling masks (undersampling/undersampler.py) vs vectors made by the reference ------------
+def _us_gold():
+    g = dict(np.load(os.path.join(GOLD, "undersampling.npz")))
+    meta = json.load(open(os.path.join(GOLD, "undersampling_meta.json")))
+    return g, meta
+
+
+def test_radial_mask_matches_reference():
+    from inr_mi355x import undersampling as U
+    g, meta = _us_gold()
+    for key, (H, W, acc) in {"radial_640x368_acc4": (640, 368, 4), "radial_65x48_acc2": (65, 48, 2)}.items():
+        ref = np.unpackbits(g[key])[:H * W].reshape(H, W).astype(bool)
+        got = U.radial_mask(H, W, acc, t=meta["radial_t"])
+        assert np.array_equal(got.numpy(), ref), key
+        assert np.array_equal(U.radial_mask(H, W, acc, seed=meta["radial_seed"]).numpy(), ref), key
+    m = U.radial_mask(640, 368, 4, t=meta["radial_t"])
+    assert 3.5 < U.acceleration_factor(m) < 4.5
+
+
+def test_grid_apply_matches_reference():
+    from inr_mi355x import undersampling as U
+    from inr_mi355x.synthetic import create_coords
+    g, meta = _us_gold()
+    C, H, W = meta["shape"]
+    k = torch.from_numpy(g["grid_masked"])
+    us = U.Undersampler("grid")
+    masked, grid, gm = us.apply(k, meta["grid"])  # masking twice is idempotent
+    assert torch.equal(masked, k)
+    assert torch.equal(grid, torch.from_numpy(g["grid_coords"]))
+    assert np.array_equal(gm.numpy(), g["grid_mask"])
+    assert int(us.mask_image.sum()) == len(range(0, H, meta["grid"][0])) * len(range(0, W, meta["grid"][1]))
+    assert torch.equal(grid, create_coords(C, H, W))
+
+
+def test_random_line_and_argument_grammar():
+    from inr_mi355x import undersampling as U
+    assert U.parse_undersampling_argument(None) == (None, [])
+    assert U.parse_undersampling_argument("none") == ("none", [])
+    assert U.parse_undersampling_argument("grid-3*2") == ("grid", [3, 2])
+    assert U.parse_undersampling_argument("random_line-0.5") == ("random_line", [0.5])
+    assert U.parse_undersampling_argument("radial-4") == ("radial", [4])
+    with pytest.raises(AssertionError):
+        U.parse_undersampling_argument("grid-3")
+    with pytest.raises(AssertionError):
+        U.Undersampler("spiral")
+    # rows drawn before columns from torch's global RNG, as the reference does (undersampler.py:100-101)
+    torch.manual_seed(3)
+    m = U.random_line_mask(12, 9, 0.5)
+    torch.manual_seed(3)
+    rows, cols = torch.rand(12) <= 0.5, torch.rand(9) <= 0.5
+    ref = torch.zeros(12, 9, dtype=torch.bool)
+    ref[rows, :] = True
+    ref[:, cols] = True
+    assert torch.equal(m, ref)
+    assert U.random_line_mask(8, 8, 1.0).all()

@@ -224,6 +224,25 @@ def test_trajectories_golden(golden_dir):
                                    msg=lambda m: f"{tag}: {m}")
 
 
+def test_percoil_tv_trajectory_golden(golden_dir):
+    """Per-coil batches + grid undersampling + tv_loss (train.py:172-177 with use_tv), reference-driven."""
+    arrs = _load(golden_dir, "undersampling.npz")
+    meta = json.load(open(os.path.join(golden_dir, "undersampling_meta.json")))
+    cfg = meta["config"]
+    C, H, W = meta["shape"]
+    coords, image = _t(arrs["grid_coords"]), _t(arrs["grid_masked"]).reshape(-1, 2)
+    mask = _t(arrs["grid_mask"])[:, 0]
+    torch.manual_seed(meta["seed"])
+    B = O.encoder_init(cfg["encoder"])
+    sd = O.init_model(cfg["model"], cfg["net"])
+    losses = O.train_single_scale(cfg, sd, B, coords, image, 10 ** 6, mask=mask, grid_hw=(H, W))
+    assert len(losses) == cfg["max_epoch"] * C
+    np.testing.assert_allclose(np.array(losses), arrs["percoil_tv/losses"], rtol=2e-5)
+    with torch.no_grad():
+        out = O.model_forward(cfg["model"], sd, O.encode(coords, B, "gauss"), cfg["net"])
+    torch.testing.assert_close(out, _t(arrs["percoil_tv/final_out"]), rtol=1e-3, atol=2e-5)
+
+
 def test_multiscale_trajectories_golden(golden_dir):
     arrs = _load(golden_dir, "trajectory_ms.npz")
     meta = json.load(open(os.path.join(golden_dir, "trajectory_ms_meta.json")))

@@ -411,8 +411,75 @@ def multiscale_trajectory():
         json.dump({"shape": [C, H, W], "cases": cases, "seed": 4, "steps": 8, "radii": radii}, f, indent=1, sort_keys=True)
 
 
+def undersampling_vectors():
+    """Masks from the reference's Undersampler (undersampling/undersampler.py) and a per-coil + TV
+    trajectory (train.py:158-192 with len(mask_coords) != 0 and use_tv)."""
+    from torch.optim.lr_scheduler import LambdaLR
+    from undersampling.undersampler import Undersampler
+    cwd = os.getcwd()
+    os.chdir("/tmp")  # the reference saves undersampling_mask.png into the cwd
+    try:
+        arrs = {}
+        # radial, BASELINE shape, acc 4: the reference draws t from an UNSEEDED RandomState
+        # (undersampler.py:115,123); pin it by handing it a seeded one
+        real_rs = np.random.RandomState
+        np.random.RandomState = lambda *a, **k: real_rs(11)
+        try:
+            u = Undersampler("radial")
+            quiet(u.create_mask_for_radial_based_undersampling, (15, 640, 368, 2), 4, False)
+            m = u._Undersampler__mask_image
+            arrs["radial_640x368_acc4"] = np.packbits(m.numpy().astype(np.uint8))
+            t = real_rs(11).randint(low=0, high=1e4, size=1, dtype=int).item()
+            u2 = Undersampler("radial")
+            quiet(u2.create_mask_for_radial_based_undersampling, (3, 65, 48, 2), 2, False)  # odd side: pad path
+            arrs["radial_65x48_acc2"] = np.packbits(u2._Undersampler__mask_image.numpy().astype(np.uint8))
+        finally:
+            np.random.RandomState = real_rs
+        # grid 3x2 through apply(): masked data, grid and the [N,3] bool coordinate mask
+        C, H, W = 2, 24, 20
+        k = synth_kspace(C, H, W, 8)
+        masked, grid, grid_mask = quiet(Undersampler("grid").apply, k, [3, 2])
+        arrs["grid_full"], arrs["grid_masked"], arrs["grid_coords"] = npy(k), npy(masked), npy(grid)
+        arrs["grid_mask"] = grid_mask.numpy()
+        # per-coil + TV trajectory: one step = one coil (MRICoilWrapperDataset, nerp_datasets.py:397-441)
+        cfg = dict(model="SIREN", loss="L2", lr=2e-4, batch_size=H * W, max_epoch=4, weight_decay=0.0, beta1=0.9,
+                   beta2=0.999, per_coil=True, use_tv=True, undersampling="grid-3*2",
+                   net=dict(network_input_size=16, network_output_size=2, network_depth=4, network_width=32),
+                   encoder=dict(embedding="gauss", scale=2, embedding_size=8, coordinates_size=3))
+        torch.manual_seed(5)
+        encoder = Positional_Encoder(cfg["encoder"], device="cpu")
+        model = quiet(SIREN, cfg["net"])
+        optim = torch.optim.Adam(model.parameters(), lr=cfg["lr"], betas=(0.9, 0.999), weight_decay=0.0)
+        sched = LambdaLR(optim, lambda x: 0.2 ** min(x / cfg["max_epoch"], 1))
+        image = masked.reshape(C * H * W, 2)
+        losses = []
+        for epoch in range(cfg["max_epoch"]):
+            for c in range(C):
+                sl = slice(c * H * W, (c + 1) * H * W)
+                coords, gt, mask_coords = grid[sl], image[sl], grid_mask[sl]
+                out = model(encoder.embedding(coords))
+                optim.zero_grad()
+                loss = tv_loss(out.view((H, W, 2)))
+                out_m, gt_m = out[mask_coords[:, 0]], gt[mask_coords[:, 0]]
+                loss = loss + 0.5 * torch.nn.functional.mse_loss(out_m, gt_m)
+                loss.backward()
+                optim.step()
+                losses.append(float(loss.detach()))
+            sched.step()
+        arrs["percoil_tv/losses"] = np.array(losses, dtype=np.float64)
+        with torch.no_grad():
+            arrs["percoil_tv/final_out"] = npy(model(encoder.embedding(grid)))
+        np.savez_compressed(os.path.join(OUT, "undersampling.npz"), **arrs)
+        with open(os.path.join(OUT, "undersampling_meta.json"), "w") as f:
+            json.dump({"radial_seed": 11, "radial_t": t, "shape": [C, H, W], "grid": [3, 2], "config": cfg, "seed": 5},
+                      f, indent=1, sort_keys=True)
+    finally:
+        os.chdir(cwd)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    undersampling_vectors()
     init_hashes()
     model_vectors()
     loss_vectors()
