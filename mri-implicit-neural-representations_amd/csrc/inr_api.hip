@@ -29,6 +29,13 @@ int hip_fail(hipError_t e, const char* what) {
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
+// smallest built block count that holds `need` 32-row blocks (narrower nets run zero-padded), or -1
+inline int pick_nb(int need, std::initializer_list<int> built) {
+  for (int nb : built)
+    if (nb >= need) return nb;
+  return -1;
+}
+
 constexpr int kMaxBlocks = 256;  // one persistent workgroup per CU (MI355X: 256 CUs)
 
 #ifdef INR_STAMPS
@@ -50,8 +57,9 @@ static int create_mfn_plan(const inr_net_desc* d, inr_plan** out) {
   const int n = d->depth, W = d->width;
   if (n < 1 || 2 * n + 1 + (multi ? n + 1 : 1) > INR_MAX_LAYERS)
     return fail(INR_ERR_INVALID, "inr_plan_create: MFN depth %d", n);
-  if (W != 32 && W != 256 && W != 512)
-    return fail(INR_ERR_UNSUPPORTED, "inr_plan_create: MFN width %d (kernels are built for 32, 256 and 512)", W);
+  const int NB = W < 1 ? -1 : pick_nb((W + 31) / 32, {1, 4, 8, 16});
+  if (NB < 0)
+    return fail(INR_ERR_UNSUPPORTED, "inr_plan_create: MFN width %d (kernels are built for widths 1..512)", W);
   if (d->input != INR_INPUT_GAUSS || d->enc_size < 8 || (d->enc_size % 8) != 0 || d->in_features != 2 * d->enc_size)
     return fail(INR_ERR_UNSUPPORTED, "inr_plan_create: MFN kernels need the fused gauss encoder (in_features == 2*enc_size, "
                 "enc_size %% 8 == 0)");
@@ -62,7 +70,6 @@ static int create_mfn_plan(const inr_net_desc* d, inr_plan** out) {
   p->desc = *d;
   NetDesc& nd = p->nd;
   memset(&nd, 0, sizeof(nd));
-  const int NB = W / 32;
   nd.NB = NB;
   nd.NW = NB == 16 ? 2 : 4;
   nd.hact = ACT_SIN;
@@ -100,8 +107,8 @@ static int create_mfn_plan(const inr_net_desc* d, inr_plan** out) {
     L.K = K;
     L.M = M;
     L.Kpad8 = filter ? round_up(K, 8) : NB * 32;
-    L.Kblk = (K + 31) / 32;
-    L.Mblk = (M + 31) / 32;
+    L.Kblk = filter ? (K + 31) / 32 : NB;  // hidden images always span all NB blocks (zero padding)
+    L.Mblk = head ? (M + 31) / 32 : NB;
     L.Mpad8 = head ? round_up(M, 8) : NB * 32;
     L.ltype = LT_REAL;
     L.wn = M * K;
@@ -198,21 +205,21 @@ int inr_plan_create(const inr_net_desc* d, inr_plan** out) {
   if (d->width < 1) return fail(INR_ERR_INVALID, "inr_plan_create: width %d", d->width);
   // rows of the hidden activations as the kernel sees them: complex features are (Re, Im) row pairs
   const int hid = wire ? 2 * d->width : d->width;
-  const int NB = (hid + 31) / 32;
+  const int need = (hid + 31) / 32;
+  const int NB = wire ? pick_nb(need, {2, 4, 8, 12}) : pick_nb(need, {1, 2, 4, 8, 16});
   int NW;
   if (wire) {
-    if (NB <= 2) NW = 4;
-    else if (NB == 12) NW = 3;
-    else
+    if (NB < 0)
       return fail(INR_ERR_UNSUPPORTED, "inr_plan_create: WIRE with %d complex hidden features (kernels are built for "
-                  "<= 32 and for 181 = int(256/sqrt 2))", d->width);
+                  "up to 192 = 384 interleaved rows; network_width 256 gives 181)", d->width);
+    NW = NB == 12 ? 3 : 4;
     if (d->input != INR_INPUT_X)
       return fail(INR_ERR_UNSUPPORTED, "inr_plan_create: WIRE takes raw coordinates (input must be INR_INPUT_X)");
     if (d->last_act != INR_ACT_ID) return fail(INR_ERR_INVALID, "inr_plan_create: WIRE's output is linear");
   } else {
-    if (d->width != 32 && d->width != 256)
-      return fail(INR_ERR_UNSUPPORTED, "inr_plan_create: width %d (kernels are built for 32 and 256)", d->width);
-    NW = 4;
+    if (NB < 0)
+      return fail(INR_ERR_UNSUPPORTED, "inr_plan_create: width %d (kernels are built for widths 1..512)", d->width);
+    NW = NB == 16 ? 2 : 4;
   }
   if (d->input == INR_INPUT_GAUSS) {
     if (d->enc_size < 8 || (d->enc_size % 8) != 0)
@@ -250,8 +257,8 @@ int inr_plan_create(const inr_net_desc* d, inr_plan** out) {
     L.M = last ? d->out_features : hid;
     // hidden-to-hidden products run over all NB*32 image rows (padding rows carry zero weights)
     L.Kpad8 = first ? round_up(L.K, 8) : NB * 32;
-    L.Kblk = (L.K + 31) / 32;
-    L.Mblk = (L.M + 31) / 32;
+    L.Kblk = first ? (L.K + 31) / 32 : NB;  // hidden images always span all NB blocks (zero padding)
+    L.Mblk = last ? (L.M + 31) / 32 : NB;
     L.Mpad8 = last ? round_up(L.M, 8) : NB * 32;
     if (!wire) {
       L.ltype = LT_REAL;
@@ -280,10 +287,12 @@ int inr_plan_create(const inr_net_desc* d, inr_plan** out) {
     poff += L.wn;
     L.b_off = poff;
     poff += L.bn;
+    // gradient slab: hidden layers keep all NB*32 rows (the dW pass stores whole row blocks without a
+    // bounds test; padding rows receive exact zeros and are never read back)
     L.gw_off = goff;
-    goff += L.M * L.K;
+    goff += (last ? L.M : NB * 32) * L.K;
     L.gb_off = goff;
-    goff += L.M;
+    goff += last ? L.M : NB * 32;
     L.pf_off = (int)pk;
     pk += (int64_t)L.Kpad8 * L.Mblk * 32;  // (Kpad8/8 groups) x Mblk x 64 lanes x 4
     if (l >= 1) {
@@ -339,14 +348,27 @@ static int launch(const inr_plan* plan, const LossDesc& ld, const inr::MlpArgs& 
   hipError_t e;
   const NetDesc& nd = plan->nd;
   if (nd.mfn_n > 0)
-    e = nd.NB == 1 ? inr::launch_mfn_nb1(nd, ld, a, mode, grid, st)
-                   : (nd.NB == 8 ? inr::launch_mfn_nb8(nd, ld, a, mode, grid, st) : inr::launch_mfn_nb16(nd, ld, a, mode, grid, st));
+    switch (nd.NB) {
+      case 1: e = inr::launch_mfn_nb1(nd, ld, a, mode, grid, st); break;
+      case 4: e = inr::launch_mfn_nb4(nd, ld, a, mode, grid, st); break;
+      case 8: e = inr::launch_mfn_nb8(nd, ld, a, mode, grid, st); break;
+      default: e = inr::launch_mfn_nb16(nd, ld, a, mode, grid, st); break;
+    }
   else if (nd.hact == ACT_GABOR)
-    e = nd.NB == 12 ? inr::launch_wire_nb12(nd, ld, a, mode, grid, st) : inr::launch_wire_nb2(nd, ld, a, mode, grid, st);
-  else if (nd.NB == 1)
-    e = inr::launch_mlp_nb1(nd, ld, a, mode, grid, st);
+    switch (nd.NB) {
+      case 2: e = inr::launch_wire_nb2(nd, ld, a, mode, grid, st); break;
+      case 4: e = inr::launch_wire_nb4(nd, ld, a, mode, grid, st); break;
+      case 8: e = inr::launch_wire_nb8(nd, ld, a, mode, grid, st); break;
+      default: e = inr::launch_wire_nb12(nd, ld, a, mode, grid, st); break;
+    }
   else
-    e = inr::launch_mlp_nb8(nd, ld, a, mode, grid, st);
+    switch (nd.NB) {
+      case 1: e = inr::launch_mlp_nb1(nd, ld, a, mode, grid, st); break;
+      case 2: e = inr::launch_mlp_nb2(nd, ld, a, mode, grid, st); break;
+      case 4: e = inr::launch_mlp_nb4(nd, ld, a, mode, grid, st); break;
+      case 8: e = inr::launch_mlp_nb8(nd, ld, a, mode, grid, st); break;
+      default: e = inr::launch_mlp_nb16(nd, ld, a, mode, grid, st); break;
+    }
   if (e != hipSuccess) return hip_fail(e, "inr mlp kernel launch");
   return INR_OK;
 }

@@ -38,7 +38,7 @@ __device__ __forceinline__ void stash_group(f32x16 (&acc)[NB], const f32x4 (&a_u
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int NB, int TL>
+template <int NB, int TL, int NBT = NB>
 __device__ __forceinline__ void gemm_enc_stash(f32x16 (&acc)[NB], const float* __restrict__ wp,
                                                const float* __restrict__ sv_enc, int E, int wcol, int lane) {
   const int half = lane >> 5;
@@ -53,8 +53,8 @@ __device__ __forceinline__ void gemm_enc_stash(f32x16 (&acc)[NB], const float* _
 #pragma unroll 1
   for (int s4 = 0; s4 < n4; s4 += 2) {
     const int n2 = (s4 + 2 < n4) ? (s4 + 2) : s4;
-    stash_group<NB, TL>(acc, A0, A1, p + (size_t)(s4 + 1) * NB * 64, B0, B1, svl + 4 * (s4 + 1) * TL);
-    stash_group<NB, TL>(acc, A1, A0, p + (size_t)n2 * NB * 64, B1, B0, svl + 4 * n2 * TL);
+    stash_group<NB, TL>(acc, A0, A1, p + (size_t)(s4 + 1) * NBT * 64, B0, B1, svl + 4 * (s4 + 1) * TL);
+    stash_group<NB, TL>(acc, A1, A0, p + (size_t)n2 * NBT * 64, B1, B0, svl + 4 * n2 * TL);
   }
 }
 
@@ -165,7 +165,7 @@ __device__ __forceinline__ void dwf_group(f32x16 (&acc)[MT], float (&bsum)[MT], 
 
 // rows [32*m0, 32*(m0+MT)) x column block n of dW = (G*fac)^T . B over the tile's TL coordinates
 template <int MT, int TL, bool BIAS, class BSrc>
-__device__ __forceinline__ void dwf_pass_impl(const float* Rall, int region_stride, const float* fac, BSrc& bsrc,
+__device__ __noinline__ void dwf_pass_impl(const float* Rall, int region_stride, const float* fac, BSrc& bsrc,
                                               int m0, int n, float* slab_w, float* slab_b, int M, int K, bool first,
                                               int lane) {
   const int half = lane >> 5, li = lane & 31;
@@ -265,8 +265,42 @@ __device__ __forceinline__ float mfn_loss_row(const LossDesc& ld, int n_heads, i
 }
 
 // ---------------------------------------------------------------------------------------------
+// Wide stages in register-sized chunks: the 16 row blocks of the 512-wide shape are accumulated 8 at a
+// time (the B operand is streamed twice), so a GEMM phase holds 256 accumulator + 64 A-fragment
+// registers instead of 256 + 128 and stays inside the 512-register file without scratch.
+// ---------------------------------------------------------------------------------------------
+template <int MT, int NB>
+__device__ __forceinline__ f32x16 (&chunk(f32x16 (&acc)[NB], int m0))[MT] {
+  return *reinterpret_cast<f32x16(*)[MT]>(&acc[m0]);
+}
+
+// acc += A[image at wpT] . (image R)  for all NB row blocks;  HASD: R <- R * sv_d in place on the way
+template <int NB, int TL, bool HASD>
+__device__ __forceinline__ void gemm_image(f32x16 (&acc)[NB], float* R, const float* __restrict__ wpT, int Kpad8,
+                                           const float* __restrict__ sv_d, int wcol, int lane) {
+  constexpr int MT = NB > 8 ? 8 : NB;
+  bwd_dx<MT, TL, false, HASD, NB>(chunk<MT, NB>(acc, 0), R, wpT, Kpad8, sv_d, wcol, lane);
+#pragma unroll
+  for (int m0 = MT; m0 < NB; m0 += MT)  // R already holds the products: plain second pass
+    bwd_dx<MT, TL, false, false, NB>(chunk<MT, NB>(acc, m0), R, wpT + (size_t)m0 * 256, Kpad8, nullptr, wcol, lane);
+}
+
+template <int NB, int TL>
+__device__ __forceinline__ void gemm_enc(f32x16 (&acc)[NB], const float* __restrict__ wp,
+                                         const float* __restrict__ sv_enc, int E, int wcol, int lane) {
+  constexpr int MT = NB > 8 ? 8 : NB;
+#pragma unroll
+  for (int m0 = 0; m0 < NB; m0 += MT)
+    gemm_enc_stash<MT, TL, NB>(chunk<MT, NB>(acc, m0), wp + (size_t)m0 * 256, sv_enc, E, wcol, lane);
+}
+
+// ---------------------------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------------------------
+// Head outputs y[k][o] and their gradients g[k][o] of a coordinate live in rows 8 + 4k + o of the wave's
+// head-gradient image (own column), not in registers: the head code then exists once, indexed by the
+// (wave-uniform) head number.  Rows >= 8 of that image are never consumed: the head dW pass keeps rows
+// < out_features only, and dX = W_head^T g contracts over rows 0..7.
 template <int NB, int NW, int MODE>
 __global__ __launch_bounds__(NW * 64) void inr_mfn_kernel(const NetDesc nd, const LossDesc ld, const MlpArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -303,12 +337,6 @@ __global__ __launch_bounds__(NW * 64) void inr_mfn_kernel(const NetDesc nd, cons
     float* sv_enc = sv + (size_t)3 * S * HSZ;
     float keep = 1.f;  // bounded linears: per-coordinate 0/1 (recomputed per stage)
     const float dist = (a.dist != nullptr && valid) ? a.dist[crow] : 0.f;
-    float y[INR_MAX_HEADS][4], g[INR_MAX_HEADS][4];
-#pragma unroll
-    for (int k = 0; k < INR_MAX_HEADS; ++k)
-#pragma unroll
-      for (int o = 0; o < 4; ++o) y[k][o] = g[k][o] = 0.f;
-
     // ================================ forward =================================
     if (MODE != MODE_BWD) {
       {
@@ -322,10 +350,16 @@ __global__ __launch_bounds__(NW * 64) void inr_mfn_kernel(const NetDesc nd, cons
           x2 = a.x[3 * crow + 2];
         }
         const float two_pi = 6.283185307179586f;
-        fwd_layer0_gauss<NB, TL, true>(acc, a.packed + Fl[0].pf_off, encB_lds, nd.E, two_pi * x0, two_pi * x1,
-                                       two_pi * x2, sv_enc, wcol, lane);
+        constexpr int MT = NB > 8 ? 8 : NB;
+        fwd_layer0_gauss<MT, TL, true, NB>(chunk<MT, NB>(acc, 0), a.packed + Fl[0].pf_off, encB_lds, nd.E, two_pi * x0,
+                                           two_pi * x1, two_pi * x2, sv_enc, wcol, lane);
+#pragma unroll
+        for (int m0 = MT; m0 < NB; m0 += MT)  // remaining row blocks: features come back from the stash just written
+          gemm_enc_stash<MT, TL, NB>(chunk<MT, NB>(acc, m0), a.packed + Fl[0].pf_off + (size_t)m0 * 256, sv_enc, nd.E,
+                                     wcol, lane);
         mfn_epilogue<NB, TL, true, true>(acc, R, a.packed + Fl[0].pbias_off, sv, wcol, lane);
       }
+#pragma unroll 1
       for (int i = 1; i < S; ++i) {
         f32x16 acc[NB];
 #pragma unroll
@@ -336,83 +370,93 @@ __global__ __launch_bounds__(NW * 64) void inr_mfn_kernel(const NetDesc nd, cons
             for (int r = half; r < NB * 32; r += 2) R[swz(r, col)] = 0.f;  // own column only
           }
         }
-        bwd_dx<NB, TL, false, false>(acc, R, a.packed + Ll[i - 1].pf_off, NB * 32, nullptr, wcol, lane);  // V = L h
+        gemm_image<NB, TL, false>(acc, R, a.packed + Ll[i - 1].pf_off, NB * 32, nullptr, wcol, lane);  // V = L h
         acc_to_lds<NB, true>(acc, R, a.packed + Ll[i - 1].pbias_off, lane);                               // park l
 #pragma unroll
         for (int m = 0; m < NB; ++m) acc[m] = zero16();
-        gemm_enc_stash<NB, TL>(acc, a.packed + Fl[i].pf_off, sv_enc, nd.E, wcol, lane);                   // U = F x
+        gemm_enc<NB, TL>(acc, a.packed + Fl[i].pf_off, sv_enc, nd.E, wcol, lane);                          // U = F x
         mfn_epilogue<NB, TL, false, true>(acc, R, a.packed + Fl[i].pbias_off, sv + (size_t)3 * i * HSZ, wcol, lane);
-        // heads fed by this stage (explicit instances: y[k] must keep compile-time indices)
-#define INR_HEAD_FWD(k)                                                                                        \
-  if ((k) < NH && nd.head_stage[k] == i) {                                                                     \
-    const LayerDesc& Hd = nd.L[nd.head_layer[k]];                                                              \
-    f32x16 accH[1];                                                                                            \
-    accH[0] = zero16();                                                                                        \
-    bwd_dx<1, TL, false, false>(accH, R, a.packed + Hd.pf_off, NB * 32, nullptr, wcol, lane);                  \
-    _Pragma("unroll") for (int o = 0; o < 4; ++o) {                                                            \
-      float z = accH[0][o];                                                                                    \
-      if (o < nd.out_f) z += a.packed[Hd.pbias_off + o];                                                       \
-      y[k][o] = z;                                                                                             \
-      if (half == 0 && valid && o < nd.out_f && a.out != nullptr)                                              \
-        a.out[((size_t)(k) * a.B + crow) * nd.out_f + o] = z;                                                  \
-    }                                                                                                          \
-  }
-        INR_HEAD_FWD(0)
-        INR_HEAD_FWD(1)
-        INR_HEAD_FWD(2)
-        INR_HEAD_FWD(3)
-#undef INR_HEAD_FWD
+        // head fed by this stage, if any (output_layers are distinct stages)
+        int kh = -1;
+        for (int k = 0; k < NH; ++k)
+          if (nd.head_stage[k] == i) kh = k;
+        if (kh >= 0) {
+          const LayerDesc& Hd = nd.L[nd.head_layer[kh]];
+          f32x16 accH[1];
+          accH[0] = zero16();
+          bwd_dx<1, TL, false, false>(accH, R, a.packed + Hd.pf_off, NB * 32, nullptr, wcol, lane);
+#pragma unroll
+          for (int o = 0; o < 4; ++o) {
+            float z = accH[0][o];  // half 0: rows 0..3 = output o
+            if (o < nd.out_f) z += a.packed[Hd.pbias_off + o];
+            if (half == 0) {
+              HG[swz(8 + 4 * kh + o, col)] = z;
+              if (valid && o < nd.out_f && a.out != nullptr) a.out[((size_t)kh * a.B + crow) * nd.out_f + o] = z;
+            }
+          }
+        }
       }
-      if (MODE == MODE_FUSED) {
-        if (half == 0 && valid && (a.mask == nullptr || a.mask[crow] != 0)) {
+      if (MODE == MODE_FUSED && half == 0) {
+        float y[INR_MAX_HEADS][4], g[INR_MAX_HEADS][4];
+#pragma unroll
+        for (int k = 0; k < INR_MAX_HEADS; ++k)
+#pragma unroll
+          for (int o = 0; o < 4; ++o) {
+            y[k][o] = k < NH ? HG[swz(8 + 4 * k + o, col)] : 0.f;
+            g[k][o] = 0.f;
+          }
+        if (valid && (a.mask == nullptr || a.mask[crow] != 0)) {
           float t[4] = {0.f, 0.f, 0.f, 0.f};
           for (int o = 0; o < nd.out_f; ++o) t[o] = a.gt[crow * nd.out_f + o];
           loss_acc += mfn_loss_row(ld, NH, nd.out_f, y, t, dist, g);
         }
+#pragma unroll
+        for (int k = 0; k < INR_MAX_HEADS; ++k)
+#pragma unroll
+          for (int o = 0; o < 4; ++o)
+            if (k < NH) HG[swz(8 + 4 * k + o, col)] = g[k][o];
       }
     }
 
     // ================================ backward ================================
     if (MODE != MODE_FWD) {
-      if (MODE == MODE_BWD) {
-#pragma unroll
-        for (int k = 0; k < INR_MAX_HEADS; ++k)
-#pragma unroll
-          for (int o = 0; o < 4; ++o)
-            if (k < NH && half == 0 && valid && o < nd.out_f) g[k][o] = a.dout[((size_t)k * a.B + crow) * nd.out_f + o];
-      }
       f32x16 gacc[NB];
 #pragma unroll
       for (int m = 0; m < NB; ++m) gacc[m] = zero16();
+#pragma unroll 1
       for (int i = S - 1; i >= 1; --i) {
         float* svi = sv + (size_t)3 * i * HSZ;
         // ---- heads fed by stage i: dW_head, and their contribution W_k^T g_k to g_h_i
-#define INR_HEAD_BWD(k)                                                                                        \
-  if ((k) < NH && nd.head_stage[k] == i) {                                                                     \
-    const LayerDesc& Hd = nd.L[nd.head_layer[k]];                                                              \
-    __syncthreads(); /* previous readers of the head-gradient images are done */                               \
-    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                           \
-      float v = 0.f;                                                                                           \
-      if (r < 4 && half == 0 && r < nd.out_f) v = g[k][r & 3];                                                 \
-      HG[swz(acc_row(r, half), col)] = v;                                                                      \
-    }                                                                                                          \
-    __syncthreads();                                                                                           \
-    {                                                                                                          \
-      BSrcStash<TL> bs{svi + (size_t)2 * HSZ}; /* h_i */                                                       \
-      for (int nn = w; nn < Hd.Kblk; nn += NW)                                                                 \
-        dw_pass<1, TL, false, BSrcStash<TL>>(HGall, HS, bs, nn, slab + Hd.gw_off, slab + Hd.gb_off, Hd.M, Hd.K, \
-                                             first, nn == 0, lane);                                            \
-    }                                                                                                          \
-    bwd_dx<NB, TL, false, false>(gacc, HG, a.packed + Hd.pb_off, Hd.Mpad8, nullptr, wcol, lane);               \
-  }
-        INR_HEAD_BWD(0)
-        INR_HEAD_BWD(1)
-        INR_HEAD_BWD(2)
-        INR_HEAD_BWD(3)
-#undef INR_HEAD_BWD
+        // ---- head fed by stage i (if any): its contribution W_k^T g_k to g_h_i now, its dW below, once the
+        //      accumulators are parked (a call with 16 live accumulator blocks would spill all of them)
+        int kh = -1;
+        for (int k = 0; k < NH; ++k)
+          if (nd.head_stage[k] == i) kh = k;
+        if (kh >= 0) {
+          const LayerDesc& Hd = nd.L[nd.head_layer[kh]];
+          float gv[4];
+#pragma unroll
+          for (int o = 0; o < 4; ++o) {
+            if (MODE == MODE_BWD)
+              gv[o] = (half == 0 && valid && o < nd.out_f) ? a.dout[((size_t)kh * a.B + crow) * nd.out_f + o] : 0.f;
+            else
+              gv[o] = (half == 0 && o < nd.out_f) ? HG[swz(8 + 4 * kh + o, col)] : 0.f;
+          }
+          __syncthreads();  // previous readers of the head-gradient images (the last head's dW) are done
+#pragma unroll
+          for (int o = 0; o < 4; ++o) HG[swz(o + 4 * half, col)] = gv[o];  // rows 0..3 = g, rows 4..7 = 0
+          gemm_image<NB, TL, false>(gacc, HG, a.packed + Hd.pb_off, Hd.Mpad8, nullptr, wcol, lane);  // own image only
+        }
         __syncthreads();  // readers of the main images (previous stage's dW / dX) are done
         acc_to_lds<NB, false>(gacc, R, nullptr, lane);  // image <- g_h_i
         __syncthreads();
+        if (kh >= 0) {
+          const LayerDesc& Hd = nd.L[nd.head_layer[kh]];
+          BSrcStash<TL> bs{svi + (size_t)2 * HSZ};  // h_i
+          for (int nn = w; nn < Hd.Kblk; nn += NW)
+            dw_pass<1, TL, false, BSrcStash<TL>>(HGall, HS, bs, nn, slab + Hd.gw_off, slab + Hd.gb_off, Hd.M, Hd.K,
+                                                 first, nn == 0, lane);
+        }
         // ---- dL_{i-1} = (g_h*f_i)^T h_{i-1} (+ db), dF_i = (g_h*l_i cos u_i)^T x (+ dc)
         {
           if (nd.bounded) {
@@ -430,7 +474,7 @@ __global__ __launch_bounds__(NW * 64) void inr_mfn_kernel(const NetDesc nd, cons
         // ---- g_h_{i-1} = L_{i-1}^T (g_h_i * f_i)   (in place on the image, which is dead afterwards)
 #pragma unroll
         for (int m = 0; m < NB; ++m) gacc[m] = zero16();
-        bwd_dx<NB, TL, false, true>(gacc, R, a.packed + Ll[i - 1].pb_off, NB * 32, svi, wcol, lane);
+        gemm_image<NB, TL, true>(gacc, R, a.packed + Ll[i - 1].pb_off, NB * 32, svi, wcol, lane);
         if (nd.bounded) {
           keep = (dist < nd.bound_lo[i - 1] || dist > nd.bound_hi[i - 1]) ? 0.f : 1.f;
 #pragma unroll

@@ -1,4 +1,5 @@
 // inr_mfn_inst.h -- instantiates the MFN kernel for one width (INR_NB blocks) / workgroup shape.
+#define INR_DW_ATTR __noinline__  // head dW passes as real functions, like dwf_pass_impl
 #include "inr_mfn_impl.h"
 #include "inr_aux.h"
 

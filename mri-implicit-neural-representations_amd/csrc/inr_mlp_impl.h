@@ -206,7 +206,9 @@ __device__ __forceinline__ void gauss_group(f32x16 (&acc)[NB], const f32x4 (&a_u
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int NB, int TL, bool SAVE>
+// NBT: row blocks of the whole packed image (stride between k-groups); NB of them, starting at the block
+// `wp` already points to, are accumulated (NBT > NB: wide layers done in register-sized chunks)
+template <int NB, int TL, bool SAVE, int NBT = NB>
 __device__ __forceinline__ void fwd_layer0_gauss(f32x16 (&acc)[NB], const float* __restrict__ wp,
                                                  const float* encB_lds, int E, float xs0, float xs1, float xs2,
                                                  float* __restrict__ sv_enc, int wcol, int lane) {
@@ -222,9 +224,9 @@ __device__ __forceinline__ void fwd_layer0_gauss(f32x16 (&acc)[NB], const float*
 #pragma unroll 1
   for (int s4 = 0; s4 < n4; s4 += 2) {
     const int n2 = (s4 + 2 < n4) ? (s4 + 2) : s4;
-    gauss_group<NB, TL, SAVE>(acc, A0, A1, p + (size_t)(s4 + 1) * NB * 64, encB_lds, s4 + 1, xs0, xs1, xs2, half, F0,
+    gauss_group<NB, TL, SAVE>(acc, A0, A1, p + (size_t)(s4 + 1) * NBT * 64, encB_lds, s4 + 1, xs0, xs1, xs2, half, F0,
                               F1, sve + 4 * s4 * TL);
-    gauss_group<NB, TL, SAVE>(acc, A1, A0, p + (size_t)n2 * NB * 64, encB_lds, n2, xs0, xs1, xs2, half, F1, F0,
+    gauss_group<NB, TL, SAVE>(acc, A1, A0, p + (size_t)n2 * NBT * 64, encB_lds, n2, xs0, xs1, xs2, half, F1, F0,
                               sve + 4 * (s4 + 1) * TL);
   }
 }
@@ -397,7 +399,7 @@ __device__ __forceinline__ void dx_group(f32x16 (&acc)[NB], const f32x4 (&a_use)
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int NB, int TL, bool PAIR, bool HASD>
+template <int NB, int TL, bool PAIR, bool HASD, int NBT = NB>
 __device__ __forceinline__ void bwd_dx(f32x16 (&acc)[NB], float* R, const float* __restrict__ wpT, int Mpad8,
                                        const float* __restrict__ sv_d, int wcol, int lane) {
   const int half = lane >> 5, col = lane & 31;
@@ -422,9 +424,9 @@ __device__ __forceinline__ void bwd_dx(f32x16 (&acc)[NB], float* R, const float*
 #pragma unroll 1
   for (int s4 = 0; s4 < n4; s4 += 2) {  // n4 even for hidden layers
     const int n2 = (s4 + 2 < n4) ? (s4 + 2) : s4;
-    dx_group<NB, TL, PAIR, HASD>(acc, A0, A1, p + (size_t)(s4 + 1) * NB * 64, G0, P0, G1, P1, D0, E0, D1, E1, Rcol, s4,
+    dx_group<NB, TL, PAIR, HASD>(acc, A0, A1, p + (size_t)(s4 + 1) * NBT * 64, G0, P0, G1, P1, D0, E0, D1, E1, Rcol, s4,
                                  s4 + 1, dl, hsz, half, true);
-    dx_group<NB, TL, PAIR, HASD>(acc, A1, A0, p + (size_t)n2 * NB * 64, G1, P1, G0, P0, D1, E1, D0, E0, Rcol, s4 + 1,
+    dx_group<NB, TL, PAIR, HASD>(acc, A1, A0, p + (size_t)n2 * NBT * 64, G1, P1, G0, P0, D1, E1, D0, E0, Rcol, s4 + 1,
                                  n2, dl, hsz, half, true);
   }
 }
@@ -503,8 +505,15 @@ __device__ __forceinline__ void dw_group(f32x16 (&acc)[MT], float (&bsum)[MT], c
   __builtin_amdgcn_sched_barrier(0);
 }
 
+// INR_DW_ATTR: a translation unit whose kernels are register-bound (WIRE, MFN) compiles the pass as a real
+// function: it is self-contained (operands from LDS / the stash, results to the slab), so a call costs
+// nothing measurable and keeps the pass's ~200 registers and its hoisted addresses out of the
+// allocation of the surrounding kernel.
+#ifndef INR_DW_ATTR
+#define INR_DW_ATTR __forceinline__
+#endif
 template <int MT, int TL, bool FULLM, bool BIAS, class BSrc>
-__device__ __forceinline__ void dw_pass_impl(const float* Rall, int region_stride, BSrc& bsrc, int n, float* slab_w,
+__device__ INR_DW_ATTR void dw_pass_impl(const float* Rall, int region_stride, BSrc& bsrc, int n, float* slab_w,
                                              float* slab_b, int M, int K, bool first, int lane) {
   const int half = lane >> 5, li = lane & 31;
   f32x16 acc[MT];
@@ -621,7 +630,7 @@ __global__ __launch_bounds__(NW * 64) void inr_mlp_kernel(const NetDesc nd, cons
   const LayerDesc& LL = nd.L[D - 1];
   // hidden rows == NB*32 except for WIRE's 181 complex features (362 rows padded to 384); the plan
   // only pairs NB == 12 with that width (inr_api.hip)
-  constexpr bool HFULL = !(PAIR && NB == 12);
+  constexpr bool HFULL = true;  // hidden-layer slabs span all NB*32 rows (inr_plan_create)
 
   for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
     const long long row0 = (long long)tile * TL;

@@ -1,6 +1,9 @@
 // inr_mlp_inst.h -- instantiates the fused MLP kernel for one hidden block count (INR_NB blocks of
 // 32 rows), one workgroup shape (INR_NW waves) and one family, and exposes a mode / input
 // dispatcher.  Included by inr_mlp_nb*.hip / inr_wire_nb*.hip (one translation unit each).
+#ifdef INR_FAMILY_WIRE
+#define INR_DW_ATTR __noinline__  // WIRE kernels are register-bound: keep the dW pass out of their allocation
+#endif
 #include "inr_mlp_impl.h"
 #include "inr_aux.h"
 

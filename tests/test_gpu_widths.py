@@ -1,0 +1,146 @@
+"""Arbitrary hidden widths -- ``-m gpu``.  The kernels are built for 32-row block counts
+{1,2,4,8,16} (MLP), {2,4,8,12} (WIRE, interleaved Re/Im rows) and {1,4,8,16} (MFN); any other width
+runs zero-padded in the next larger build.  The reference accepts any ``network_width``
+(networks.py:100-119, :206-250; mfn.py:61-83), so the drop-in must too.
+
+Criterion as in test_gpu_wire.py: as close to a float64 evaluation of the oracle as the oracle's own
+fp32 evaluation is (x10, floor 2e-5) -- forward, loss and flat gradient, fused and ragged batch."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import oracle as O  # noqa: E402  (checker only)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _real(t):
+    return torch.view_as_real(t) if t.is_complex() else t
+
+
+def rel_l2(a, b):
+    a, b = _real(a).double().flatten(), _real(b).double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _ref(kind, sd, net, coords, enc_B, gt, dtype):
+    cd = torch.complex128 if dtype == torch.float64 else torch.complex64
+    keys = O.trainable_keys(kind, sd)
+    params = {}
+    for k, v in sd.items():
+        v = v.to(cd) if v.is_complex() else v.to(dtype)
+        params[k] = v.clone().requires_grad_(True) if k in keys else v
+    x = coords.to(dtype) if enc_B is None else O.encode(coords.to(dtype), enc_B.to(dtype), "gauss")
+    outs = O.model_forward(kind, params, x, net)
+    outs = outs if isinstance(outs, list) else [outs]
+    loss = sum(O.loss_l2_half(o.contiguous(), gt.to(dtype)) for o in outs)
+    grads = torch.autograd.grad(loss, [params[k] for k in keys])
+    return torch.stack([o.detach() for o in outs]), loss.detach(), torch.cat([_real(g).reshape(-1) for g in grads])
+
+
+def _check(got_out, got_loss, got_grad, r32, r64):
+    for name, got, a32, a64 in (("out", got_out, r32[0], r64[0]), ("grad", got_grad, r32[2], r64[2])):
+        e_gpu, e_cpu = rel_l2(got, a64), rel_l2(a32, a64)
+        assert e_gpu <= max(10 * e_cpu, 2e-5), (name, e_gpu, e_cpu)
+    l32, l64 = float(r32[1]), float(r64[1])
+    assert abs(float(got_loss) - l64) <= max(10 * abs(l32 - l64), 2e-5 * abs(l64))
+
+
+@pytest.mark.parametrize("width", [1, 17, 33, 64, 100, 128, 200, 300, 512])
+@pytest.mark.parametrize("model", ["SIREN", "FFN"])
+def test_mlp_widths(dev, model, width):
+    import inr_mi355x as M
+    from inr_mi355x import _lib as L
+    net = dict(network_input_size=48, network_output_size=2, network_depth=4, network_width=width)
+    enc_cfg = dict(embedding="gauss", scale=2, embedding_size=24, coordinates_size=3)
+    torch.manual_seed(width)
+    enc = M.Positional_Encoder(enc_cfg, device=dev)
+    mdl = getattr(M, model)(net)
+    sd = {k: v.clone() for k, v in mdl.state_dict().items()}
+    mdl = mdl.to(dev)
+    B = 391
+    g = torch.Generator().manual_seed(width)
+    coords = torch.rand(B, 3, generator=g) * 2 - 1
+    gt = torch.rand(B, 2, generator=g) * 0.5
+    r32 = _ref(model, sd, net, coords, enc.B.cpu(), gt, torch.float32)
+    r64 = _ref(model, sd, net, coords, enc.B.cpu(), gt, torch.float64)
+    eng = mdl.fused_engine(24)
+    out = eng.forward(coords.to(dev), enc.B.contiguous(), save=False).cpu()[None]
+    loss = eng.train_step(coords.to(dev), enc.B.contiguous(), gt.to(dev), M.LossSpec(L.LOSS_L2_HALF))
+    _check(out, loss, eng.grads.cpu(), r32, r64)
+    # tier 1 (unfused forward / backward kernels on a materialised encoding)
+    o1 = mdl(enc.embedding(coords.to(dev)))
+    (0.5 * torch.nn.functional.mse_loss(o1, gt.to(dev))).backward()
+    g1 = torch.cat([p.grad.reshape(-1) for p in mdl.parameters()]).cpu()
+    _check(o1.detach().cpu()[None], loss, g1, r32, r64)
+    # one Adam step re-packs the padded images consistently
+    eng.adam_step(1e-3, 0.9, 0.999, 1e-8, 0.0)
+    sd2 = {k: v.detach().cpu().clone() for k, v in mdl.state_dict().items()}
+    out2 = eng.forward(coords.to(dev), enc.B.contiguous(), save=False).cpu()[None]
+    q32 = _ref(model, sd2, net, coords, enc.B.cpu(), gt, torch.float32)
+    q64 = _ref(model, sd2, net, coords, enc.B.cpu(), gt, torch.float64)
+    assert rel_l2(out2, q64[0]) <= max(10 * rel_l2(q32[0], q64[0]), 2e-5)
+
+
+@pytest.mark.parametrize("width", [24, 64, 90, 128, 200])
+def test_wire_widths(dev, width):
+    """network_width -> int(width/sqrt 2) complex features (networks.py:228): 16, 45, 63, 90, 141."""
+    import inr_mi355x as M
+    from inr_mi355x import _lib as L
+    net = dict(network_input_size=3, network_output_size=2, network_depth=2, network_width=width,
+               first_omega_0=10, hidden_omega_0=10, scale=5)
+    torch.manual_seed(width)
+    mdl = M.WIRE(net)
+    sd = {k: v.clone() for k, v in mdl.state_dict().items()}
+    mdl = mdl.to(dev)
+    B = 203
+    g = torch.Generator().manual_seed(width)
+    coords = torch.rand(B, 3, generator=g) * 2 - 1
+    gt = torch.randn(B, 2, generator=g) * 0.2
+    r32 = _ref("WIRE", sd, net, coords, None, gt, torch.float32)
+    r64 = _ref("WIRE", sd, net, coords, None, gt, torch.float64)
+    eng = mdl._engine()
+    out = eng.forward(coords.to(dev), None, save=False).cpu()[None]
+    loss = eng.train_step(coords.to(dev), None, gt.to(dev), M.LossSpec(L.LOSS_L2_HALF))
+    _check(out, loss, eng.grads.cpu(), r32, r64)
+
+
+@pytest.mark.parametrize("width", [20, 48, 128, 160, 384])
+@pytest.mark.parametrize("kind", ["Fourier", "MultiscaleKFourier"])
+def test_mfn_widths(dev, kind, width):
+    import inr_mi355x as M
+    from inr_mi355x import _lib as L
+    from inr_mi355x.mfn import FourierNet, MultiscaleKFourier
+    multi = kind != "Fourier"
+    net = dict(network_input_size=32, network_output_size=2, network_depth=8 if multi else 3, network_width=width)
+    enc_cfg = dict(embedding="gauss", scale=2, embedding_size=16, coordinates_size=3)
+    torch.manual_seed(width)
+    enc = M.Positional_Encoder(enc_cfg, device=dev)
+    mdl = (MultiscaleKFourier if multi else FourierNet)(net)
+    sd = {k: v.clone() for k, v in mdl.state_dict().items()}
+    mdl = mdl.to(dev).bind_encoder(enc)
+    B = 150
+    g = torch.Generator().manual_seed(width)
+    coords = torch.rand(B, 3, generator=g) * 2 - 1
+    gt = torch.randn(B, 2, generator=g) * 0.2
+    r32 = _ref(kind, sd, net, coords, enc.B.cpu(), gt, torch.float32)
+    r64 = _ref(kind, sd, net, coords, enc.B.cpu(), gt, torch.float64)
+    eng = mdl._engine()
+    out = eng.forward(coords.to(dev), enc.B.contiguous(), save=False).cpu()
+    loss = eng.train_step(coords.to(dev), enc.B.contiguous(), gt.to(dev), M.LossSpec(L.LOSS_L2_HALF))
+    flat = eng.grads.cpu()
+    live = torch.cat([flat[o:o + n] for (o, n, s, c), lv in zip(mdl._layout, mdl._live) if lv])
+    _check(out, loss, live, r32, r64)
+
+
+def test_unsupported_width_fails_loudly(dev):
+    import inr_mi355x as M
+    net = dict(network_input_size=48, network_output_size=2, network_depth=3, network_width=513)
+    mdl = M.SIREN(net).to(dev)
+    with pytest.raises(RuntimeError, match="width 513"):
+        mdl._engine()
