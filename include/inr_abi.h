@@ -48,8 +48,12 @@ enum inr_kind {
   INR_KIND_MSFOURIER = 4, /* models/mfn.py:206-267  MultiscaleKFourier: heads output_linear[i], i in [1,3,5,7];
                              the unused last stage / heads exist in flat params but are never evaluated or
                              stepped (the reference leaves their .grad = None) */
-  INR_KIND_MSBOUNDED = 5  /* models/mfn.py:288-355  MultiscaleBoundedFourier: BoundedLinear (:269-286) zeroes the rows
+  INR_KIND_MSBOUNDED = 5, /* models/mfn.py:288-355  MultiscaleBoundedFourier: BoundedLinear (:269-286) zeroes the rows
                              of h whose dist lies outside [lo,hi] before each hidden Linear */
+  INR_KIND_GABOR = 6,     /* models/mfn.py:133-162  GaborNet: GaborLayer filters (:96-131)
+                             sin(F x + c) * exp(-0.5 * gamma_j * |x - mu_j|^2), mu and gamma trainable */
+  INR_KIND_KGABOR = 7     /* models/mfn.py:164-204  KGaborNet: same arithmetic (dist_to_center is passed to the
+                             filters but with_dist_filtering is never enabled); the dist argument is ignored */
 };
 
 /* activation of the last layer */

@@ -54,8 +54,9 @@ struct inr_plan {
 // parameters keep the state_dict order  linear.* , output_linear(.k).* , filters.*  (SURVEY Appendix B).
 static int create_mfn_plan(const inr_net_desc* d, inr_plan** out) {
   const bool multi = d->kind == INR_KIND_MSFOURIER || d->kind == INR_KIND_MSBOUNDED;
+  const bool gabor = d->kind == INR_KIND_GABOR || d->kind == INR_KIND_KGABOR;
   const int n = d->depth, W = d->width;
-  if (n < 1 || 2 * n + 1 + (multi ? n + 1 : 1) > INR_MAX_LAYERS)
+  if (n < 1 || 2 * n + 1 + (multi ? n + 1 : 1) + (gabor ? n + 1 : 0) > INR_MAX_LAYERS)
     return fail(INR_ERR_INVALID, "inr_plan_create: MFN depth %d", n);
   const int NB = W < 1 ? -1 : pick_nb((W + 31) / 32, {1, 4, 8, 16});
   if (NB < 0)
@@ -101,7 +102,9 @@ static int create_mfn_plan(const inr_net_desc* d, inr_plan** out) {
   }
   nd.mfn_stages = nd.head_stage[nd.n_heads - 1] + 1;
   const int n_head_layers = multi ? n + 1 : 1;
-  nd.D = (n + 1) + n + n_head_layers;
+  nd.gabor = gabor ? 1 : 0;
+  nd.mu0 = (n + 1) + n + n_head_layers;
+  nd.D = nd.mu0 + (gabor ? n + 1 : 0);
   const int TL = 32 * nd.NW;
   auto fill = [&](LayerDesc& L, int K, int M, bool filter, bool head) {
     L.K = K;
@@ -131,6 +134,12 @@ static int create_mfn_plan(const inr_net_desc* d, inr_plan** out) {
     nd.head_layer[k] = 2 * n + 1 + (multi ? nd.head_stage[k] : 0);
     nd.L[nd.head_layer[k]].live = 1;
   }
+  if (gabor)  // (mu_i, gamma_i) of GaborLayer i as a (weight, bias) pair: same shapes as the filter's Linear
+    for (int i = 0; i <= n; ++i) {
+      fill(nd.L[nd.mu0 + i], d->in_features, W, true, false);
+      nd.L[nd.mu0 + i].ltype = LT_GABOR_MU;
+      nd.L[nd.mu0 + i].live = 1;
+    }
   // flat offsets in state_dict order: linears, heads, filters
   int poff = 0;
   auto place = [&](LayerDesc& L) {
@@ -141,17 +150,21 @@ static int create_mfn_plan(const inr_net_desc* d, inr_plan** out) {
   };
   for (int i = 0; i < n; ++i) place(nd.L[n + 1 + i]);
   for (int i = 0; i < n_head_layers; ++i) place(nd.L[2 * n + 1 + i]);
-  for (int i = 0; i <= n; ++i) place(nd.L[i]);
+  for (int i = 0; i <= n; ++i) {  // filters.i.mu, filters.i.gamma, filters.i.linear.weight, filters.i.linear.bias
+    if (gabor) place(nd.L[nd.mu0 + i]);
+    place(nd.L[i]);
+  }
   nd.P = poff;
   int goff = 0;
   int64_t pk = 0;
   for (int l = 0; l < nd.D; ++l) {
     LayerDesc& L = nd.L[l];
-    const bool filter = l <= n;
+    const bool filter = l <= n || l >= nd.mu0;
+    const bool mu = l >= nd.mu0;
     L.gw_off = goff;
     goff += L.M * L.K;
     L.gb_off = goff;
-    goff += L.M;
+    goff += mu ? 2 * NB * 32 : L.M;  // LT_GABOR_MU: [s0 | T], NB*32 apart
     L.pf_off = (int)pk;
     pk += (int64_t)L.Kpad8 * L.Mblk * 32;
     if (!filter) {
@@ -161,11 +174,11 @@ static int create_mfn_plan(const inr_net_desc* d, inr_plan** out) {
       L.pb_off = -1;
     }
     L.pbias_off = (int)pk;
-    pk += L.Mblk * 32;
+    pk += (mu ? 2 : 1) * L.Mblk * 32;  // LT_GABOR_MU: [gamma | |mu_j|^2]
   }
   nd.slab_loss_off = goff;
   nd.slab_floats = round_up(goff + 4, 64);
-  nd.save_floats_per_tile = 3 * nd.mfn_stages * NB * 32 * TL + nd.L[0].Kblk * 32 * TL;
+  nd.save_floats_per_tile = 3 * nd.mfn_stages * NB * 32 * TL + nd.L[0].Kblk * 32 * TL + (gabor ? TL : 0);
   p->packed_floats = pk;
   *out = p;
   return INR_OK;
@@ -188,7 +201,8 @@ int inr_last_error(char* buf, size_t cap) {
 int inr_plan_create(const inr_net_desc* d, inr_plan** out) {
   if (d == nullptr || out == nullptr) return fail(INR_ERR_INVALID, "inr_plan_create: null argument");
   *out = nullptr;
-  if (d->kind == INR_KIND_FOURIER || d->kind == INR_KIND_MSFOURIER || d->kind == INR_KIND_MSBOUNDED)
+  if (d->kind == INR_KIND_FOURIER || d->kind == INR_KIND_MSFOURIER || d->kind == INR_KIND_MSBOUNDED ||
+      d->kind == INR_KIND_GABOR || d->kind == INR_KIND_KGABOR)
     return create_mfn_plan(d, out);
   if (d->kind != INR_KIND_SIREN && d->kind != INR_KIND_FFN && d->kind != INR_KIND_WIRE)
     return fail(INR_ERR_UNSUPPORTED, "inr_plan_create: kind %d has no kernel yet", d->kind);
@@ -446,7 +460,7 @@ int inr_backward(const inr_plan* plan, const float* params, const float* packed,
   memset(&ld, 0, sizeof(ld));
   int rc = launch(plan, ld, a, 1, (int)nb, (hipStream_t)stream);
   if (rc != INR_OK) return rc;
-  hipError_t e = inr::launch_reduce_slabs(plan->nd, slabs, (int)nb, grads, nullptr,
+  hipError_t e = inr::launch_reduce_slabs(plan->nd, slabs, (int)nb, grads, nullptr, params, packed,
                                           (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "inr_backward: slab reduction");
   return INR_OK;
@@ -534,7 +548,7 @@ int inr_train_step(const inr_plan* plan, const inr_loss_desc* loss, const float*
   int rc = launch(plan, ld, a, 2, (int)nb, (hipStream_t)stream);
   if (rc != INR_OK) return rc;
   if (grads == nullptr) return INR_OK;  // profiling: leave the per-block slabs unreduced
-  hipError_t e = inr::launch_reduce_slabs(plan->nd, slabs, (int)nb, grads, loss_out,
+  hipError_t e = inr::launch_reduce_slabs(plan->nd, slabs, (int)nb, grads, loss_out, params, packed,
                                           (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "inr_train_step: slab reduction");
   return INR_OK;
@@ -613,7 +627,8 @@ int inr_backward_multi(const inr_plan* plan, const float* params, const float* p
   memset(&ld, 0, sizeof(ld));
   int rc = launch(plan, ld, a, 1, (int)nb, (hipStream_t)stream);
   if (rc != INR_OK) return rc;
-  hipError_t e = inr::launch_reduce_slabs(plan->nd, slabs, (int)nb, grads, nullptr, (hipStream_t)stream);
+  hipError_t e = inr::launch_reduce_slabs(plan->nd, slabs, (int)nb, grads, nullptr, params, packed,
+                                          (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "inr_backward_multi: slab reduction");
   return INR_OK;
 }
@@ -652,7 +667,8 @@ int inr_train_step_multi(const inr_plan* plan, const inr_loss_desc* loss, const 
   int rc = launch(plan, ld, a, 2, (int)nb, (hipStream_t)stream);
   if (rc != INR_OK) return rc;
   if (grads == nullptr) return INR_OK;
-  hipError_t e = inr::launch_reduce_slabs(plan->nd, slabs, (int)nb, grads, loss_out, (hipStream_t)stream);
+  hipError_t e = inr::launch_reduce_slabs(plan->nd, slabs, (int)nb, grads, loss_out, params, packed,
+                                          (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "inr_train_step_multi: slab reduction");
   return INR_OK;
 }

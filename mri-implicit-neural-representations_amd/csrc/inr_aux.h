@@ -18,7 +18,7 @@ struct AdamArgs {
 
 
 hipError_t launch_reduce_slabs(const NetDesc& nd, const float* slabs, int n_blocks, float* grads, float* loss_out,
-                               hipStream_t st);
+                               const float* params, const float* packed, hipStream_t st);
 hipError_t launch_adam_pack(const NetDesc& nd, float* params, const float* grads, float* m1, float* m2,
                             float* packed, const AdamArgs& aa, hipStream_t st);
 hipError_t launch_encode_gauss(const float* coords, const float* encB, long long B, int E, float* out,

@@ -26,7 +26,7 @@ __device__ __forceinline__ bool locate(const NetDesc& nd, int i, int& l, Virtual
     const LayerDesc& L = nd.L[l];
     const int off = i - L.w_off;
     if (off >= 0 && off < L.wn) {
-      if (L.ltype == LT_REAL) {
+      if (L.ltype == LT_REAL || L.ltype == LT_GABOR_MU) {
         vp.n = 1; vp.row[0] = off / L.K; vp.col[0] = off - vp.row[0] * L.K; vp.sign[0] = 1.f;
       } else if (L.ltype == LT_WIRE_FIRST) {
         const int r = off / L.K;
@@ -51,7 +51,7 @@ __device__ __forceinline__ bool locate(const NetDesc& nd, int i, int& l, Virtual
     }
     const int ob = i - L.b_off;
     if (ob >= 0 && ob < L.bn) {
-      if (L.ltype == LT_REAL) vp.bias_row = ob;
+      if (L.ltype == LT_REAL || L.ltype == LT_GABOR_MU) vp.bias_row = ob;
       else if (L.ltype == LT_WIRE_FIRST) vp.bias_row = 2 * ob;
       else if (L.ltype == LT_WIRE_HIDDEN) vp.bias_row = ob;            // (i, c) -> row 2i + c
       else vp.bias_row = (ob & 1) ? -2 : (ob >> 1);                    // imaginary output bias: no effect
@@ -144,8 +144,49 @@ __global__ __launch_bounds__(256) void reduce_slabs_real_kernel(const float* __r
   }
 }
 
+// GaborLayer centres (mfn.py:116-131).  The fused kernel leaves, per filter and row j,
+//   S1[j,k] = sum_c a_cj x_ck,  s0_j = sum_c a_cj,  T_j = sum_c a_cj |x_c|^2      (a = g_h * h, so that
+// d h / d q = h * gamma with q = mu_j . x, and D = |x|^2 + |mu_j|^2 - 2 q); after the block reduction
+// grads[mu] holds S1 and grads[gamma] holds s0.  This kernel (one wave per row) finishes
+//   d gamma_j = -0.5 (T_j + |mu_j|^2 s0_j - 2 sum_k mu_jk S1_jk),   d mu_jk = gamma_j (S1_jk - s0_j mu_jk).
+__global__ __launch_bounds__(64) void gabor_finish_kernel(const NetDesc nd, const float* __restrict__ slabs,
+                                                          int n_blocks, const float* __restrict__ params,
+                                                          const float* __restrict__ packed, float* __restrict__ grads) {
+  const LayerDesc& L = nd.L[nd.mu0 + blockIdx.y];
+  const int j = blockIdx.x, lane = threadIdx.x;
+  if (j >= L.M) return;
+  const int NBW = nd.NB * 32;
+  float t = 0.f, dot = 0.f;
+  for (int b = lane; b < n_blocks; b += 64) t += slabs[(size_t)b * nd.slab_floats + L.gb_off + NBW + j];
+  const float* mu = params + L.w_off + (size_t)j * L.K;
+  float* g = grads + L.w_off + (size_t)j * L.K;
+  for (int k = lane; k < L.K; k += 64) dot = fmaf(mu[k], g[k], dot);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    t += __shfl_xor(t, off);
+    dot += __shfl_xor(dot, off);
+  }
+  const float s0 = grads[L.b_off + j], gamma = params[L.b_off + j], m2 = packed[L.pbias_off + NBW + j];
+  for (int k = lane; k < L.K; k += 64) g[k] = gamma * (g[k] - s0 * mu[k]);
+  if (lane == 0) grads[L.b_off + j] = -0.5f * ((t + m2 * s0) - 2.f * dot);
+}
+
+// |mu_j|^2 into the second half of the centre layer's bias image (after every (re)pack of the parameters)
+__global__ __launch_bounds__(64) void gabor_m2_kernel(const NetDesc nd, const float* __restrict__ params,
+                                                      float* __restrict__ packed) {
+  const LayerDesc& L = nd.L[nd.mu0 + blockIdx.y];
+  const int j = blockIdx.x, lane = threadIdx.x;
+  if (j >= L.M) return;
+  const float* mu = params + L.w_off + (size_t)j * L.K;
+  float s = 0.f;
+  for (int k = lane; k < L.K; k += 64) s = fmaf(mu[k], mu[k], s);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+  if (lane == 0) packed[L.pbias_off + nd.NB * 32 + j] = s;
+}
+
 hipError_t launch_reduce_slabs(const NetDesc& nd, const float* slabs, int n_blocks, float* grads, float* loss_out,
-                               hipStream_t st) {
+                               const float* params, const float* packed, hipStream_t st) {
   bool all_real = true;  // ... and slab layout == flat layout (not the case for MFN: L[] order != flat order)
   for (int l = 0; l < nd.D; ++l) all_real = all_real && nd.L[l].ltype == LT_REAL && nd.L[l].gw_off == nd.L[l].w_off;
   if (all_real) {  // slab offsets == flat offsets; slab_floats % 64 == 0 keeps every slab 16-byte aligned
@@ -156,6 +197,9 @@ hipError_t launch_reduce_slabs(const NetDesc& nd, const float* slabs, int n_bloc
     const int grid = (nd.P + 255) / 256;
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(grid), dim3(256), 0, st, nd, slabs, n_blocks, grads, loss_out);
   }
+  if (nd.gabor)
+    hipLaunchKernelGGL(gabor_finish_kernel, dim3(nd.L[nd.mu0].M, nd.mfn_n + 1), dim3(64), 0, st, nd, slabs, n_blocks,
+                       params, packed, grads);
   return hipGetLastError();
 }
 
@@ -245,11 +289,13 @@ hipError_t launch_adam_pack(const NetDesc& nd, float* params, const float* grads
   aa.all_real = 1;
   aa.has_dead = 0;
   for (int l = 0; l < nd.D; ++l) {
-    aa.all_real = aa.all_real && nd.L[l].ltype == LT_REAL;
+    aa.all_real = aa.all_real && (nd.L[l].ltype == LT_REAL || nd.L[l].ltype == LT_GABOR_MU);
     aa.has_dead = aa.has_dead || nd.L[l].live == 0;
   }
   const int grid = (nd.P + 255) / 256;
   hipLaunchKernelGGL(adam_pack_kernel, dim3(grid), dim3(256), 0, st, nd, params, grads, m1, m2, packed, aa);
+  if (nd.gabor)
+    hipLaunchKernelGGL(gabor_m2_kernel, dim3(nd.L[nd.mu0].M, nd.mfn_n + 1), dim3(64), 0, st, nd, params, packed);
   return hipGetLastError();
 }
 

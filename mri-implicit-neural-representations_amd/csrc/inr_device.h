@@ -24,6 +24,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define LT_WIRE_FIRST 1    // weight [M/2,K] f32 -> rows 2i, rows 2i+1 are zero (networks.py:185-188)
 #define LT_WIRE_HIDDEN 2   // weight [M/2,K/2] complex64 -> [[Wr,-Wi],[Wi,Wr]] interleaved
 #define LT_WIRE_LAST 3     // weight [M,K/2] complex64, output = real part: row o = [Wr, -Wi] interleaved
+#define LT_GABOR_MU 4      // GaborLayer centres: "weight" = mu [M,K], "bias" = gamma [M] (mfn.py:106-111); packed
+                           // bias image = [gamma | ||mu_j||^2], slab = [S1 (M x K) | s0 (NB*32) | T (NB*32)]
 
 #define IN_X 0
 #define IN_GAUSS 1
@@ -72,6 +74,8 @@ struct NetDesc {
   int n_heads;                    // 1 (FourierNet) or 4 (multiscale)
   int head_stage[INR_MAX_HEADS];  // stage whose h feeds head k
   int head_layer[INR_MAX_HEADS];  // index into L[] of head k
+  int gabor;                      // GaborNet / KGaborNet: L[mu0 + i] describes (mu_i, gamma_i) of filter i
+  int mu0;
   int bounded;                    // MultiscaleBoundedFourier: linears see h only where lo <= dist <= hi
   float bound_lo[INR_MAX_LAYERS / 2], bound_hi[INR_MAX_LAYERS / 2];  // per linear
   LayerDesc L[INR_MAX_LAYERS];

@@ -59,29 +59,44 @@ __device__ __forceinline__ void gemm_enc_stash(f32x16 (&acc)[NB], const float* _
 }
 
 // ---------------------------------------------------------------------------------------------
-// stage epilogue: u = acc + c (bias image), f = sin u, fc = cos u;
+// stage epilogue for row blocks [m0, m0+MT): u = accU + c (bias image), f = sin u, fc = cos u;
+//   GABOR (GaborLayer.forward, mfn.py:116-131): D = |x|^2 + |mu_j|^2 - 2 q (q = accQ = mu_j . x),
+//          env = exp(-0.5 D gamma_j);  f *= env, fc *= env        (gm = [gamma | |mu|^2] image)
 //   FIRST: h = f                         image <- h;  stash f, fc, h
 //   else : l = image (parked), h = f*l   image <- h;  stash f, l*fc, h
 // All accesses use this lane's own accumulator positions (row = 32m + (r&3) + 8(r>>2) + 4*half).
 // ---------------------------------------------------------------------------------------------
-template <int NB, int TL, bool FIRST, bool SAVE>
-__device__ __forceinline__ void mfn_epilogue(const f32x16 (&acc)[NB], float* R, const float* __restrict__ cbias,
+template <int NB, int MT, int TL, bool FIRST, bool GABOR>
+__device__ __forceinline__ void mfn_epilogue(const f32x16 (&accU)[MT], const f32x16 (&accQ)[MT], int m0, float* R,
+                                             const float* __restrict__ cbias, const float* __restrict__ gm, float x2,
                                              float* __restrict__ sv, int wcol, int lane) {
   const int half = lane >> 5, col = lane & 31;
   constexpr int hsz = NB * 32 * TL;
-  float* Rl = R + (4 * half) * INR_LDS_LD + col;
-  float* svl = SAVE ? sv + (4 * half) * TL + wcol : nullptr;
-  const float* bl = cbias + 4 * half;
+  float* Rl = R + (32 * m0 + 4 * half) * INR_LDS_LD + col;
+  float* svl = sv + (32 * m0 + 4 * half) * TL + wcol;
+  const float* bl = cbias + 32 * m0 + 4 * half;
+  const float* gl = GABOR ? gm + 32 * m0 + 4 * half : nullptr;
 #pragma unroll
-  for (int m = 0; m < NB; ++m) {
+  for (int m = 0; m < MT; ++m) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const f32x4 c4 = *reinterpret_cast<const f32x4*>(bl + 32 * m + 8 * g);
+      f32x4 ga4 = {0.f, 0.f, 0.f, 0.f}, m24 = {0.f, 0.f, 0.f, 0.f};
+      if (GABOR) {
+        ga4 = *reinterpret_cast<const f32x4*>(gl + 32 * m + 8 * g);
+        m24 = *reinterpret_cast<const f32x4*>(gl + NB * 32 + 32 * m + 8 * g);
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int row = 32 * m + 8 * g + j;  // + 4*half folded into Rl / svl
+        const int row = 32 * m + 8 * g + j;  // + 32*m0 + 4*half folded into Rl / svl
         float sn, cs;
-        sincos_cw(acc[m][4 * g + j] + c4[j], sn, cs);
+        sincos_cw(accU[m][4 * g + j] + c4[j], sn, cs);
+        if (GABOR) {
+          const float D = (x2 + m24[j]) - 2.f * accQ[m][4 * g + j];
+          const float env = expf((-0.5f * D) * ga4[j]);
+          sn *= env;
+          cs *= env;
+        }
         float h = sn, lc = cs;
         if (!FIRST) {
           const float l = Rl[row * INR_LDS_LD];
@@ -89,11 +104,9 @@ __device__ __forceinline__ void mfn_epilogue(const f32x16 (&acc)[NB], float* R, 
           lc = l * cs;
         }
         Rl[row * INR_LDS_LD] = h;
-        if (SAVE) {
-          svl[row * TL] = sn;
-          svl[hsz + row * TL] = lc;
-          svl[2 * hsz + row * TL] = h;
-        }
+        svl[row * TL] = sn;
+        svl[hsz + row * TL] = lc;
+        svl[2 * hsz + row * TL] = h;
       }
     }
   }
@@ -141,14 +154,17 @@ __device__ __forceinline__ void load_fac(f32x4 (&f)[MT], const float* __restrict
     f[m] = *reinterpret_cast<const f32x4*>(fac + (32 * (m0 + m) + li) * TL + 8 * q + 4 * (lane >> 5));
 }
 
-template <int MT, int TL, bool BIAS, class BSrc>
-__device__ __forceinline__ void dwf_group(f32x16 (&acc)[MT], float (&bsum)[MT], const f32x4 (&a_use)[MT],
-                                          const f32x4 (&f_use)[MT], f32x4 (&a_load)[MT], f32x4 (&f_load)[MT],
-                                          const f32x4& b_use, f32x4& b_load, BSrc& bsrc, const float* fac, int m0,
-                                          int n, int q_next, const float* Rq_next, int lane) {
+// T2 (Gabor centres): a second row sum weighted by |x_c|^2 of the coordinate (x2 [TL], see gabor notes below)
+template <int MT, int TL, bool BIAS, bool T2, class BSrc>
+__device__ __forceinline__ void dwf_group(f32x16 (&acc)[MT], float (&bsum)[MT], float (&bsum2)[MT],
+                                          const f32x4 (&a_use)[MT], const f32x4 (&f_use)[MT], f32x4 (&a_load)[MT],
+                                          f32x4 (&f_load)[MT], const f32x4& b_use, f32x4& b_load, const f32x4& w_use,
+                                          f32x4& w_load, BSrc& bsrc, const float* fac, const float* x2, int m0, int n,
+                                          int q_next, const float* Rq_next, int lane) {
   const typename BSrc::Raw raw = bsrc.fetch(n, q_next, lane);
   load_fac<MT, TL>(f_load, fac, m0, q_next, lane);
   load_dw_a<MT>(a_load, Rq_next);
+  if (T2) w_load = *reinterpret_cast<const f32x4*>(x2 + 8 * q_next + 4 * (lane >> 5));
   __builtin_amdgcn_sched_barrier(0);
   b_load = bsrc.finish(raw);
 #pragma unroll
@@ -157,6 +173,7 @@ __device__ __forceinline__ void dwf_group(f32x16 (&acc)[MT], float (&bsum)[MT], 
     for (int m = 0; m < MT; ++m) {
       const float a = a_use[m][e] * f_use[m][e];
       if (BIAS) bsum[m] += a;
+      if (BIAS && T2) bsum2[m] = fmaf(a, w_use[e], bsum2[m]);
       acc[m] = mfma32(a, b_use[e], acc[m]);
     }
   }
@@ -164,19 +181,19 @@ __device__ __forceinline__ void dwf_group(f32x16 (&acc)[MT], float (&bsum)[MT], 
 }
 
 // rows [32*m0, 32*(m0+MT)) x column block n of dW = (G*fac)^T . B over the tile's TL coordinates
-template <int MT, int TL, bool BIAS, class BSrc>
+template <int MT, int TL, bool BIAS, bool T2, class BSrc>
 __device__ __noinline__ void dwf_pass_impl(const float* Rall, int region_stride, const float* fac, BSrc& bsrc,
-                                              int m0, int n, float* slab_w, float* slab_b, int M, int K, bool first,
-                                              int lane) {
+                                           int m0, int n, float* slab_w, float* slab_b, float* slab_b2,
+                                           const float* x2, int M, int K, bool first, int lane) {
   const int half = lane >> 5, li = lane & 31;
   f32x16 acc[MT];
-  float bsum[MT];
+  float bsum[MT], bsum2[MT];
   const int jcol = 32 * n + li;
   const bool colok = jcol < K;
   const int lane_off = 4 * half * K + jcol;
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
-    bsum[m] = 0.f;
+    bsum[m] = bsum2[m] = 0.f;
     acc[m] = zero16();
     if (!first) {
 #pragma unroll
@@ -191,15 +208,17 @@ __device__ __noinline__ void dwf_pass_impl(const float* Rall, int region_stride,
   const float* Rl = Rall + (32 * m0 + li) * INR_LDS_LD + 4 * half;
   f32x4 B0 = bsrc.finish(bsrc.fetch(n, 0, lane)), B1;
   f32x4 A0[MT], A1[MT], F0[MT], F1[MT];
+  f32x4 W0 = {0.f, 0.f, 0.f, 0.f}, W1 = W0;
   load_dw_a<MT>(A0, Rl);
   load_fac<MT, TL>(F0, fac, m0, 0, lane);
+  if (T2) W0 = *reinterpret_cast<const f32x4*>(x2 + 4 * half);
 #pragma unroll 1
   for (int q = 0; q < TL / 8; q += 2) {
     const int q2 = (q + 2 < TL / 8) ? q + 2 : q;
-    dwf_group<MT, TL, BIAS, BSrc>(acc, bsum, A0, F0, A1, F1, B0, B1, bsrc, fac, m0, n, q + 1,
-                                  Rl + ((q + 1) >> 2) * region_stride + 8 * ((q + 1) & 3), lane);
-    dwf_group<MT, TL, BIAS, BSrc>(acc, bsum, A1, F1, A0, F0, B1, B0, bsrc, fac, m0, n, q2,
-                                  Rl + (q2 >> 2) * region_stride + 8 * (q2 & 3), lane);
+    dwf_group<MT, TL, BIAS, T2, BSrc>(acc, bsum, bsum2, A0, F0, A1, F1, B0, B1, W0, W1, bsrc, fac, x2, m0, n, q + 1,
+                                      Rl + ((q + 1) >> 2) * region_stride + 8 * ((q + 1) & 3), lane);
+    dwf_group<MT, TL, BIAS, T2, BSrc>(acc, bsum, bsum2, A1, F1, A0, F0, B1, B0, W1, W0, bsrc, fac, x2, m0, n, q2,
+                                      Rl + (q2 >> 2) * region_stride + 8 * (q2 & 3), lane);
   }
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
@@ -212,23 +231,30 @@ __device__ __noinline__ void dwf_pass_impl(const float* Rall, int region_stride,
       const float tot = bsum[m] + __shfl_xor(bsum[m], 32);
       const int row = 32 * (m0 + m) + li;
       if (half == 0 && row < M) slab_b[row] = first ? tot : slab_b[row] + tot;
+      if (T2) {
+        const float tot2 = bsum2[m] + __shfl_xor(bsum2[m], 32);
+        if (half == 0 && row < M) slab_b2[row] = first ? tot2 : slab_b2[row] + tot2;
+      }
     }
   }
 }
 
-template <int NB, int TL, class BSrc>
+// T2: the layer is a GaborLayer centre matrix (LT_GABOR_MU): S1 = (G*fac)^T x into the dW region, its row sums
+// s0 into the bias region and the |x|^2-weighted row sums T right behind them (NB*32 further)
+template <int NB, int TL, bool T2, class BSrc>
 __device__ __forceinline__ void dwf_layer(const float* lds, int RS, const float* fac, BSrc& bsrc, const LayerDesc& L,
-                                          float* slab, bool first, int w, int nw, int lane) {
+                                          float* slab, const float* x2, bool first, int w, int nw, int lane) {
   constexpr int MT = NB > 8 ? 8 : NB;  // 16-block rows go in two halves (accumulators + operands <= 512 regs)
+  float* sb = slab + L.gb_off;
   for (int n = w; n < L.Kblk; n += nw) {
 #pragma unroll
     for (int m0 = 0; m0 < NB; m0 += MT) {
       if (n == 0)
-        dwf_pass_impl<MT, TL, true, BSrc>(lds, RS, fac, bsrc, m0, n, slab + L.gw_off, slab + L.gb_off, L.M, L.K, first,
-                                          lane);
+        dwf_pass_impl<MT, TL, true, T2, BSrc>(lds, RS, fac, bsrc, m0, n, slab + L.gw_off, sb, sb + NB * 32, x2, L.M, L.K,
+                                              first, lane);
       else
-        dwf_pass_impl<MT, TL, false, BSrc>(lds, RS, fac, bsrc, m0, n, slab + L.gw_off, slab + L.gb_off, L.M, L.K,
-                                           first, lane);
+        dwf_pass_impl<MT, TL, false, false, BSrc>(lds, RS, fac, bsrc, m0, n, slab + L.gw_off, sb, sb, x2, L.M, L.K,
+                                                  first, lane);
     }
   }
 }
@@ -301,7 +327,7 @@ __device__ __forceinline__ void gemm_enc(f32x16 (&acc)[NB], const float* __restr
 // head-gradient image (own column), not in registers: the head code then exists once, indexed by the
 // (wave-uniform) head number.  Rows >= 8 of that image are never consumed: the head dW pass keeps rows
 // < out_features only, and dX = W_head^T g contracts over rows 0..7.
-template <int NB, int NW, int MODE>
+template <int NB, int NW, int MODE, bool GABOR>
 __global__ __launch_bounds__(NW * 64) void inr_mfn_kernel(const NetDesc nd, const LossDesc ld, const MlpArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int TL = NW * 32;
@@ -321,6 +347,8 @@ __global__ __launch_bounds__(NW * 64) void inr_mfn_kernel(const NetDesc nd, cons
   const int n = nd.mfn_n, S = nd.mfn_stages, NH = nd.n_heads;
   const LayerDesc* Fl = nd.L;           // filters 0..n
   const LayerDesc* Ll = nd.L + n + 1;   // linears 0..n-1
+  const LayerDesc* Ml = nd.L + nd.mu0;  // GABOR: (mu_i, gamma_i) of filter i
+  constexpr int MT = NB > 8 ? 8 : NB;   // row blocks per register-sized chunk
   float* slab = (MODE != MODE_FWD) ? a.slabs + (size_t)blockIdx.x * nd.slab_floats : nullptr;
   float loss_acc = 0.f;
   bool first = true;
@@ -335,29 +363,53 @@ __global__ __launch_bounds__(NW * 64) void inr_mfn_kernel(const NetDesc nd, cons
     // stash: stage i -> [f_i | l_i cos u_i | h_i] ; then encoder features; without a save buffer the
     // encoder features still need a home for stages >= 1: the caller always passes one for MFN
     float* sv_enc = sv + (size_t)3 * S * HSZ;
+    float* sv_x2 = sv_enc + (size_t)Fl[0].Kblk * 32 * TL;  // GABOR: |x_c|^2 of the tile's coordinates [TL]
+    float x2 = 0.f;
     float keep = 1.f;  // bounded linears: per-coordinate 0/1 (recomputed per stage)
     const float dist = (a.dist != nullptr && valid) ? a.dist[crow] : 0.f;
     // ================================ forward =================================
     if (MODE != MODE_BWD) {
       {
-        f32x16 acc[NB];
-#pragma unroll
-        for (int m = 0; m < NB; ++m) acc[m] = zero16();
-        float x0 = 0.f, x1 = 0.f, x2 = 0.f;
+        float x0 = 0.f, x1 = 0.f, x2c = 0.f;
         if (valid) {
           x0 = a.x[3 * crow + 0];
           x1 = a.x[3 * crow + 1];
-          x2 = a.x[3 * crow + 2];
+          x2c = a.x[3 * crow + 2];
         }
         const float two_pi = 6.283185307179586f;
-        constexpr int MT = NB > 8 ? 8 : NB;
-        fwd_layer0_gauss<MT, TL, true, NB>(chunk<MT, NB>(acc, 0), a.packed + Fl[0].pf_off, encB_lds, nd.E, two_pi * x0,
-                                           two_pi * x1, two_pi * x2, sv_enc, wcol, lane);
 #pragma unroll
-        for (int m0 = MT; m0 < NB; m0 += MT)  // remaining row blocks: features come back from the stash just written
-          gemm_enc_stash<MT, TL, NB>(chunk<MT, NB>(acc, m0), a.packed + Fl[0].pf_off + (size_t)m0 * 256, sv_enc, nd.E,
-                                     wcol, lane);
-        mfn_epilogue<NB, TL, true, true>(acc, R, a.packed + Fl[0].pbias_off, sv, wcol, lane);
+        for (int m0 = 0; m0 < NB; m0 += MT) {
+          f32x16 accU[MT], accQ[GABOR ? MT : 1];
+#pragma unroll
+          for (int m = 0; m < MT; ++m) accU[m] = zero16();
+          if (m0 == 0)  // generates the encoder features and leaves them in the stash for everything after
+            fwd_layer0_gauss<MT, TL, true, NB>(accU, a.packed + Fl[0].pf_off, encB_lds, nd.E, two_pi * x0, two_pi * x1,
+                                               two_pi * x2c, sv_enc, wcol, lane);
+          else
+            gemm_enc_stash<MT, TL, NB>(accU, a.packed + Fl[0].pf_off + (size_t)m0 * 256, sv_enc, nd.E, wcol, lane);
+          if (GABOR) {
+            if (m0 == 0) {  // |x_c|^2 = sum of squared features (mfn.py:125), this lane's half then both
+              const float* svl = sv_enc + (half ? nd.E : 0) * TL + wcol;
+              float acc2 = 0.f;
+              for (int e = 0; e < nd.E; ++e) {
+                const float v = svl[e * TL];
+                acc2 = fmaf(v, v, acc2);
+              }
+              x2 = acc2 + __shfl_xor(acc2, 32);
+              if (half == 0) sv_x2[wcol] = x2;
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m) accQ[m] = zero16();
+            gemm_enc_stash<MT, TL, NB>(reinterpret_cast<f32x16(&)[MT]>(accQ), a.packed + Ml[0].pf_off + (size_t)m0 * 256,
+                                       sv_enc, nd.E, wcol, lane);
+            mfn_epilogue<NB, MT, TL, true, true>(accU, reinterpret_cast<f32x16(&)[MT]>(accQ), m0, R,
+                                                 a.packed + Fl[0].pbias_off, a.packed + Ml[0].pbias_off, x2, sv, wcol,
+                                                 lane);
+          } else {
+            mfn_epilogue<NB, MT, TL, true, false>(accU, accU, m0, R, a.packed + Fl[0].pbias_off, nullptr, 0.f, sv, wcol,
+                                                  lane);
+          }
+        }
       }
 #pragma unroll 1
       for (int i = 1; i < S; ++i) {
@@ -373,9 +425,23 @@ __global__ __launch_bounds__(NW * 64) void inr_mfn_kernel(const NetDesc nd, cons
         gemm_image<NB, TL, false>(acc, R, a.packed + Ll[i - 1].pf_off, NB * 32, nullptr, wcol, lane);  // V = L h
         acc_to_lds<NB, true>(acc, R, a.packed + Ll[i - 1].pbias_off, lane);                               // park l
 #pragma unroll
-        for (int m = 0; m < NB; ++m) acc[m] = zero16();
-        gemm_enc<NB, TL>(acc, a.packed + Fl[i].pf_off, sv_enc, nd.E, wcol, lane);                          // U = F x
-        mfn_epilogue<NB, TL, false, true>(acc, R, a.packed + Fl[i].pbias_off, sv + (size_t)3 * i * HSZ, wcol, lane);
+        for (int m0 = 0; m0 < NB; m0 += MT) {  // U = F x (and Q = mu x), epilogue, one register-sized chunk at a time
+          f32x16 accU[MT], accQ[GABOR ? MT : 1];
+#pragma unroll
+          for (int m = 0; m < MT; ++m) accU[m] = zero16();
+          gemm_enc_stash<MT, TL, NB>(accU, a.packed + Fl[i].pf_off + (size_t)m0 * 256, sv_enc, nd.E, wcol, lane);
+          if (GABOR) {
+            f32x16 (&q)[MT] = reinterpret_cast<f32x16(&)[MT]>(accQ);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) q[m] = zero16();
+            gemm_enc_stash<MT, TL, NB>(q, a.packed + Ml[i].pf_off + (size_t)m0 * 256, sv_enc, nd.E, wcol, lane);
+            mfn_epilogue<NB, MT, TL, false, true>(accU, q, m0, R, a.packed + Fl[i].pbias_off,
+                                                  a.packed + Ml[i].pbias_off, x2, sv + (size_t)3 * i * HSZ, wcol, lane);
+          } else {
+            mfn_epilogue<NB, MT, TL, false, false>(accU, accU, m0, R, a.packed + Fl[i].pbias_off, nullptr, 0.f,
+                                                   sv + (size_t)3 * i * HSZ, wcol, lane);
+          }
+        }
         // head fed by this stage, if any (output_layers are distinct stages)
         int kh = -1;
         for (int k = 0; k < NH; ++k)
@@ -423,6 +489,7 @@ __global__ __launch_bounds__(NW * 64) void inr_mfn_kernel(const NetDesc nd, cons
       f32x16 gacc[NB];
 #pragma unroll
       for (int m = 0; m < NB; ++m) gacc[m] = zero16();
+      if (GABOR && MODE == MODE_BWD) x2 = 0.f;  // the passes read sv_x2 themselves
 #pragma unroll 1
       for (int i = S - 1; i >= 1; --i) {
         float* svi = sv + (size_t)3 * i * HSZ;
@@ -462,13 +529,15 @@ __global__ __launch_bounds__(NW * 64) void inr_mfn_kernel(const NetDesc nd, cons
           if (nd.bounded) {
             BSrcStashKeep<TL> bh{sv + (size_t)(3 * (i - 1) + 2) * HSZ, a.dist, row0, a.B, nd.bound_lo[i - 1],
                                  nd.bound_hi[i - 1]};
-            dwf_layer<NB, TL, BSrcStashKeep<TL>>(lds, RS, svi, bh, Ll[i - 1], slab, first, w, NW, lane);
+            dwf_layer<NB, TL, false, BSrcStashKeep<TL>>(lds, RS, svi, bh, Ll[i - 1], slab, nullptr, first, w, NW, lane);
           } else {
             BSrcStash<TL> bh{sv + (size_t)(3 * (i - 1) + 2) * HSZ};
-            dwf_layer<NB, TL, BSrcStash<TL>>(lds, RS, svi, bh, Ll[i - 1], slab, first, w, NW, lane);
+            dwf_layer<NB, TL, false, BSrcStash<TL>>(lds, RS, svi, bh, Ll[i - 1], slab, nullptr, first, w, NW, lane);
           }
           BSrcStash<TL> bx{sv_enc};
-          dwf_layer<NB, TL, BSrcStash<TL>>(lds, RS, svi + HSZ, bx, Fl[i], slab, first, w, NW, lane);
+          dwf_layer<NB, TL, false, BSrcStash<TL>>(lds, RS, svi + HSZ, bx, Fl[i], slab, nullptr, first, w, NW, lane);
+          // GABOR: S1_i = (g_h * h_i)^T x, s0_i, T_i  ->  d mu_i, d gamma_i in the finishing kernel
+          if (GABOR) dwf_layer<NB, TL, true, BSrcStash<TL>>(lds, RS, svi + 2 * HSZ, bx, Ml[i], slab, sv_x2, first, w, NW, lane);
         }
         __syncthreads();
         // ---- g_h_{i-1} = L_{i-1}^T (g_h_i * f_i)   (in place on the image, which is dead afterwards)
@@ -489,7 +558,8 @@ __global__ __launch_bounds__(NW * 64) void inr_mfn_kernel(const NetDesc nd, cons
       __syncthreads();
       {
         BSrcStash<TL> bx{sv_enc};
-        dwf_layer<NB, TL, BSrcStash<TL>>(lds, RS, sv + HSZ, bx, Fl[0], slab, first, w, NW, lane);
+        dwf_layer<NB, TL, false, BSrcStash<TL>>(lds, RS, sv + HSZ, bx, Fl[0], slab, nullptr, first, w, NW, lane);
+        if (GABOR) dwf_layer<NB, TL, true, BSrcStash<TL>>(lds, RS, sv + 2 * HSZ, bx, Ml[0], slab, sv_x2, first, w, NW, lane);
       }
       __syncthreads();
       first = false;
@@ -511,10 +581,10 @@ __global__ __launch_bounds__(NW * 64) void inr_mfn_kernel(const NetDesc nd, cons
   }
 }
 
-template <int NB, int NW, int MODE>
+template <int NB, int NW, int MODE, bool GABOR>
 inline hipError_t launch_mfn(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int grid, hipStream_t st) {
   const size_t lds_bytes = ((size_t)NW * (NB + 1) * 32 * INR_LDS_LD + 3 * (size_t)nd.E) * sizeof(float);
-  auto k = inr_mfn_kernel<NB, NW, MODE>;
+  auto k = inr_mfn_kernel<NB, NW, MODE, GABOR>;
   static thread_local bool attr_set = false;
   if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
   if (!attr_set) {

@@ -1,5 +1,6 @@
 """Drop-in mirrors of the reference's multiplicative filter networks (models/mfn.py):
-``FourierNet`` (:61-94) and ``MultiscaleKFourier`` (:206-267).  Same constructor signature, RNG
+``FourierNet`` (:61-94), ``GaborNet`` / ``KGaborNet`` (:133-204), ``MultiscaleKFourier`` (:206-267) and
+``MultiscaleBoundedFourier`` (:288-355).  Same constructor signature, RNG
 order, state_dict keys / order (``linear.*``, ``output_linear(.k).*``, ``filters.k.linear.*``).
 
 The MI355X kernel fuses the gauss encoder into every filter (the encoded [B,2E] input is never
@@ -53,6 +54,17 @@ class _FilterShell(nn.Module):
         self.linear = holder  # filters.k.linear.weight / bias
 
 
+class _GaborShell(nn.Module):
+    """filters.k of GaborNet: own parameters mu, gamma precede the child Linear in state_dict order
+    (mfn.py:101-111)."""
+
+    def __init__(self, mu: nn.Parameter, gamma: nn.Parameter, holder: _Holder):
+        super().__init__()
+        self.mu = mu
+        self.gamma = gamma
+        self.linear = holder
+
+
 class _BoundedShell(nn.Module):
     def __init__(self, holder: _Holder, bounds):
         super().__init__()
@@ -63,6 +75,7 @@ class _BoundedShell(nn.Module):
 class _MFNBase(_FlatModel):
     _multiscale = False
     _bounds = None
+    _gabor = None  # (alpha, beta) of the GaborLayer gamma prior, or None for Fourier filters
 
     def _build_mfn(self, params, filter_scale: float, weight_scale: float):
         n = params["network_depth"]
@@ -80,17 +93,27 @@ class _MFNBase(_FlatModel):
         if self._bounds is not None:  # mfn.py:319-321: a fresh list of BoundedLinear (default init) replaces it
             lin = [nn.Linear(W, W) for _ in range(n)]
         # child: n+1 FourierLayer (mfn.py:50-55): default init, weight *= scale, bias ~ U(-pi, pi)
-        filt = []
+        filt, centres = [], []
         for _ in range(n + 1):
             m = nn.Linear(in_size, W)
-            m.weight.data *= filter_scale
+            if self._gabor is not None:  # GaborLayer.__init__ (mfn.py:101-113): Linear, mu, gamma, scale, bias
+                mu = 2 * torch.rand(W, in_size) - 1
+                gamma = torch.distributions.gamma.Gamma(*self._gabor).sample((W,))
+                m.weight.data *= filter_scale * torch.sqrt(gamma[:, None])
+                centres.append((mu, gamma))
+            else:
+                m.weight.data *= filter_scale
             m.bias.data.uniform_(-np.pi, np.pi)
             filt.append(m)
         heads = [out_lin]
         if self._multiscale:  # mfn.py:247: output_linear replaced by n+1 fresh heads (after the filters)
             heads = [nn.Linear(W, out_size) for _ in range(n + 1)]
         tensors = []
-        for m in lin + heads + filt:  # state_dict order: linear, output_linear, filters
+        for m in lin + heads:  # state_dict order: linear, output_linear, filters
+            tensors += [m.weight.detach(), m.bias.detach()]
+        for i, m in enumerate(filt):
+            if self._gabor is not None:
+                tensors += list(centres[i])
             tensors += [m.weight.detach(), m.bias.detach()]
         ps = self._flatten(tensors)
         k = 0
@@ -106,7 +129,13 @@ class _MFNBase(_FlatModel):
         else:
             self.output_linear = _Holder(ps[k], ps[k + 1])
             k += 2
-        self.filters = nn.ModuleList([_FilterShell(_Holder(ps[k + 2 * i], ps[k + 2 * i + 1])) for i in range(n + 1)])
+        if self._gabor is not None:
+            self.filters = nn.ModuleList([_GaborShell(ps[k + 4 * i], ps[k + 4 * i + 1],
+                                                      _Holder(ps[k + 4 * i + 2], ps[k + 4 * i + 3]))
+                                          for i in range(n + 1)])
+        else:
+            self.filters = nn.ModuleList([_FilterShell(_Holder(ps[k + 2 * i], ps[k + 2 * i + 1]))
+                                          for i in range(n + 1)])
         # which parameter tensors are live
         if self._multiscale:
             head_stages = [s for s in (1, 3, 5, 7) if s <= n]
@@ -135,6 +164,8 @@ class _MFNBase(_FlatModel):
         if self._eng is None:
             from . import _lib as L
             kind = L.KIND_MSBOUNDED if self._bounds is not None else (L.KIND_MSFOURIER if self._multiscale else L.KIND_FOURIER)
+            if self._gabor is not None:
+                kind = self._kind
             self._eng = MFNEngine(kind, self._in, self._W, self._n, self._out, self._enc_B.shape[0], self._bounds)
             self._eng.bind(self._flat)
         return self._eng
@@ -154,6 +185,32 @@ class FourierNet(_MFNBase):
         if output_act:
             raise NotImplementedError("output_act")
         self._build_mfn(params, input_scale / np.sqrt(params["network_depth"] + 1), weight_scale)
+
+    def forward(self, x, dist_to_center=None):
+        return self._heads(x)[0]
+
+
+class GaborNet(_MFNBase):
+    """mfn.py:133-162: multiplicative filter network with Gabor filters
+    sin(F x + c) * exp(-0.5 * gamma_j * |x - mu_j|^2); mu and gamma are trained."""
+
+    def __init__(self, params, input_scale=2, weight_scale=1.0, alpha=6.0, beta=1.0, bias=True, output_act=False):
+        super().__init__()
+        if output_act:
+            raise NotImplementedError("output_act")
+        from . import _lib as L
+        self._kind = L.KIND_KGABOR if isinstance(self, KGaborNet) else L.KIND_GABOR
+        n = params["network_depth"]
+        self._gabor = (alpha / (n + 1), beta)
+        self._build_mfn(params, input_scale / np.sqrt(n + 1), weight_scale)
+
+    def forward(self, x, dist_to_center=None):
+        return self._heads(x)[0]
+
+
+class KGaborNet(GaborNet):
+    """mfn.py:164-204: ``forward(x, dist_to_center)``; the filters receive dist_to_center but never use it
+    (with_dist_filtering stays False), so the arithmetic is GaborNet's."""
 
     def forward(self, x, dist_to_center=None):
         return self._heads(x)[0]

@@ -27,11 +27,14 @@ import yaml
 from . import _lib as L
 from .engine import LossSpec
 from .evalchain import psnr, reconstruct
+from .mfn import FourierNet, GaborNet, KGaborNet
 from .networks import FFN, SIREN, WIRE, Positional_Encoder
 from .synthetic import make_kspace
 from .undersampling import Undersampler, parse_undersampling_argument
 
-MODELS = {"SIREN": SIREN, "FFN": FFN, "WIRE": WIRE}
+MODELS = {"SIREN": SIREN, "FFN": FFN, "WIRE": WIRE,  # train.py:55-68
+          "Fourier": FourierNet, "Gabor": GaborNet, "KGabor": KGaborNet}
+MFN_MODELS = ("Fourier", "Gabor", "KGabor")
 
 
 def get_config(path: str) -> dict:
@@ -96,7 +99,12 @@ class INRTrainer:
         self.encoder = Positional_Encoder(config["encoder"], device=self.device)
         self.model = MODELS[config["model"]](config["net"]).to(self.device)
         emb = config["encoder"]["embedding"]
-        if emb == "gauss":
+        self.is_mfn = config["model"] in MFN_MODELS
+        if self.is_mfn:  # the gauss encoder is fused into every filter: the model runs on raw coordinates
+            self.model.bind_encoder(self.encoder)
+            self.engine = self.model._engine()
+            self.enc_B = self.encoder.B.contiguous()
+        elif emb == "gauss":
             self.engine = self.model.fused_engine(config["encoder"]["embedding_size"])
             self.enc_B = self.encoder.B.contiguous()
         else:
@@ -130,6 +138,8 @@ class INRTrainer:
         self.use_tv = bool(config["use_tv"]) and self.mask is not None  # train.py:172-175: only inside the mask branch
         if self.use_tv and not self.per_coil:
             raise ValueError("use_tv needs per_coil batches: tv_loss views the batch as one [H,W,2] coil (train.py:175)")
+        if self.use_tv and self.is_mfn:
+            raise NotImplementedError("use_tv with the multiplicative filter networks")
         self.steps_per_epoch = math.ceil(self.n / self.bs)
         self.global_step = 0
         self._hdr_A = {}
@@ -214,7 +224,8 @@ class INRTrainer:
         outs = []
         for lo in range(0, self.n, chunk):
             hi = min(lo + chunk, self.n)
-            outs.append(self.engine.forward(self._inputs(lo, hi), self.enc_B, save=False))
+            o = self.engine.forward(self._inputs(lo, hi), self.enc_B, save=False)
+            outs.append(o[0] if self.is_mfn else o)
         return torch.cat(outs, 0)
 
     @torch.no_grad()

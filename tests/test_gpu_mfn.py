@@ -1,4 +1,5 @@
-"""Multiplicative filter networks (models/mfn.py: FourierNet, MultiscaleKFourier) on the HIP path."""
+"""Multiplicative filter networks (models/mfn.py: FourierNet, GaborNet, KGaborNet, MultiscaleKFourier,
+MultiscaleBoundedFourier) on the HIP path."""
 import json
 import os
 
@@ -34,13 +35,13 @@ def dev():
 
 
 def _classes():
-    from inr_mi355x.mfn import FourierNet, MultiscaleBoundedFourier, MultiscaleKFourier
+    from inr_mi355x.mfn import FourierNet, GaborNet, KGaborNet, MultiscaleBoundedFourier, MultiscaleKFourier
     b8 = META["BoundedFourier"]["bounds8"]
-    return {"Fourier": FourierNet, "MultiscaleKFourier": MultiscaleKFourier,
+    return {"Fourier": FourierNet, "MultiscaleKFourier": MultiscaleKFourier, "Gabor": GaborNet, "KGabor": KGaborNet,
             "BoundedFourier": lambda net: MultiscaleBoundedFourier(net, boundaries=b8)}
 
 
-@pytest.mark.parametrize("name", ["Fourier", "MultiscaleKFourier", "BoundedFourier"])
+@pytest.mark.parametrize("name", ["Fourier", "MultiscaleKFourier", "BoundedFourier", "Gabor", "KGabor"])
 def test_mfn_tier1_golden(dev, name):
     """Drop-in class on raw coordinates (encoder fused) + stock torch.optim.Adam vs the reference's vectors;
     dead layers of the multiscale net keep grad None and are not stepped (SURVEY A.4 #3)."""
@@ -57,7 +58,13 @@ def test_mfn_tier1_golden(dev, name):
         sd = model.state_dict()
         assert list(sd.keys()) == gold_keys
         for k in gold_keys:
-            assert torch.equal(sd[k], _t(arrs["sd/" + k])), k
+            if name in ("Gabor", "KGabor") and k.endswith("linear.weight") and k.startswith("filters"):
+                # weight *= scale * sqrt(gamma) (mfn.py:112): torch's own CPU kernels round this 1 ulp apart on
+                # different hosts (AVX512 Intel vs AMD), for the reference as well
+                torch.testing.assert_close(sd[k], _t(arrs["sd/" + k]), rtol=3e-7, atol=0)
+            else:
+                assert torch.equal(sd[k], _t(arrs["sd/" + k])), k
+        model.load_state_dict({k: _t(arrs["sd/" + k]) for k in gold_keys})  # pin the start to the vectors' own
         model = model.to(dev).bind_encoder(enc)
         optim = torch.optim.Adam(model.parameters(), lr=meta["lr"], betas=(0.9, 0.999), weight_decay=wd)
         for step in range(1, 4):
@@ -88,7 +95,7 @@ def test_mfn_tier1_golden(dev, name):
                                                msg=lambda m: f"{wd_tag} step{step} {k}: {m}")
 
 
-@pytest.mark.parametrize("name", ["Fourier", "MultiscaleKFourier", "BoundedFourier"])
+@pytest.mark.parametrize("name", ["Fourier", "MultiscaleKFourier", "BoundedFourier", "Gabor", "KGabor"])
 def test_mfn_tier2_fused_golden(dev, name):
     import inr_mi355x as M
     from inr_mi355x import _lib as L
@@ -99,7 +106,9 @@ def test_mfn_tier2_fused_golden(dev, name):
     for wd_tag, wd in (("wd0", 0.0), ("wd1", meta["wd1"])):
         torch.manual_seed(meta["seed"])
         enc = M.Positional_Encoder(meta["encoder"], device=dev)
-        model = _classes()[name](meta["net"]).to(dev).bind_encoder(enc)
+        model = _classes()[name](meta["net"])
+        model.load_state_dict({k[3:]: _t(v) for k, v in arrs.items() if k.startswith("sd/")})
+        model = model.to(dev).bind_encoder(enc)
         eng = model._engine()
         for step in range(1, 4):
             loss = eng.train_step(coords, enc.B.contiguous(), gt, M.LossSpec(L.LOSS_L2_HALF), dist=dist)
@@ -183,3 +192,26 @@ def test_mfn_full_size_vs_oracle(dev, shape):
         e_gpu, e_cpu = rel_l2(got, r64), rel_l2(r32, r64)
         assert e_gpu <= max(10 * e_cpu, 2e-5), (name, e_gpu, e_cpu)
     assert abs(float(loss) - float(l64)) <= max(10 * abs(float(l32) - float(l64)), 2e-5 * abs(float(l64)))
+
+
+@pytest.mark.parametrize("model", ["Fourier", "Gabor", "KGabor"])
+def test_single_scale_trainer_mfn_vs_oracle(dev, model):
+    """train.py's registry (train.py:63-68) also builds the filter networks for the single-scale loop:
+    INRTrainer against the oracle's restatement of that loop, same seeds, masked rows included."""
+    from inr_mi355x.synthetic import make_kspace
+    from inr_mi355x.train import INRTrainer
+    C, H, W = 2, 24, 20
+    image, coords, shape = make_kspace(C, H, W)
+    cfg = dict(model=model, loss="L2", lr=1e-3, batch_size=300, max_epoch=2, weight_decay=0.0, beta1=0.9, beta2=0.999,
+               net=dict(network_input_size=32, network_output_size=2, network_depth=3, network_width=48),
+               encoder=dict(embedding="gauss", scale=2, embedding_size=16, coordinates_size=3))
+    mask = torch.rand(coords.shape[0], generator=torch.Generator().manual_seed(2)) < 0.7
+    tr = INRTrainer(cfg, image, coords, shape, dev, seed=3, mask=mask)
+    sd = {k: v.detach().cpu().clone() for k, v in tr.model.state_dict().items()}
+    ref = O.train_single_scale(cfg, sd, tr.encoder.B.cpu(), coords, image, 7, mask=mask)
+    got = np.array([s[1] for s in tr.fit(7, log_every=1)])
+    np.testing.assert_allclose(got, np.array(ref), rtol=5e-5)
+    out = tr.predict_all().cpu()
+    with torch.no_grad():
+        want = O.model_forward(model, sd, O.encode(coords, tr.encoder.B.cpu(), "gauss"), cfg["net"])
+    torch.testing.assert_close(out, want, rtol=1e-3, atol=2e-5)

@@ -111,17 +111,17 @@ def test_wire_widths(dev, width):
 
 
 @pytest.mark.parametrize("width", [20, 48, 128, 160, 384])
-@pytest.mark.parametrize("kind", ["Fourier", "MultiscaleKFourier"])
+@pytest.mark.parametrize("kind", ["Fourier", "MultiscaleKFourier", "Gabor"])
 def test_mfn_widths(dev, kind, width):
     import inr_mi355x as M
     from inr_mi355x import _lib as L
-    from inr_mi355x.mfn import FourierNet, MultiscaleKFourier
-    multi = kind != "Fourier"
+    from inr_mi355x.mfn import FourierNet, GaborNet, MultiscaleKFourier
+    multi = kind == "MultiscaleKFourier"
     net = dict(network_input_size=32, network_output_size=2, network_depth=8 if multi else 3, network_width=width)
     enc_cfg = dict(embedding="gauss", scale=2, embedding_size=16, coordinates_size=3)
     torch.manual_seed(width)
     enc = M.Positional_Encoder(enc_cfg, device=dev)
-    mdl = (MultiscaleKFourier if multi else FourierNet)(net)
+    mdl = {"Fourier": FourierNet, "MultiscaleKFourier": MultiscaleKFourier, "Gabor": GaborNet}[kind](net)
     sd = {k: v.clone() for k, v in mdl.state_dict().items()}
     mdl = mdl.to(dev).bind_encoder(enc)
     B = 150

@@ -46,7 +46,7 @@ def test_plan_validation_and_sizes():
     assert "B = 0" in L.last_error()
     lib.inr_plan_destroy(plan)
     for bad, frag in ((dict(width=513), "width"), (dict(width=0), "width"), (dict(depth=1), "depth"), (dict(out_features=9), "out_features"),
-                      (dict(in_features=500), "2*enc_size"), (dict(kind=7), "kind")):
+                      (dict(in_features=500), "2*enc_size"), (dict(kind=99), "kind")):
         kw = dict(kind=L.KIND_SIREN, in_features=512, width=256, depth=5, out_features=2, last_act=L.ACT_TANH,
                   input=L.INPUT_GAUSS, enc_size=256, w0=30.0)
         kw.update(bad)
