@@ -147,6 +147,11 @@ int inr_pack_params(const inr_plan* plan, const float* params, float* packed, vo
 int inr_encode_gauss(const float* coords, const float* enc_B, int64_t B, int32_t E, float* out,
                      void* stream);
 
+/* Replaces Positional_Encoder.embedding, 'LogF' (networks.py:16,24-29): bands [n_bands] =
+ * 2^linspace(0, scale, n_bands); out [B, 6*n_bands] = per axis [sin(2 pi x_a b) | cos(2 pi x_a b)]. */
+int inr_encode_logf(const float* coords, const float* bands, int64_t B, int32_t n_bands, float* out,
+                    void* stream);
+
 /* Replaces model.forward (networks.py:121-124 / 67-69).  `x` is [B,in_features] (INR_INPUT_X) or
  * coords [B,3] (INR_INPUT_GAUSS, with enc_B [E,3]).  out [B,out_features].  `save` (may be NULL
  * for a no_grad forward, train.py:203-220) receives n_tiles * save_bytes_per_tile bytes. */

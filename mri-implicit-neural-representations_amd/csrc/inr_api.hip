@@ -399,6 +399,14 @@ int inr_pack_params(const inr_plan* plan, const float* params, float* packed, vo
   return INR_OK;
 }
 
+int inr_encode_logf(const float* coords, const float* bands, int64_t B, int32_t n_bands, float* out, void* stream) {
+  if (coords == nullptr || bands == nullptr || out == nullptr) return fail(INR_ERR_INVALID, "inr_encode_logf: null argument");
+  if (B <= 0 || n_bands <= 0) return fail(INR_ERR_INVALID, "inr_encode_logf: B %lld, n_bands %d", (long long)B, n_bands);
+  hipError_t e = inr::launch_encode_logf(coords, bands, B, n_bands, out, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "inr_encode_logf");
+  return INR_OK;
+}
+
 int inr_encode_gauss(const float* coords, const float* enc_B, int64_t B, int32_t E, float* out, void* stream) {
   if (coords == nullptr || enc_B == nullptr || out == nullptr)
     return fail(INR_ERR_INVALID, "inr_encode_gauss: null argument");

@@ -21,6 +21,8 @@ hipError_t launch_reduce_slabs(const NetDesc& nd, const float* slabs, int n_bloc
                                const float* params, const float* packed, hipStream_t st);
 hipError_t launch_adam_pack(const NetDesc& nd, float* params, const float* grads, float* m1, float* m2,
                             float* packed, const AdamArgs& aa, hipStream_t st);
+hipError_t launch_encode_logf(const float* coords, const float* bands, long long B, int nb, float* out,
+                              hipStream_t st);
 hipError_t launch_encode_gauss(const float* coords, const float* encB, long long B, int E, float* out,
                                hipStream_t st);
 hipError_t launch_loss_grad(const LossDesc& ld, const float* out, const float* gt, const float* kcoords,

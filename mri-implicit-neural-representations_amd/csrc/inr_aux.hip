@@ -319,6 +319,30 @@ __global__ __launch_bounds__(256) void encode_gauss_kernel(const float* __restri
   out[r * 2 * E + E + s] = cs;
 }
 
+// Positional_Encoder.embedding 'LogF' (networks.py:16,24-29): per axis a = 0..2,
+// [sin(2 pi x_a b) | cos(2 pi x_a b)] over the nb log-spaced bands b, concatenated: out [B, 6 nb].
+__global__ __launch_bounds__(256) void encode_logf_kernel(const float* __restrict__ coords,
+                                                          const float* __restrict__ bands, long long B, int nb,
+                                                          float* __restrict__ out) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= B * 3 * nb) return;
+  const long long r = idx / (3 * nb);
+  const int t = (int)(idx - r * 3 * nb), a = t / nb, s = t - a * nb;
+  const float ph = (6.283185307179586f * coords[3 * r + a]) * bands[s];  // (2 pi x_a) @ B^T with K = 1
+  float sn, cs;
+  sincosf(ph, &sn, &cs);
+  float* o = out + r * 6 * nb + a * 2 * nb;
+  o[s] = sn;
+  o[nb + s] = cs;
+}
+
+hipError_t launch_encode_logf(const float* coords, const float* bands, long long B, int nb, float* out,
+                              hipStream_t st) {
+  const long long n = B * 3 * nb;
+  hipLaunchKernelGGL(encode_logf_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, coords, bands, B, nb, out);
+  return hipGetLastError();
+}
+
 hipError_t launch_encode_gauss(const float* coords, const float* encB, long long B, int E, float* out,
                                hipStream_t st) {
   const long long n = B * E;

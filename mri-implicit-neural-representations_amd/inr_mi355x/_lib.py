@@ -49,6 +49,7 @@ SYMBOLS = {
     "inr_plan_launch_dims": (C.c_int, [_P, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "inr_pack_params": (C.c_int, [_P, _P, _P, _P]),
     "inr_encode_gauss": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P]),
+    "inr_encode_logf": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P]),
     "inr_forward": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, _P, _P, _P]),
     "inr_backward": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, _P, _P, _P, _P, _P]),
     "inr_loss_grad": (C.c_int, [C.POINTER(LossDesc), _P, _P, _P, _P, C.c_int64, _P, _P, _P]),

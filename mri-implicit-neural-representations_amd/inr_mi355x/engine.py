@@ -205,6 +205,16 @@ def encode_gauss(coords: torch.Tensor, enc_B: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def encode_logf(coords: torch.Tensor, bands: torch.Tensor) -> torch.Tensor:
+    """Positional_Encoder.embedding, 'LogF' (networks.py:24-29) on the device; bands = encoder.B [n,1]."""
+    lib = L.load()
+    B, nb = coords.shape[0], bands.numel()
+    out = torch.empty(B, 6 * nb, device=coords.device)
+    L.check(lib.inr_encode_logf(_ptr(coords, "coords"), _ptr(bands.reshape(-1), "bands"), B, nb, _ptr(out, "out"),
+                                torch.cuda.current_stream(coords.device).cuda_stream))
+    return out
+
+
 @dataclass
 class ConsistencySpec:
     """ConsistencyLoss(pairs) of train_kspace_multiscale.py:122,179 for one batch."""

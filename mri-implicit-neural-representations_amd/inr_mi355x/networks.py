@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib as L
-from .engine import MLPEngine, encode_gauss
+from .engine import encode_logf, MLPEngine, encode_gauss
 
 SIREN_W0 = 30.0  # SirenLayer(w0=30) for every layer, first included (networks.py:75,114-117)
 
@@ -44,12 +44,7 @@ class Positional_Encoder:
         if self.embedding_type == "gauss":
             return encode_gauss(x.contiguous(), self.B.contiguous())
         if self.embedding_type == "LogF":
-            # not on any BASELINE config; kept as plain tensor ops on the device (no HIP kernel yet)
-            parts = []
-            for a in range(3):
-                p = (2.0 * np.pi * x[:, a:a + 1]) @ self.B.T
-                parts.append(torch.cat((torch.sin(p), torch.cos(p)), dim=-1))
-            return torch.cat(parts, dim=-1)
+            return encode_logf(x.contiguous(), self.B.contiguous())
         return x
 
 

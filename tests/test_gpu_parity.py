@@ -291,3 +291,28 @@ def test_eval_chain_and_psnr(dev):
     p_dev = float(psnr(reconstruct(image.to(dev), shape, False), reconstruct(noisy.to(dev), shape, False)))
     p_cpu = float(O.psnr(ref, O.reconstruct(noisy, shape, False)))
     assert abs(p_dev - p_cpu) < 1e-2
+
+
+def test_logf_encoder_and_trainer(dev):
+    """Positional_Encoder 'LogF' (networks.py:16,24-29) through inr_encode_logf, and a SIREN fit on it
+    (unfused first layer: the [B,6*nb] features are materialised, as the reference does)."""
+    import inr_mi355x as M
+    from inr_mi355x.synthetic import make_kspace
+    from inr_mi355x.train import INRTrainer
+    cfgE = dict(embedding="LogF", scale=5, embedding_size=60, coordinates_size=3)
+    enc = M.Positional_Encoder(cfgE, device=dev)
+    assert enc.B.shape == (10, 1)
+    g = torch.Generator().manual_seed(0)
+    coords = torch.rand(3001, 3, generator=g) * 2 - 1
+    ref = O.encode(coords, enc.B.cpu(), "LogF")
+    got = enc.embedding(coords.to(dev)).cpu()
+    assert got.shape == (3001, 60)
+    torch.testing.assert_close(got, ref, rtol=0, atol=1e-5)  # phases up to 2 pi 32 ~ 200 rad: ulp(200) = 1.5e-5
+    image, kc, shape = make_kspace(2, 16, 12)
+    cfg = dict(model="SIREN", loss="L2", lr=1e-4, batch_size=150, max_epoch=2, weight_decay=0.0, beta1=0.9, beta2=0.999,
+               net=dict(network_input_size=60, network_output_size=2, network_depth=3, network_width=32), encoder=cfgE)
+    tr = INRTrainer(cfg, image, kc, shape, dev, seed=2)
+    sd = {k: v.detach().cpu().clone() for k, v in tr.model.state_dict().items()}
+    want = O.train_single_scale(cfg, sd, tr.encoder.B.cpu(), kc, image, 5)
+    got = np.array([s[1] for s in tr.fit(5, log_every=1)])
+    np.testing.assert_allclose(got, np.array(want), rtol=5e-5)
