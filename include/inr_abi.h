@@ -52,8 +52,11 @@ enum inr_kind {
                              of h whose dist lies outside [lo,hi] before each hidden Linear */
   INR_KIND_GABOR = 6,     /* models/mfn.py:133-162  GaborNet: GaborLayer filters (:96-131)
                              sin(F x + c) * exp(-0.5 * gamma_j * |x - mu_j|^2), mu and gamma trainable */
-  INR_KIND_KGABOR = 7     /* models/mfn.py:164-204  KGaborNet: same arithmetic (dist_to_center is passed to the
+  INR_KIND_KGABOR = 7,    /* models/mfn.py:164-204  KGaborNet: same arithmetic (dist_to_center is passed to the
                              filters but with_dist_filtering is never enabled); the dist argument is ignored */
+  INR_KIND_WIRE2D = 8     /* models/wire2d.py:62-117 WIRE2D / ComplexGaborLayer2D :3-60: two Linears per layer
+                             (linear, scale_orth), width NOT reduced; flat params interleave them per layer.
+                             inr_forward needs a save buffer (the orth terms travel through it). */
 };
 
 /* activation of the last layer */

@@ -105,6 +105,7 @@ static int create_mfn_plan(const inr_net_desc* d, inr_plan** out) {
   nd.gabor = gabor ? 1 : 0;
   nd.mu0 = (n + 1) + n + n_head_layers;
   nd.D = nd.mu0 + (gabor ? n + 1 : 0);
+  nd.ND = nd.D;
   const int TL = 32 * nd.NW;
   auto fill = [&](LayerDesc& L, int K, int M, bool filter, bool head) {
     L.K = K;
@@ -204,9 +205,10 @@ int inr_plan_create(const inr_net_desc* d, inr_plan** out) {
   if (d->kind == INR_KIND_FOURIER || d->kind == INR_KIND_MSFOURIER || d->kind == INR_KIND_MSBOUNDED ||
       d->kind == INR_KIND_GABOR || d->kind == INR_KIND_KGABOR)
     return create_mfn_plan(d, out);
-  if (d->kind != INR_KIND_SIREN && d->kind != INR_KIND_FFN && d->kind != INR_KIND_WIRE)
+  if (d->kind != INR_KIND_SIREN && d->kind != INR_KIND_FFN && d->kind != INR_KIND_WIRE && d->kind != INR_KIND_WIRE2D)
     return fail(INR_ERR_UNSUPPORTED, "inr_plan_create: kind %d has no kernel yet", d->kind);
-  const bool wire = d->kind == INR_KIND_WIRE;
+  const bool wire2d = d->kind == INR_KIND_WIRE2D;
+  const bool wire = d->kind == INR_KIND_WIRE || wire2d;
   // number of Linear layers: SIREN/FFN network_depth counts all of them (networks.py:114-117);
   // WIRE's counts the hidden complex layers only, total = depth + 2 (networks.py:234-250)
   const int D = wire ? d->depth + 2 : d->depth;
@@ -220,13 +222,16 @@ int inr_plan_create(const inr_net_desc* d, inr_plan** out) {
   // rows of the hidden activations as the kernel sees them: complex features are (Re, Im) row pairs
   const int hid = wire ? 2 * d->width : d->width;
   const int need = (hid + 31) / 32;
-  const int NB = wire ? pick_nb(need, {2, 4, 8, 12}) : pick_nb(need, {1, 2, 4, 8, 16});
+  const int NB = wire2d ? pick_nb(need, {2, 4, 8, 16})
+                        : (wire ? pick_nb(need, {2, 4, 8, 12}) : pick_nb(need, {1, 2, 4, 8, 16}));
   int NW;
   if (wire) {
     if (NB < 0)
       return fail(INR_ERR_UNSUPPORTED, "inr_plan_create: WIRE with %d complex hidden features (kernels are built for "
-                  "up to 192 = 384 interleaved rows; network_width 256 gives 181)", d->width);
-    NW = NB == 12 ? 3 : 4;
+                  "up to 192 = 384 interleaved rows, network_width 256 gives 181; WIRE2D: up to 256)", d->width);
+    NW = NB == 12 ? 3 : (NB == 16 ? 2 : 4);
+    if (wire2d && 2 * D - 1 > INR_MAX_LAYERS)
+      return fail(INR_ERR_INVALID, "inr_plan_create: WIRE2D depth %d", d->depth);
     if (d->input != INR_INPUT_X)
       return fail(INR_ERR_UNSUPPORTED, "inr_plan_create: WIRE takes raw coordinates (input must be INR_INPUT_X)");
     if (d->last_act != INR_ACT_ID) return fail(INR_ERR_INVALID, "inr_plan_create: WIRE's output is linear");
@@ -255,7 +260,9 @@ int inr_plan_create(const inr_net_desc* d, inr_plan** out) {
   nd.D = D;
   nd.NB = NB;
   nd.NW = NW;
-  nd.hact = wire ? ACT_GABOR : (d->kind == INR_KIND_SIREN ? ACT_SIN : ACT_RELU);
+  nd.hact = wire2d ? ACT_GABOR2D : (wire ? ACT_GABOR : (d->kind == INR_KIND_SIREN ? ACT_SIN : ACT_RELU));
+  nd.ND = wire2d ? 2 * D - 1 : D;
+  nd.orth0 = D;
   nd.last_act = d->last_act;
   nd.input = d->input;
   nd.E = d->enc_size;
@@ -264,8 +271,11 @@ int inr_plan_create(const inr_net_desc* d, inr_plan** out) {
   const int TL = 32 * NW;
   int poff = 0, goff = 0;
   int64_t pk = 0;
-  for (int l = 0; l < D; ++l) {
-    LayerDesc& L = nd.L[l];
+  // descriptors in flat-parameter order: WIRE2D interleaves linear / scale_orth of each layer (wire2d.py:40-47)
+  for (int t = 0; t < nd.ND; ++t) {
+    const int l = wire2d ? (t == nd.ND - 1 ? D - 1 : t / 2) : t;
+    const bool orth = wire2d && t != nd.ND - 1 && (t & 1);
+    LayerDesc& L = nd.L[orth ? nd.orth0 + l : l];
     const bool first = l == 0, last = l == D - 1;
     L.K = first ? d->in_features : hid;
     L.M = last ? d->out_features : hid;
@@ -323,9 +333,10 @@ int inr_plan_create(const inr_net_desc* d, inr_plan** out) {
   nd.P = poff;
   nd.slab_loss_off = goff;
   nd.slab_floats = round_up(goff + 4, 64);
-  const int ns = wire ? 3 : 2;
+  const int ns = wire2d ? 7 : (wire ? 3 : 2);
   nd.save_floats_per_tile = ns * (D - 1) * NB * 32 * TL + 4 * TL +
-                            (d->input == INR_INPUT_GAUSS ? nd.L[0].Kblk * 32 * TL : 0);
+                            (d->input == INR_INPUT_GAUSS ? nd.L[0].Kblk * 32 * TL : 0) +
+                            (wire2d ? NB * 32 * TL : 0);  // WIRE2D: copy of a layer's output gradient
   p->packed_floats = pk;
   *out = p;
   return INR_OK;
@@ -367,6 +378,13 @@ static int launch(const inr_plan* plan, const LossDesc& ld, const inr::MlpArgs& 
       case 4: e = inr::launch_mfn_nb4(nd, ld, a, mode, grid, st); break;
       case 8: e = inr::launch_mfn_nb8(nd, ld, a, mode, grid, st); break;
       default: e = inr::launch_mfn_nb16(nd, ld, a, mode, grid, st); break;
+    }
+  else if (nd.hact == ACT_GABOR2D)
+    switch (nd.NB) {
+      case 2: e = inr::launch_wire2d_nb2(nd, ld, a, mode, grid, st); break;
+      case 4: e = inr::launch_wire2d_nb4(nd, ld, a, mode, grid, st); break;
+      case 8: e = inr::launch_wire2d_nb8(nd, ld, a, mode, grid, st); break;
+      default: e = inr::launch_wire2d_nb16(nd, ld, a, mode, grid, st); break;
     }
   else if (nd.hact == ACT_GABOR)
     switch (nd.NB) {
@@ -422,6 +440,8 @@ int inr_forward(const inr_plan* plan, const float* params, const float* packed, 
     return fail(INR_ERR_INVALID, "inr_forward: null argument");
   if (plan->nd.mfn_n > 0) return fail(INR_ERR_INVALID, "inr_forward: multiplicative-filter plans use inr_forward_multi");
   if (plan->nd.input == IN_GAUSS && enc_B == nullptr) return fail(INR_ERR_INVALID, "inr_forward: enc_B is null");
+  if (plan->nd.hact == ACT_GABOR2D && save == nullptr)
+    return fail(INR_ERR_INVALID, "inr_forward: WIRE2D needs a save buffer (n_tiles * save_floats_per_tile floats)");
   if (B <= 0) return fail(INR_ERR_INVALID, "inr_forward: B = %lld", (long long)B);
   int64_t nt, nb;
   inr_plan_launch_dims(plan, B, &nt, &nb);

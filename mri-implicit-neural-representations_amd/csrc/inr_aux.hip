@@ -22,7 +22,7 @@ struct VirtualPos {
 __device__ __forceinline__ bool locate(const NetDesc& nd, int i, int& l, VirtualPos& vp) {
   vp.n = 0;
   vp.bias_row = -1;
-  for (l = 0; l < nd.D; ++l) {
+  for (l = 0; l < nd.ND; ++l) {
     const LayerDesc& L = nd.L[l];
     const int off = i - L.w_off;
     if (off >= 0 && off < L.wn) {
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(64) void gabor_m2_kernel(const NetDesc nd, const fl
 hipError_t launch_reduce_slabs(const NetDesc& nd, const float* slabs, int n_blocks, float* grads, float* loss_out,
                                const float* params, const float* packed, hipStream_t st) {
   bool all_real = true;  // ... and slab layout == flat layout (not the case for MFN: L[] order != flat order)
-  for (int l = 0; l < nd.D; ++l) all_real = all_real && nd.L[l].ltype == LT_REAL && nd.L[l].gw_off == nd.L[l].w_off;
+  for (int l = 0; l < nd.ND; ++l) all_real = all_real && nd.L[l].ltype == LT_REAL && nd.L[l].gw_off == nd.L[l].w_off;
   if (all_real) {  // slab offsets == flat offsets; slab_floats % 64 == 0 keeps every slab 16-byte aligned
     const int grid = (nd.P + 255) / 256;
     hipLaunchKernelGGL(reduce_slabs_real_kernel, dim3(grid), dim3(256), 0, st, slabs, n_blocks, nd.slab_floats, nd.P,
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void adam_pack_kernel(const NetDesc nd, float*
   float p = params[i];
   bool live = true;
   if (aa.has_dead) {
-    for (int l = 0; l < nd.D; ++l) {
+    for (int l = 0; l < nd.ND; ++l) {
       const LayerDesc& L = nd.L[l];
       if ((i >= L.w_off && i < L.w_off + L.wn) || (i >= L.b_off && i < L.b_off + L.bn)) live = L.live != 0;
     }
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) void adam_pack_kernel(const NetDesc nd, float*
     params[i] = p;
   }
   if (aa.all_real) {  // SIREN / FFN: one weight entry or one bias entry, no sign, no pair
-    for (int l = 0; l < nd.D; ++l) {
+    for (int l = 0; l < nd.ND; ++l) {
       const LayerDesc& L = nd.L[l];
       const int off = i - L.w_off;
       if (off >= 0 && off < L.wn) {
@@ -288,7 +288,7 @@ hipError_t launch_adam_pack(const NetDesc& nd, float* params, const float* grads
   AdamArgs aa = aa_in;
   aa.all_real = 1;
   aa.has_dead = 0;
-  for (int l = 0; l < nd.D; ++l) {
+  for (int l = 0; l < nd.ND; ++l) {
     aa.all_real = aa.all_real && (nd.L[l].ltype == LT_REAL || nd.L[l].ltype == LT_GABOR_MU);
     aa.has_dead = aa.has_dead || nd.L[l].live == 0;
   }

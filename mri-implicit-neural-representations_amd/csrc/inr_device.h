@@ -18,6 +18,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define ACT_RELU 3
 #define ACT_SIGMOID 4
 #define ACT_GABOR 5   // WIRE complex Gabor wavelet on interleaved (Re, Im) rows; hidden layers only
+#define ACT_GABOR2D 6 // WIRE2D (wire2d.py:49-60): the same with a second Linear `scale_orth` per layer feeding the
+                      // Gaussian window; L[orth0 + l] describes that Linear of layer l
 
 // how a layer's virtual real matrix [M x K] maps to the flat parameters
 #define LT_REAL 0          // weight [M,K] f32, bias [M]                       (SIREN / FFN)
@@ -55,7 +57,9 @@ struct LayerDesc {
 };
 
 struct NetDesc {
-  int D;             // number of Linear layers
+  int D;             // number of Linear layers the network chains (MFN: all descriptors)
+  int ND;            // number of LayerDesc entries in L[] (== D except WIRE2D: D + D - 1)
+  int orth0;         // WIRE2D: L[orth0 + l] = scale_orth of layer l (0 <= l < D - 1)
   int NB;            // hidden width / 32
   int hact;          // hidden activation (ACT_SIN / ACT_RELU)
   int last_act;

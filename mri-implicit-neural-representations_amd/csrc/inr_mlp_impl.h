@@ -73,6 +73,27 @@ __device__ __forceinline__ void act_gabor(float za, float zb, float omega, float
   dB = half ? kb * yi : fmaf(ka, yi, omega * yr);   // d(y_i)/d(row)
 }
 
+// WIRE2D (wire2d.py:49-60): y = exp(j omega lin) * exp(-s0^2 (|lin|^2 + |orth|^2)), orth = u + jv the second
+// Linear of the layer.  o = this lane's own orth row (u for half 0, v for half 1), q = u^2 + v^2 of the pair.
+// Besides the Jacobian entries of the lane's lin row (as act_gabor) it emits those of its orth row:
+//   dZ_orth[row] = p * dA2 + q * dB2,   d y / d o = -2 s0^2 o y.
+__device__ __forceinline__ void act_gabor2d(float za, float zb, float o, float q, float omega, float s0, int half,
+                                            float& h, float& dA, float& dB, float& dA2, float& dB2) {
+  float sn, cs;
+  sincos_cw(omega * za, sn, cs);
+  const float s2 = s0 * s0;
+  const float Ef = expf(-omega * zb);                          // |exp(1j*omega*lin)|
+  const float G = expf(-s2 * ((za * za + zb * zb) + q));       // gauss_term
+  const float yr = (Ef * cs) * G, yi = (Ef * sn) * G;
+  h = half ? yi : yr;
+  const float ka = -2.f * s2 * za, kb = -omega - 2.f * s2 * zb;
+  dA = half ? kb * yr : fmaf(ka, yr, -omega * yi);
+  dB = half ? kb * yi : fmaf(ka, yi, omega * yr);
+  const float ko = -2.f * s2 * o;
+  dA2 = ko * yr;
+  dB2 = ko * yi;
+}
+
 __device__ __forceinline__ void act_fwd_rt(int act, float z, float w0, float& h, float& d) {
   switch (act) {
     case ACT_SIN: act_fwd<ACT_SIN>(z, w0, h, d); break;
@@ -269,11 +290,15 @@ struct ActParams {
 };
 
 template <int HACT>
-__device__ __forceinline__ void lazy_act(const float (&z)[4], const float (&zp)[4], const ActParams& ap, int half,
-                                         float (&h)[4], float (&d)[4], float (&d2)[4]) {
+__device__ __forceinline__ void lazy_act(const float (&z)[4], const float (&zp)[4], const float (&zo)[4],
+                                         const float (&zq)[4], const ActParams& ap, int half, float (&h)[4],
+                                         float (&d)[4], float (&d2)[4], float (&d3)[4], float (&d4)[4]) {
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    if (HACT == ACT_GABOR) {
+    d3[e] = d4[e] = 0.f;
+    if (HACT == ACT_GABOR2D) {
+      act_gabor2d(z[e], zp[e], zo[e], zq[e], ap.w0, ap.s0, half, h[e], d[e], d2[e], d3[e], d4[e]);
+    } else if (HACT == ACT_GABOR) {
       // z = Re row value, zp = Im row value of the pair (both halves read both rows)
       act_gabor(z[e], zp[e], ap.w0, ap.s0, half, h[e], d[e], d2[e]);
     } else {
@@ -299,27 +324,45 @@ __device__ __forceinline__ void load_z(float (&z)[4], float (&zp)[4], const floa
   }
 }
 
+// WIRE2D: own orth row value and the pair's u^2+v^2 of group s4, from the stash of the producing layer
+template <int TL, bool ON>
+__device__ __forceinline__ void load_oq(float (&zo)[4], float (&zq)[4], const float* __restrict__ svo, int hsz, int s4) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    zo[e] = ON ? svo[(8 * s4 + 2 * e) * TL] : 0.f;
+    zq[e] = ON ? svo[hsz + (8 * s4 + 2 * e) * TL] : 0.f;
+  }
+}
+
 template <int NBOUT, int TL, int HACT, bool SAVE>
 __device__ __forceinline__ void fwd_group(f32x16 (&acc)[NBOUT], const f32x4 (&a_use)[NBOUT],
                                           f32x4 (&a_load)[NBOUT], const f32x4* p_next, float (&z_buf)[4],
-                                          float (&zp_buf)[4], const float* Rcol, int s4_next2, int s4,
+                                          float (&zp_buf)[4], float (&zo_buf)[4], float (&zq_buf)[4],
+                                          const float* Rcol, int s4_next2, int s4,
                                           const ActParams& ap, int half, float* __restrict__ svl, int hsz,
                                           const float (&h_use)[4], const float (&d_use)[4],
-                                          const float (&d2_use)[4], float (&h_load)[4], float (&d_load)[4],
-                                          float (&d2_load)[4]) {
+                                          const float (&d2_use)[4], const float (&d3_use)[4],
+                                          const float (&d4_use)[4], float (&h_load)[4], float (&d_load)[4],
+                                          float (&d2_load)[4], float (&d3_load)[4], float (&d4_load)[4]) {
   // z_buf holds the pre-activations of group s4+1 (fetched one group ago); they become h_load/d_load
   // during this group's MFMAs, and z_buf is refilled with group s4+2.
+  constexpr bool G2D = HACT == ACT_GABOR2D;
   load_afrag<NBOUT>(a_load, p_next);
-  float z_next[4], zp_next[4];
-  load_z<HACT == ACT_GABOR>(z_next, zp_next, Rcol, s4_next2, half);
+  float z_next[4], zp_next[4], zo_next[4], zq_next[4];
+  load_z<HACT == ACT_GABOR || G2D>(z_next, zp_next, Rcol, s4_next2, half);
+  load_oq<TL, G2D>(zo_next, zq_next, svl + 5 * hsz, hsz, s4_next2);
   __builtin_amdgcn_sched_barrier(0);  // operands of the following groups are in flight behind the MFMAs
-  lazy_act<HACT>(z_buf, zp_buf, ap, half, h_load, d_load, d2_load);
+  lazy_act<HACT>(z_buf, zp_buf, zo_buf, zq_buf, ap, half, h_load, d_load, d2_load, d3_load, d4_load);
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     if (SAVE) {
       svl[(8 * s4 + 2 * e) * TL] = h_use[e];
       svl[hsz + (8 * s4 + 2 * e) * TL] = d_use[e];
-      if (HACT == ACT_GABOR) svl[2 * hsz + (8 * s4 + 2 * e) * TL] = d2_use[e];
+      if (HACT == ACT_GABOR || G2D) svl[2 * hsz + (8 * s4 + 2 * e) * TL] = d2_use[e];
+      if (G2D) {
+        svl[3 * hsz + (8 * s4 + 2 * e) * TL] = d3_use[e];
+        svl[4 * hsz + (8 * s4 + 2 * e) * TL] = d4_use[e];
+      }
     }
 #pragma unroll
     for (int m = 0; m < NBOUT; ++m) acc[m] = mfma32(a_use[m][e], h_use[e], acc[m]);
@@ -330,6 +373,8 @@ __device__ __forceinline__ void fwd_group(f32x16 (&acc)[NBOUT], const f32x4 (&a_
   for (int e = 0; e < 4; ++e) {
     z_buf[e] = z_next[e];
     zp_buf[e] = zp_next[e];
+    zo_buf[e] = zo_next[e];
+    zq_buf[e] = zq_next[e];
   }
 }
 
@@ -340,23 +385,106 @@ __device__ __forceinline__ void fwd_layer(f32x16 (&acc)[NBOUT], const float* R, 
   const f32x4* p = reinterpret_cast<const f32x4*>(wp) + lane;
   constexpr int n4 = NB * 4;  // K = 32*NB features -> 16*NB k-steps -> 4*NB groups of 4 (even)
   constexpr int hsz = NB * 32 * TL;
-  constexpr bool PAIR = HACT == ACT_GABOR;
+  constexpr bool G2D = HACT == ACT_GABOR2D;  // always called with SAVE: its orth inputs live in the stash
+  constexpr bool PAIR = HACT == ACT_GABOR || G2D;
   const float* Rcol = R + col;
-  float* svl = SAVE ? sv + half * TL + wcol : nullptr;  // stash row k = 8*s4 + 2e + half
+  float* svl = (SAVE || G2D) ? sv + half * TL + wcol : nullptr;  // stash row k = 8*s4 + 2e + half
   f32x4 A0[NBOUT], A1[NBOUT];
-  float Z[4], ZP[4], H0[4], D0[4], E0[4], H1[4], D1[4], E1[4];
+  float Z[4], ZP[4], ZO[4], ZQ[4], H0[4], D0[4], E0[4], F0[4], G0[4], H1[4], D1[4], E1[4], F1[4], G1[4];
   load_afrag<NBOUT>(A0, p);
   load_z<PAIR>(Z, ZP, Rcol, 0, half);
-  lazy_act<HACT>(Z, ZP, ap, half, H0, D0, E0);
+  load_oq<TL, G2D>(ZO, ZQ, svl + 5 * hsz, hsz, 0);
+  lazy_act<HACT>(Z, ZP, ZO, ZQ, ap, half, H0, D0, E0, F0, G0);
   load_z<PAIR>(Z, ZP, Rcol, 1, half);  // group 1 (n4 >= 4)
+  load_oq<TL, G2D>(ZO, ZQ, svl + 5 * hsz, hsz, 1);
 #pragma unroll 1
   for (int s4 = 0; s4 < n4; s4 += 2) {
     const int n2 = (s4 + 2 < n4) ? (s4 + 2) : s4;
     const int n3 = (s4 + 3 < n4) ? (s4 + 3) : s4;
-    fwd_group<NBOUT, TL, HACT, SAVE>(acc, A0, A1, p + (size_t)(s4 + 1) * NBOUT * 64, Z, ZP, Rcol, n2, s4, ap, half, svl,
-                                     hsz, H0, D0, E0, H1, D1, E1);
-    fwd_group<NBOUT, TL, HACT, SAVE>(acc, A1, A0, p + (size_t)n2 * NBOUT * 64, Z, ZP, Rcol, n3, s4 + 1, ap, half, svl,
-                                     hsz, H1, D1, E1, H0, D0, E0);
+    fwd_group<NBOUT, TL, HACT, SAVE>(acc, A0, A1, p + (size_t)(s4 + 1) * NBOUT * 64, Z, ZP, ZO, ZQ, Rcol, n2, s4, ap,
+                                     half, svl, hsz, H0, D0, E0, F0, G0, H1, D1, E1, F1, G1);
+    fwd_group<NBOUT, TL, HACT, SAVE>(acc, A1, A0, p + (size_t)n2 * NBOUT * 64, Z, ZP, ZO, ZQ, Rcol, n3, s4 + 1, ap,
+                                     half, svl, hsz, H1, D1, E1, F1, G1, H0, D0, E0, F0, G0);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// WIRE2D helpers.  acc += A . h^T with h read back from the stash (natural k order: k-step s -> rows 2s, 2s+1),
+// the second Linear of a layer; its epilogue leaves the orth pre-activations and u^2+v^2 of each pair in the
+// stash slots the next layer's lazy activation reads.
+// ---------------------------------------------------------------------------------------------
+template <int NB, int TL>
+__device__ __forceinline__ void gemm_stash_nat(f32x16 (&acc)[NB], const float* __restrict__ wp,
+                                               const float* __restrict__ sv_h, int wcol, int lane) {
+  const int half = lane >> 5;
+  const float* svl = sv_h + half * TL + wcol;
+  const f32x4* p = reinterpret_cast<const f32x4*>(wp) + lane;
+  constexpr int n4 = NB * 4;
+  f32x4 A0[NB], A1[NB];
+  float B0[4], B1[4];
+  load_afrag<NB>(A0, p);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) B0[e] = svl[(2 * e) * TL];
+#pragma unroll 1
+  for (int s4 = 0; s4 < n4; s4 += 2) {
+    const int n2 = (s4 + 2 < n4) ? (s4 + 2) : s4;
+    load_afrag<NB>(A1, p + (size_t)(s4 + 1) * NB * 64);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) B1[e] = svl[(8 * (s4 + 1) + 2 * e) * TL];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int m = 0; m < NB; ++m) acc[m] = mfma32(A0[m][e], B0[e], acc[m]);
+    __builtin_amdgcn_sched_barrier(0);
+    load_afrag<NB>(A0, p + (size_t)n2 * NB * 64);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) B0[e] = svl[(8 * n2 + 2 * e) * TL];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int m = 0; m < NB; ++m) acc[m] = mfma32(A1[m][e], B1[e], acc[m]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// registers (2p, 2p+1) of a lane are the (u, v) rows of one complex feature
+template <int NB, int TL>
+__device__ __forceinline__ void orth_epilogue(const f32x16 (&acc)[NB], const float* __restrict__ bias,
+                                              float* __restrict__ svO, int wcol, int lane) {
+  const int half = lane >> 5;
+  constexpr int hsz = NB * 32 * TL;
+  float* so = svO + (4 * half) * TL + wcol;
+  const float* bl = bias + 4 * half;
+#pragma unroll
+  for (int m = 0; m < NB; ++m) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(bl + 32 * m + 8 * g);
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = acc[m][4 * g + j] + b4[j];
+      const float q01 = v[0] * v[0] + v[1] * v[1], q23 = v[2] * v[2] + v[3] * v[3];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        so[(32 * m + 8 * g + j) * TL] = v[j];
+        so[hsz + (32 * m + 8 * g + j) * TL] = j < 2 ? q01 : q23;
+      }
+    }
+  }
+}
+
+// wave image <-> global scratch [NB*32 rows][TL] (own column): the layer's output gradient is needed twice
+template <int NB, int TL, bool TO_GLOBAL>
+__device__ __forceinline__ void image_copy(float* R, float* __restrict__ G, int wcol, int lane) {
+  const int half = lane >> 5, col = lane & 31;
+#pragma unroll 8
+  for (int r = half; r < NB * 32; r += 2) {
+    if (TO_GLOBAL)
+      G[r * TL + wcol] = R[swz(r, col)];
+    else
+      R[swz(r, col)] = G[r * TL + wcol];
   }
 }
 
@@ -609,8 +737,10 @@ template <int NB, int NW, int INMODE, int HACT, int MODE>
 __global__ __launch_bounds__(NW * 64) void inr_mlp_kernel(const NetDesc nd, const LossDesc ld, const MlpArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int TL = NW * 32;                      // coordinates per tile
-  constexpr bool PAIR = HACT == ACT_GABOR;         // complex layers as interleaved (Re, Im) rows
-  constexpr int NS = PAIR ? 3 : 2;                 // stashed tensors per hidden layer
+  constexpr bool G2D = HACT == ACT_GABOR2D;        // WIRE2D: a second Linear (scale_orth) per layer
+  constexpr bool PAIR = HACT == ACT_GABOR || G2D;  // complex layers as interleaved (Re, Im) rows
+  // stashed tensors per hidden layer: h, act' (SIREN/FFN) | h, dA, dB (WIRE) | h, dA, dB, dA2, dB2, orth, u^2+v^2 (2D)
+  constexpr int NS = G2D ? 7 : (PAIR ? 3 : 2);
   const int tid = threadIdx.x;
   const int lane = tid & 63, w = tid >> 6;
   const int half = lane >> 5, col = lane & 31;
@@ -636,11 +766,12 @@ __global__ __launch_bounds__(NW * 64) void inr_mlp_kernel(const NetDesc nd, cons
     const long long row0 = (long long)tile * TL;
     const long long crow = row0 + wcol;
     const bool valid = crow < a.B;
-    const bool saving = (MODE != MODE_FWD) || (a.save != nullptr);
+    const bool saving = G2D || (MODE != MODE_FWD) || (a.save != nullptr);  // WIRE2D: the API insists on a buffer
     float* sv = a.save;
     if (saving) sv += (size_t)(a.save_by_block ? blockIdx.x : tile) * nd.save_floats_per_tile;
     float* sv_last = sv + (size_t)NS * (D - 1) * HSZ;  // [4][TL]: act'(z_last) of output rows 0..3
     float* sv_enc = sv_last + 4 * TL;                   // [Kblk0*32][TL] encoder features (gauss mode)
+    float* sv_g = sv_last + 4 * TL;                     // WIRE2D (never gauss): copy of a layer's output gradient
 
     // ================================ forward =================================
     INR_STAMP(0);
@@ -669,6 +800,14 @@ __global__ __launch_bounds__(NW * 64) void inr_mlp_kernel(const NetDesc nd, cons
                            lane);
         }
         acc_to_lds<NB, true>(acc, R, a.packed + L0.pbias_off, lane);
+        if (G2D) {  // orth_0 = V_0 x + c_0 -> stash slots 5, 6 of layer 0
+          const LayerDesc& O0 = nd.L[nd.orth0];
+#pragma unroll
+          for (int m = 0; m < NB; ++m) acc[m] = zero16();
+          fwd_layer0_x<NB>(acc, a.packed + O0.pf_off, a.x + (size_t)(valid ? crow : 0) * O0.K, valid, O0.K, O0.Kpad8,
+                           lane);
+          orth_epilogue<NB, TL>(acc, a.packed + O0.pbias_off, sv + (size_t)5 * HSZ, wcol, lane);
+        }
       }
       INR_STAMP(1);
       for (int l = 1; l < D - 1; ++l) {
@@ -683,6 +822,13 @@ __global__ __launch_bounds__(NW * 64) void inr_mlp_kernel(const NetDesc nd, cons
         else
           fwd_layer<NB, NB, TL, HACT, false>(acc, R, a.packed + Ll.pf_off, ap, nullptr, wcol, lane);
         acc_to_lds<NB, true>(acc, R, a.packed + Ll.pbias_off, lane);
+        if (G2D) {  // orth_l = V_l h_{l-1} + c_l with h_{l-1} back from the stash -> slots 5, 6 of layer l
+          const LayerDesc& Ol = nd.L[nd.orth0 + l];
+#pragma unroll
+          for (int m = 0; m < NB; ++m) acc[m] = zero16();
+          gemm_stash_nat<NB, TL>(acc, a.packed + Ol.pf_off, sh, wcol, lane);
+          orth_epilogue<NB, TL>(acc, a.packed + Ol.pbias_off, sv + (size_t)(NS * l + 5) * HSZ, wcol, lane);
+        }
         INR_STAMP(1 + l);
       }
       // last layer: out_f <= 4 rows -> registers 0..3 of the lane-half-0 lanes of one row block
@@ -763,6 +909,7 @@ __global__ __launch_bounds__(NW * 64) void inr_mlp_kernel(const NetDesc nd, cons
         const LayerDesc& Ll = nd.L[l];
 #pragma unroll
         for (int m = 0; m < NB; ++m) gacc[m] = zero16();
+        if (G2D) image_copy<NB, TL, true>(R, sv_g, wcol, lane);  // dH_l is needed again for the orth Linear
         // dZ_l = dH_l * act'(z_l) (in place), dH_{l-1} = W_l^T dZ_l
         bwd_dx<NB, TL, PAIR, true>(gacc, R, a.packed + Ll.pb_off, Ll.Mpad8, sv + (size_t)(NS * l + 1) * HSZ, wcol,
                                    lane);
@@ -777,6 +924,20 @@ __global__ __launch_bounds__(NW * 64) void inr_mlp_kernel(const NetDesc nd, cons
         }
         INR_STAMP(16 + 4 * l);
         __syncthreads();
+        if (G2D) {  // second Linear of the layer: dZ_orth = J_orth dH_l, dH_{l-1} += V_l^T dZ_orth, dV_l
+          const LayerDesc& Ol = nd.L[nd.orth0 + l];
+          image_copy<NB, TL, false>(R, sv_g, wcol, lane);
+          bwd_dx<NB, TL, PAIR, true>(gacc, R, a.packed + Ol.pb_off, Ol.Mpad8, sv + (size_t)(NS * l + 3) * HSZ, wcol,
+                                     lane);
+          __syncthreads();
+          {
+            BSrcStash<TL> bs{sv + (size_t)(NS * (l - 1)) * HSZ};
+            for (int n = w; n < Ol.Kblk; n += NW)
+              dw_pass<NB, TL, HFULL, BSrcStash<TL>>(lds, RS, bs, n, slab + Ol.gw_off, slab + Ol.gb_off, Ol.M, Ol.K,
+                                                    first, n == 0, lane);
+          }
+          __syncthreads();
+        }
         if (l == 1)
           acc_times_d_to_lds<NB, TL, PAIR>(gacc, R, sv + (size_t)1 * HSZ, sv + (size_t)2 * HSZ, wcol, lane);  // dZ_0
         else
@@ -801,6 +962,16 @@ __global__ __launch_bounds__(NW * 64) void inr_mlp_kernel(const NetDesc nd, cons
         }
         INR_STAMP(41);
         __syncthreads();  // images are overwritten by the next tile's forward / dZ_last
+        if (G2D) {  // dV_0 from dZ_0,orth = J_orth,0 dH_0 (the accumulators still hold dH_0)
+          const LayerDesc& O0 = nd.L[nd.orth0];
+          acc_times_d_to_lds<NB, TL, PAIR>(gacc, R, sv + (size_t)3 * HSZ, sv + (size_t)4 * HSZ, wcol, lane);
+          __syncthreads();
+          BSrcX bs{a.x, row0, a.B, O0.K};
+          for (int n = w; n < O0.Kblk; n += NW)
+            dw_pass<NB, TL, HFULL, BSrcX>(lds, RS, bs, n, slab + O0.gw_off, slab + O0.gb_off, O0.M, O0.K, first, n == 0,
+                                          lane);
+          __syncthreads();
+        }
         INR_STAMP(42);
       }
       first = false;

@@ -1,7 +1,7 @@
 // inr_mlp_inst.h -- instantiates the fused MLP kernel for one hidden block count (INR_NB blocks of
 // 32 rows), one workgroup shape (INR_NW waves) and one family, and exposes a mode / input
 // dispatcher.  Included by inr_mlp_nb*.hip / inr_wire_nb*.hip (one translation unit each).
-#ifdef INR_FAMILY_WIRE
+#if defined(INR_FAMILY_WIRE) || defined(INR_FAMILY_WIRE2D)
 #define INR_DW_ATTR __noinline__  // WIRE kernels are register-bound: keep the dW pass out of their allocation
 #endif
 #include "inr_mlp_impl.h"
@@ -21,7 +21,10 @@ static hipError_t dispatch_mode(const NetDesc& nd, const LossDesc& ld, const Mlp
 
 hipError_t INR_LAUNCH_NAME(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int mode, int grid,
                            hipStream_t st) {
-#ifdef INR_FAMILY_WIRE
+#ifdef INR_FAMILY_WIRE2D
+  if (nd.input != IN_X) return hipErrorInvalidValue;
+  return dispatch_mode<INR_NB, INR_NW, IN_X, ACT_GABOR2D>(nd, ld, a, mode, grid, st);
+#elif defined(INR_FAMILY_WIRE)
   // WIRE takes raw coordinates (encoder.embedding: none in the reference's WIRE configs)
   if (nd.input != IN_X) return hipErrorInvalidValue;
   return dispatch_mode<INR_NB, INR_NW, IN_X, ACT_GABOR>(nd, ld, a, mode, grid, st);

@@ -1,0 +1,6 @@
+// WIRE2D with 17..64 complex hidden features
+#define INR_NB 4
+#define INR_NW 4
+#define INR_FAMILY_WIRE2D 1
+#define INR_LAUNCH_NAME launch_wire2d_nb4
+#include "inr_mlp_inst.h"

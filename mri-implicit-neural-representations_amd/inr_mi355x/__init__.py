@@ -2,5 +2,5 @@
 luisdavid64/MRI-Implicit-Neural-Representations (SIREN / FFN today; see DESIGN.md for the
 scope table).  The arithmetic lives in lib/libinr_mi355x.so (hand-written gfx950 HIP kernels
 behind the C-ABI of include/inr_abi.h); this package is the thin host side."""
-from .networks import SIREN, FFN, WIRE, Positional_Encoder  # noqa: F401
+from .networks import SIREN, FFN, WIRE, WIRE2D, Positional_Encoder  # noqa: F401
 from .engine import MLPEngine, LossSpec, encode_gauss  # noqa: F401

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("INR_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "lib", "libinr_mi355x.so")
 
 # enums (include/inr_abi.h)
-KIND_SIREN, KIND_FFN, KIND_WIRE, KIND_FOURIER, KIND_MSFOURIER, KIND_MSBOUNDED, KIND_GABOR, KIND_KGABOR = range(8)
+KIND_SIREN, KIND_FFN, KIND_WIRE, KIND_FOURIER, KIND_MSFOURIER, KIND_MSBOUNDED, KIND_GABOR, KIND_KGABOR, KIND_WIRE2D = range(9)
 ACT_ID, ACT_SIN, ACT_TANH, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3, 4
 INPUT_X, INPUT_GAUSS = 0, 1
 LOSS_L2_HALF, LOSS_L1_HALF, LOSS_TANH, LOSS_LOGSPACE, LOSS_HDR = 0, 1, 2, 3, 4

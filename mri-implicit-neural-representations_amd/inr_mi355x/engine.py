@@ -70,6 +70,7 @@ class MLPEngine:
         self.slab_floats = int(sz.slab_floats)
         self.in_features, self.out_features = in_features, out_features
         self.input_mode = input_mode
+        self.always_save = kind == L.KIND_WIRE2D  # its orth terms travel through the save buffer even when not training
         self.params: Optional[torch.Tensor] = None
         self.grads = self.exp_avg = self.exp_avg_sq = self.packed = None
         self._save = self._slabs = self._loss = None
@@ -128,7 +129,7 @@ class MLPEngine:
         B = x.shape[0]
         nt, _ = self.launch_dims(B)
         out = torch.empty(B, self.out_features, device=x.device)
-        sv = self._ws_save(nt) if save else None
+        sv = self._ws_save(nt) if (save or self.always_save) else None
         L.check(self.lib.inr_forward(self.plan, _ptr(self.params, "params"), _ptr(self.packed, "packed"),
                                      _ptr(x, "x"), _ptr(enc_B, "enc_B"), B, _ptr(out, "out"),
                                      _ptr(sv, "save"), self._stream()))

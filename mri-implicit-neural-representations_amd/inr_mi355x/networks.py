@@ -272,3 +272,56 @@ class WIRE(_FlatModel):
         return MLPEngine(L.KIND_WIRE, self.in_features, self.hidden_features, self.hidden_layers, self.out_features,
                          L.ACT_ID, L.INPUT_X, 0, 0.0, float(self.first_omega_0), float(self.hidden_omega_0),
                          float(self.scale))
+
+
+class _GaborLayer2DShell(nn.Module):
+    """net.k of WIRE2D: frozen omega_0 / scale_0, then linear and scale_orth (wire2d.py:36-47)."""
+
+    def __init__(self, omega0: float, sigma0: float, lin: _Holder, orth: _Holder):
+        super().__init__()
+        self.omega_0 = nn.Parameter(omega0 * torch.ones(1), False)
+        self.scale_0 = nn.Parameter(sigma0 * torch.ones(1), False)
+        self.linear = lin
+        self.scale_orth = orth
+
+
+class WIRE2D(_FlatModel):
+    """wire2d.py:62-117.  ComplexGaborLayer2D (:3-60): y = exp(j w0 lin) * exp(-s0^2 (|lin|^2 + |orth|^2)) with a
+    second Linear ``scale_orth`` per layer; the hidden width is NOT reduced (:76); output is the real part.
+    ``last_tanh`` (a complex Tanh before ``.real``, :106-107) has no kernel yet and raises."""
+
+    def __init__(self, params):
+        super().__init__()
+        if params.get("last_tanh", False):
+            raise NotImplementedError("WIRE2D last_tanh (complex Tanh before .real)")
+        self.hidden_layers = params["network_depth"]
+        self.hidden_features = params["network_width"]
+        self.in_features = params["network_input_size"]
+        self.out_features = params["network_output_size"]
+        self.first_omega_0 = params["first_omega_0"]
+        self.hidden_omega_0 = params["hidden_omega_0"]
+        self.scale = params["scale"]
+        hid = self.hidden_features
+        tensors = []
+        for k in range(self.hidden_layers + 1):  # linear, then scale_orth: the RNG order of wire2d.py:40-47
+            fin, dt = (self.in_features, torch.float) if k == 0 else (hid, torch.cfloat)
+            lin = nn.Linear(fin, hid, dtype=dt)
+            orth = nn.Linear(fin, hid, dtype=dt)
+            tensors += [lin.weight.detach(), lin.bias.detach(), orth.weight.detach(), orth.bias.detach()]
+        fin = nn.Linear(hid, self.out_features, dtype=torch.cfloat)
+        tensors += [fin.weight.detach(), fin.bias.detach()]
+        ps = self._flatten(tensors)
+        mods = []
+        for k in range(self.hidden_layers + 1):
+            om = self.first_omega_0 if k == 0 else self.hidden_omega_0
+            mods.append(_GaborLayer2DShell(om, self.scale, _Holder(ps[4 * k], ps[4 * k + 1]),
+                                           _Holder(ps[4 * k + 2], ps[4 * k + 3])))
+        mods.append(_Holder(ps[-2], ps[-1]))
+        self.net = nn.Sequential(*mods)
+
+    def _make_engine(self, input_mode: int, enc_size: int) -> MLPEngine:
+        if input_mode != L.INPUT_X:
+            raise NotImplementedError("WIRE2D takes raw coordinates (encoder.embedding: none)")
+        return MLPEngine(L.KIND_WIRE2D, self.in_features, self.hidden_features, self.hidden_layers, self.out_features,
+                         L.ACT_ID, L.INPUT_X, 0, 0.0, float(self.first_omega_0), float(self.hidden_omega_0),
+                         float(self.scale))

@@ -28,11 +28,11 @@ from . import _lib as L
 from .engine import LossSpec
 from .evalchain import psnr, reconstruct
 from .mfn import FourierNet, GaborNet, KGaborNet
-from .networks import FFN, SIREN, WIRE, Positional_Encoder
+from .networks import FFN, SIREN, WIRE, WIRE2D, Positional_Encoder
 from .synthetic import make_kspace
 from .undersampling import Undersampler, parse_undersampling_argument
 
-MODELS = {"SIREN": SIREN, "FFN": FFN, "WIRE": WIRE,  # train.py:55-68
+MODELS = {"SIREN": SIREN, "FFN": FFN, "WIRE": WIRE, "WIRE2D": WIRE2D,  # train.py:55-68
           "Fourier": FourierNet, "Gabor": GaborNet, "KGabor": KGaborNet}
 MFN_MODELS = ("Fourier", "Gabor", "KGabor")
 

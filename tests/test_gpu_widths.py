@@ -110,6 +110,29 @@ def test_wire_widths(dev, width):
     _check(out, loss, eng.grads.cpu(), r32, r64)
 
 
+@pytest.mark.parametrize("width", [8, 24, 64, 100, 256])
+def test_wire2d_widths(dev, width):
+    """WIRE2D keeps network_width complex features (wire2d.py:76): 16 .. 512 interleaved rows."""
+    import inr_mi355x as M
+    from inr_mi355x import _lib as L
+    net = dict(network_input_size=3, network_output_size=2, network_depth=2, network_width=width,
+               first_omega_0=10, hidden_omega_0=10, scale=5)
+    torch.manual_seed(width)
+    mdl = M.WIRE2D(net)
+    sd = {k: v.clone() for k, v in mdl.state_dict().items()}
+    mdl = mdl.to(dev)
+    B = 203
+    g = torch.Generator().manual_seed(width)
+    coords = torch.rand(B, 3, generator=g) * 2 - 1
+    gt = torch.randn(B, 2, generator=g) * 0.2
+    r32 = _ref("WIRE2D", sd, net, coords, None, gt, torch.float32)
+    r64 = _ref("WIRE2D", sd, net, coords, None, gt, torch.float64)
+    eng = mdl._engine()
+    out = eng.forward(coords.to(dev), None, save=False).cpu()[None]
+    loss = eng.train_step(coords.to(dev), None, gt.to(dev), M.LossSpec(L.LOSS_L2_HALF))
+    _check(out, loss, eng.grads.cpu(), r32, r64)
+
+
 @pytest.mark.parametrize("width", [20, 48, 128, 160, 384])
 @pytest.mark.parametrize("kind", ["Fourier", "MultiscaleKFourier", "Gabor"])
 def test_mfn_widths(dev, kind, width):

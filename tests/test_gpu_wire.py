@@ -40,16 +40,17 @@ def dev():
     return torch.device("cuda:0")
 
 
-def test_wire_tier1_golden(dev):
-    """Drop-in WIRE + stock torch.optim.Adam on complex Parameters vs the reference's vectors."""
+@pytest.mark.parametrize("name", ["WIRE", "WIRE2D"])
+def test_wire_tier1_golden(dev, name):
+    """Drop-in WIRE / WIRE2D + stock torch.optim.Adam on complex Parameters vs the reference's vectors."""
     import inr_mi355x as M
-    meta = META["WIRE"]
-    arrs = _load("model_WIRE.npz")
+    meta = META[name]
+    arrs = _load(f"model_{name}.npz")
     ck = set(meta["complex_keys"])
     x, gt = _t(arrs["x"]).to(dev), _t(arrs["gt"]).to(dev)
     for wd_tag, wd in (("wd0", 0.0), ("wd1", meta["wd1"])):
         torch.manual_seed(meta["seed"])
-        model = M.WIRE(meta["net"])
+        model = getattr(M, name)(meta["net"])
         sd = model.state_dict()
         gold_keys = [k[3:] for k in arrs if k.startswith("sd/")]
         assert list(sd.keys()) == gold_keys
@@ -83,16 +84,17 @@ def test_wire_tier1_golden(dev):
                                                msg=lambda m: f"{wd_tag} step{step} {k}: {m}")
 
 
-def test_wire_tier2_fused_golden(dev):
+@pytest.mark.parametrize("name", ["WIRE", "WIRE2D"])
+def test_wire_tier2_fused_golden(dev, name):
     import inr_mi355x as M
     from inr_mi355x import _lib as L
-    meta = META["WIRE"]
-    arrs = _load("model_WIRE.npz")
+    meta = META[name]
+    arrs = _load(f"model_{name}.npz")
     ck = set(meta["complex_keys"])
     x, gt = _t(arrs["x"]).to(dev), _t(arrs["gt"]).to(dev)
     for wd_tag, wd in (("wd0", 0.0), ("wd1", meta["wd1"])):
         torch.manual_seed(meta["seed"])
-        model = M.WIRE(meta["net"]).to(dev)
+        model = getattr(M, name)(meta["net"]).to(dev)
         eng = model._engine()
         for step in range(1, 4):
             loss = eng.train_step(x, None, gt, M.LossSpec(L.LOSS_L2_HALF))
