@@ -59,6 +59,14 @@ enum inr_kind {
                              inr_forward needs a save buffer (the orth terms travel through it). */
 };
 
+/* arithmetic of the three GEMM loops (accumulation, master weights and Adam are fp32 in both) */
+enum inr_precision {
+  INR_PRECISION_F32 = 0,  /* v_mfma_f32_32x32x2_f32: the parity path (1e-5 against the reference's fp32) */
+  INR_PRECISION_BF16 = 1  /* v_mfma_f32_32x32x16_bf16 on bf16-rounded operands + hardware sin/cos: throughput path
+                             for SIREN + fused gauss encoder, width 129..256; inr_forward / inr_train_step only
+                             (no inr_backward), always needs the save buffer */
+};
+
 /* activation of the last layer */
 enum inr_act {
   INR_ACT_ID = 0,      /* network_last_linear: True (default), networks.py:96 */
@@ -100,7 +108,8 @@ typedef struct inr_net_desc {
   float first_omega_0;  /* WIRE net.first_omega_0 */
   float hidden_omega_0; /* WIRE net.hidden_omega_0 */
   float scale_0;        /* WIRE net.scale */
-  int32_t reserved[4];
+  int32_t precision;   /* enum inr_precision; 0 (the default of a zeroed struct) = exact fp32 */
+  int32_t reserved[3];
 } inr_net_desc;
 
 typedef struct inr_loss_desc {

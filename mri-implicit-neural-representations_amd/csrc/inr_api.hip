@@ -251,6 +251,12 @@ int inr_plan_create(const inr_net_desc* d, inr_plan** out) {
   }
   if (d->last_act < INR_ACT_ID || d->last_act > INR_ACT_SIGMOID)
     return fail(INR_ERR_INVALID, "inr_plan_create: last_act %d", d->last_act);
+  if (d->precision != INR_PRECISION_F32 && d->precision != INR_PRECISION_BF16)
+    return fail(INR_ERR_INVALID, "inr_plan_create: precision %d", d->precision);
+  if (d->precision == INR_PRECISION_BF16 &&
+      (d->kind != INR_KIND_SIREN || d->input != INR_INPUT_GAUSS || NB != 8 || (d->enc_size % 8) != 0))
+    return fail(INR_ERR_UNSUPPORTED, "inr_plan_create: the bf16 path is built for SIREN with the fused gauss encoder "
+                "and hidden width 129..256 (got kind %d, input %d, width %d)", d->kind, d->input, d->width);
 
   inr_plan* p = new (std::nothrow) inr_plan();
   if (p == nullptr) return fail(INR_ERR_INVALID, "inr_plan_create: out of host memory");
@@ -260,6 +266,7 @@ int inr_plan_create(const inr_net_desc* d, inr_plan** out) {
   nd.D = D;
   nd.NB = NB;
   nd.NW = NW;
+  nd.bf16 = d->precision == INR_PRECISION_BF16 ? 1 : 0;
   nd.hact = wire2d ? ACT_GABOR2D : (wire ? ACT_GABOR : (d->kind == INR_KIND_SIREN ? ACT_SIN : ACT_RELU));
   nd.ND = wire2d ? 2 * D - 1 : D;
   nd.orth0 = D;
@@ -393,6 +400,8 @@ static int launch(const inr_plan* plan, const LossDesc& ld, const inr::MlpArgs& 
       case 8: e = inr::launch_wire_nb8(nd, ld, a, mode, grid, st); break;
       default: e = inr::launch_wire_nb12(nd, ld, a, mode, grid, st); break;
     }
+  else if (nd.bf16)
+    e = inr::launch_mlp_nb8_bf16(nd, ld, a, mode, grid, st);
   else
     switch (nd.NB) {
       case 1: e = inr::launch_mlp_nb1(nd, ld, a, mode, grid, st); break;
@@ -440,8 +449,9 @@ int inr_forward(const inr_plan* plan, const float* params, const float* packed, 
     return fail(INR_ERR_INVALID, "inr_forward: null argument");
   if (plan->nd.mfn_n > 0) return fail(INR_ERR_INVALID, "inr_forward: multiplicative-filter plans use inr_forward_multi");
   if (plan->nd.input == IN_GAUSS && enc_B == nullptr) return fail(INR_ERR_INVALID, "inr_forward: enc_B is null");
-  if (plan->nd.hact == ACT_GABOR2D && save == nullptr)
-    return fail(INR_ERR_INVALID, "inr_forward: WIRE2D needs a save buffer (n_tiles * save_floats_per_tile floats)");
+  if ((plan->nd.hact == ACT_GABOR2D || plan->nd.bf16) && save == nullptr)
+    return fail(INR_ERR_INVALID, "inr_forward: WIRE2D and bf16 plans need a save buffer (n_tiles * "
+                "save_floats_per_tile floats)");
   if (B <= 0) return fail(INR_ERR_INVALID, "inr_forward: B = %lld", (long long)B);
   int64_t nt, nb;
   inr_plan_launch_dims(plan, B, &nt, &nb);
@@ -469,6 +479,7 @@ int inr_backward(const inr_plan* plan, const float* params, const float* packed,
     return fail(INR_ERR_INVALID, "inr_backward: null argument");
   if (plan->nd.mfn_n > 0) return fail(INR_ERR_INVALID, "inr_backward: multiplicative-filter plans use inr_backward_multi");
   if (plan->nd.input == IN_GAUSS && enc_B == nullptr) return fail(INR_ERR_INVALID, "inr_backward: enc_B is null");
+  if (plan->nd.bf16) return fail(INR_ERR_UNSUPPORTED, "inr_backward: bf16 plans only have the fused inr_train_step");
   if (B <= 0) return fail(INR_ERR_INVALID, "inr_backward: B = %lld", (long long)B);
   int64_t nt, nb;
   inr_plan_launch_dims(plan, B, &nt, &nb);

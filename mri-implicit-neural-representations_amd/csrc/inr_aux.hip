@@ -208,6 +208,13 @@ hipError_t launch_reduce_slabs(const NetDesc& nd, const float* slabs, int n_bloc
 // re-pack of every weight into the two MFMA A-fragment images and of every bias into its padded
 // bias image.  do_update == 0: pack only.
 // ---------------------------------------------------------------------------------------------
+// bf16 images (nd.bf16): same (k-step s, lane-half h) decomposition, eight k-steps per fragment:
+// element ((s>>3) * blocks + block) * 64 + h*32 + lane_row) * 8 + (s & 7) of a bf16 array that starts where
+// the layer's fp32 image would (it needs at most the same bytes).
+__device__ __forceinline__ void put_bf16(float* packed, int off_floats, size_t idx, float v) {
+  reinterpret_cast<__bf16*>(packed + off_floats)[idx] = (__bf16)v;
+}
+
 __device__ __forceinline__ void put_fwd(const NetDesc& nd, const LayerDesc& L, int l, float* packed, int row, int k,
                                         float v) {
   int h, s;
@@ -218,12 +225,21 @@ __device__ __forceinline__ void put_fwd(const NetDesc& nd, const LayerDesc& L, i
     h = k & 1;
     s = k >> 1;
   }
+  if (nd.bf16) {
+    put_bf16(packed, L.pf_off, ((size_t)((s >> 3) * L.Mblk + (row >> 5)) * 64 + h * 32 + (row & 31)) * 8 + (s & 7), v);
+    return;
+  }
   packed[L.pf_off + ((size_t)((s >> 2) * L.Mblk + (row >> 5)) * 64 + h * 32 + (row & 31)) * 4 + (s & 3)] = v;
 }
 
 __device__ __forceinline__ void put_tr(const LayerDesc& L, float* packed, int row, int k, float v) {
   const int h = row & 1, s = row >> 1;  // transposed image A'[i=k][k'=row]
   packed[L.pb_off + ((size_t)((s >> 2) * L.Kblk + (k >> 5)) * 64 + h * 32 + (k & 31)) * 4 + (s & 3)] = v;
+}
+
+__device__ __forceinline__ void put_tr_bf16(const LayerDesc& L, float* packed, int row, int k, float v) {
+  const int h = row & 1, s = row >> 1;
+  put_bf16(packed, L.pb_off, ((size_t)((s >> 3) * L.Kblk + (k >> 5)) * 64 + h * 32 + (k & 31)) * 8 + (s & 7), v);
 }
 
 __global__ __launch_bounds__(256) void adam_pack_kernel(const NetDesc nd, float* __restrict__ params,
@@ -261,7 +277,10 @@ __global__ __launch_bounds__(256) void adam_pack_kernel(const NetDesc nd, float*
       if (off >= 0 && off < L.wn) {
         const int row = off / L.K, k = off - row * L.K;
         put_fwd(nd, L, l, packed, row, k, p);
-        if (L.pb_off >= 0) put_tr(L, packed, row, k, p);
+        if (L.pb_off >= 0) {
+          if (nd.bf16) put_tr_bf16(L, packed, row, k, p);
+          else put_tr(L, packed, row, k, p);
+        }
         return;
       }
       const int ob = i - L.b_off;

@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("INR_LIB_PATH") or os.path.join(os.path.dirname(_HERE)
 
 # enums (include/inr_abi.h)
 KIND_SIREN, KIND_FFN, KIND_WIRE, KIND_FOURIER, KIND_MSFOURIER, KIND_MSBOUNDED, KIND_GABOR, KIND_KGABOR, KIND_WIRE2D = range(9)
+PRECISION_F32, PRECISION_BF16 = 0, 1
 ACT_ID, ACT_SIN, ACT_TANH, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3, 4
 INPUT_X, INPUT_GAUSS = 0, 1
 LOSS_L2_HALF, LOSS_L1_HALF, LOSS_TANH, LOSS_LOGSPACE, LOSS_HDR = 0, 1, 2, 3, 4
@@ -23,7 +24,8 @@ class NetDesc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("in_features", C.c_int32), ("width", C.c_int32), ("depth", C.c_int32),
                 ("out_features", C.c_int32), ("last_act", C.c_int32), ("input", C.c_int32),
                 ("enc_size", C.c_int32), ("w0", C.c_float), ("first_omega_0", C.c_float),
-                ("hidden_omega_0", C.c_float), ("scale_0", C.c_float), ("reserved", C.c_int32 * 4)]
+                ("hidden_omega_0", C.c_float), ("scale_0", C.c_float), ("precision", C.c_int32),
+                ("reserved", C.c_int32 * 3)]
 
 
 class LossDesc(C.Structure):

@@ -51,11 +51,12 @@ class MLPEngine:
 
     def __init__(self, kind: int, in_features: int, width: int, depth: int, out_features: int, last_act: int,
                  input_mode: int = L.INPUT_X, enc_size: int = 0, w0: float = 30.0, first_omega_0: float = 0.0,
-                 hidden_omega_0: float = 0.0, scale_0: float = 0.0):
+                 hidden_omega_0: float = 0.0, scale_0: float = 0.0, precision: int = L.PRECISION_F32):
         self.lib = L.load()
         desc = L.NetDesc(kind=kind, in_features=in_features, width=width, depth=depth, out_features=out_features,
                          last_act=last_act, input=input_mode, enc_size=enc_size, w0=w0,
-                         first_omega_0=first_omega_0, hidden_omega_0=hidden_omega_0, scale_0=scale_0)
+                         first_omega_0=first_omega_0, hidden_omega_0=hidden_omega_0, scale_0=scale_0,
+                         precision=precision)
         self.desc = desc
         plan = C.c_void_p()
         L.check(self.lib.inr_plan_create(C.byref(desc), C.byref(plan)))
@@ -70,7 +71,7 @@ class MLPEngine:
         self.slab_floats = int(sz.slab_floats)
         self.in_features, self.out_features = in_features, out_features
         self.input_mode = input_mode
-        self.always_save = kind == L.KIND_WIRE2D  # its orth terms travel through the save buffer even when not training
+        self.always_save = kind == L.KIND_WIRE2D or precision == L.PRECISION_BF16  # its orth terms travel through the save buffer even when not training
         self.params: Optional[torch.Tensor] = None
         self.grads = self.exp_avg = self.exp_avg_sq = self.packed = None
         self._save = self._slabs = self._loss = None

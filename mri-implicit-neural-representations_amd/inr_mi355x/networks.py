@@ -138,11 +138,17 @@ class _FlatModel(nn.Module):
             self._eng.bind(self._flat)
         return self._eng
 
-    def fused_engine(self, enc_size: int) -> MLPEngine:
-        """Tier-2 engine over the SAME flat parameters with the gauss encoder fused into layer 0."""
+    def fused_engine(self, enc_size: int, precision: str = "f32") -> MLPEngine:
+        """Tier-2 engine over the SAME flat parameters with the gauss encoder fused into layer 0.
+        ``precision="bf16"``: the bf16-MFMA throughput path (SIREN, width 129..256; fp32 master weights)."""
         if not self._flat.is_cuda:
             raise RuntimeError("inr_mi355x models run on an MI355X only: call .to('cuda') first (no CPU fallback)")
-        eng = self._make_engine(L.INPUT_GAUSS, enc_size)
+        if precision not in ("f32", "bf16"):
+            raise ValueError(f"precision {precision!r}")
+        if precision == "bf16":
+            eng = self._make_engine(L.INPUT_GAUSS, enc_size, L.PRECISION_BF16)
+        else:
+            eng = self._make_engine(L.INPUT_GAUSS, enc_size)
         eng.bind(self._flat)
         return eng
 
@@ -165,9 +171,10 @@ class _FlatMLP(_FlatModel):
         holders = [_Holder(ps[2 * k], ps[2 * k + 1]) for k in range(len(dims) - 1)]
         self.model = key_modules(holders)
 
-    def _make_engine(self, input_mode: int, enc_size: int) -> MLPEngine:
+    def _make_engine(self, input_mode: int, enc_size: int, precision: int = L.PRECISION_F32) -> MLPEngine:
         d = self._dims
-        return MLPEngine(self._kind, d[0], d[1], len(d) - 1, d[-1], self._last_act, input_mode, enc_size, SIREN_W0)
+        return MLPEngine(self._kind, d[0], d[1], len(d) - 1, d[-1], self._last_act, input_mode, enc_size, SIREN_W0,
+                         precision=precision)
 
 
 class SIREN(_FlatMLP):

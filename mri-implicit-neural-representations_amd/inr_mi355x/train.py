@@ -104,8 +104,9 @@ class INRTrainer:
             self.model.bind_encoder(self.encoder)
             self.engine = self.model._engine()
             self.enc_B = self.encoder.B.contiguous()
-        elif emb == "gauss":
-            self.engine = self.model.fused_engine(config["encoder"]["embedding_size"])
+        elif emb == "gauss":  # config["precision"]: "f32" (parity path, default) | "bf16" (throughput path)
+            self.engine = self.model.fused_engine(config["encoder"]["embedding_size"],
+                                                  **({"precision": config["precision"]} if "precision" in config else {}))
             self.enc_B = self.encoder.B.contiguous()
         else:
             self.engine = self.model._engine()
