@@ -374,6 +374,7 @@ __global__ __launch_bounds__(NW * 64) void inr_mlp_bf16_kernel(const NetDesc nd,
     float* sv_enc = sv_last + 4 * TL;
 
     // ================================ forward =================================
+    INR_STAMP(0);
     {
       f32x16 acc[NB];
 #pragma unroll
@@ -387,6 +388,7 @@ __global__ __launch_bounds__(NW * 64) void inr_mlp_bf16_kernel(const NetDesc nd,
       fwd_layer0_gauss_bf16<NB, TL>(acc, a.packed + nd.L[0].pf_off, encB_lds, nd.E, x0, x1, x2, sv_enc, wcol, lane);
       acc_to_lds<NB, true>(acc, R, a.packed + nd.L[0].pbias_off, lane);
     }
+    INR_STAMP(1);
     for (int l = 1; l < D - 1; ++l) {
       const LayerDesc& Ll = nd.L[l];
       f32x16 acc[NB];
@@ -395,6 +397,7 @@ __global__ __launch_bounds__(NW * 64) void inr_mlp_bf16_kernel(const NetDesc nd,
       fwd_layer_bf16<NB, NB, TL>(acc, R, a.packed + Ll.pf_off, nd.L[l - 1].omega, sv + (size_t)(NS * (l - 1)) * HSZ, wcol,
                                  lane);
       acc_to_lds<NB, true>(acc, R, a.packed + Ll.pbias_off, lane);
+      INR_STAMP(1 + l);
     }
     f32x16 accL[1];
     accL[0] = zero16();
@@ -424,13 +427,16 @@ __global__ __launch_bounds__(NW * 64) void inr_mlp_bf16_kernel(const NetDesc nd,
     }
 
     // ================================ backward ================================
+    INR_STAMP(10);
     __syncthreads();
+    INR_STAMP(11);
     {
       BSrcStash<TL> bs{sv + (size_t)(NS * (D - 2)) * HSZ};
       for (int n = w; n < LL.Kblk; n += NW)
         dw_pass_bf16<1, TL, false, BSrcStash<TL>>(lds, RS, bs, n, slab + LL.gw_off, slab + LL.gb_off, LL.M, LL.K, first,
                                                   n == 0, lane);
     }
+    INR_STAMP(12);
     f32x16 gacc[NB];
 #pragma unroll
     for (int m = 0; m < NB; ++m) gacc[m] = zero16();
@@ -440,32 +446,40 @@ __global__ __launch_bounds__(NW * 64) void inr_mlp_bf16_kernel(const NetDesc nd,
       acc_times_d_to_lds_bf16<NB, TL>(gacc, R, sv + (size_t)1 * HSZ, wcol, lane);
     else
       acc_to_lds<NB, false>(gacc, R, nullptr, lane);
+    INR_STAMP(13);
     for (int l = D - 2; l >= 1; --l) {
       const LayerDesc& Ll = nd.L[l];
 #pragma unroll
       for (int m = 0; m < NB; ++m) gacc[m] = zero16();
       bwd_dx_bf16<NB, TL, true>(gacc, R, a.packed + Ll.pb_off, NB * 2, sv + (size_t)(NS * l + 1) * HSZ, wcol, lane);
+      INR_STAMP(14 + 4 * l);
       __syncthreads();
+      INR_STAMP(15 + 4 * l);
       {
         BSrcStash<TL> bs{sv + (size_t)(NS * (l - 1)) * HSZ};
         for (int n = w; n < Ll.Kblk; n += NW)
           dw_pass_bf16<NB, TL, true, BSrcStash<TL>>(lds, RS, bs, n, slab + Ll.gw_off, slab + Ll.gb_off, Ll.M, Ll.K, first,
                                                     n == 0, lane);
       }
+      INR_STAMP(16 + 4 * l);
       __syncthreads();
       if (l == 1)
         acc_times_d_to_lds_bf16<NB, TL>(gacc, R, sv + (size_t)1 * HSZ, wcol, lane);
       else
         acc_to_lds<NB, false>(gacc, R, nullptr, lane);
+      INR_STAMP(17 + 4 * l);
     }
     {
       const LayerDesc& L0 = nd.L[0];
       __syncthreads();
+      INR_STAMP(40);
       BSrcStash<TL> bs{sv_enc};
       for (int n = w; n < L0.Kblk; n += NW)
         dw_pass_bf16<NB, TL, true, BSrcStash<TL>>(lds, RS, bs, n, slab + L0.gw_off, slab + L0.gb_off, L0.M, L0.K, first,
                                                   n == 0, lane);
+      INR_STAMP(41);
       __syncthreads();
+      INR_STAMP(42);
     }
     first = false;
   }

@@ -9,13 +9,14 @@ import torch
 import inr_mi355x as M
 from inr_mi355x import _lib as L
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 25000
+PREC = sys.argv[2] if len(sys.argv) > 2 else "f32"
 dev = torch.device("cuda:0")
 net = dict(network_input_size=512, network_output_size=2, network_depth=5, network_width=256, last_tanh=True)
 enc_cfg = dict(embedding="gauss", scale=4, embedding_size=256, coordinates_size=3)
 torch.manual_seed(0)
 enc = M.Positional_Encoder(enc_cfg, device=dev)
 model = M.SIREN(net).to(dev)
-eng = model.fused_engine(256)
+eng = model.fused_engine(256, precision=PREC)
 lib = L.load()
 lib.inr_debug_set_stamp_buffer.argtypes = [C.c_void_p]
 coords = (torch.rand(B, 3) * 2 - 1).to(dev); gt = (torch.randn(B, 2) * 0.2).to(dev)
