@@ -4,7 +4,8 @@ the fused MFN kernel (MultiscaleKFourier, 4 heads) with optional data parallelis
 Per step (reference lines 164-195):  outs = model(enc(coords), dist);  loss = 0.1*ConsistencyLoss(outs,
 dist) + sum_k 0.5*loss_fn(out_k, gt)  (limit_kspace is a no-op, SURVEY A.4 #2: every head sees the full
 gt);  Adam;  per-epoch LambdaLR.  Radii of the nested discs come from the k-means ring partition
-(clustering.py, out of the hot path) and are an input here.
+(inr_mi355x/clustering.py = the reference's clustering.py; train_kspace_multiscale.py:73-84): pass ``radii`` or
+leave it None to have them computed from ``config["partition"]`` (no_steps, no_models).
 """
 from __future__ import annotations
 
@@ -29,9 +30,18 @@ def create_pairs(values: Sequence[float], multiplication_factor: int):
 
 class MultiscaleTrainer:
     def __init__(self, config: dict, image: torch.Tensor, coords: torch.Tensor, dist: torch.Tensor,
-                 radii: Sequence[float], shape, device, seed: int = 0, rank: int = 0, world: int = 1,
+                 radii: Optional[Sequence[float]], shape, device, seed: int = 0, rank: int = 0, world: int = 1,
                  process_group=None):
         config = set_default_configs(dict(config))
+        if radii is None:  # train_kspace_multiscale.py:73-84
+            from .clustering import partition_and_stats
+            C, H, W = int(shape[0]), int(shape[1]), int(shape[2])
+            part = config["partition"]
+            dev_img = image.to(device).reshape(C, H, W, 2)
+            self.mx, radii = partition_and_stats(dev_img, coords.to(device).reshape(C, H, W, 3),
+                                                 no_steps=part["no_steps"], no_parts=part["no_models"], stat="max")
+            self.mx = torch.cat((self.mx.cpu(), torch.ones(1)))
+        self.radii = [float(r) for r in radii]
         self.config = config
         self.device = torch.device(device)
         self.rank, self.world, self.pg = rank, world, process_group

@@ -215,3 +215,24 @@ def test_single_scale_trainer_mfn_vs_oracle(dev, model):
     with torch.no_grad():
         want = O.model_forward(model, sd, O.encode(coords, tr.encoder.B.cpu(), "gauss"), cfg["net"])
     torch.testing.assert_close(out, want, rtol=1e-3, atol=2e-5)
+
+
+def test_multiscale_trainer_computes_its_radii(dev):
+    """radii=None: the trainer runs the ring partition itself (train_kspace_multiscale.py:73-84) on the device
+    tensors and gets what the host computation gives; then it trains."""
+    from inr_mi355x import clustering as Cl
+    from inr_mi355x.synthetic import make_kspace
+    from inr_mi355x.train_kspace_multiscale import MultiscaleTrainer
+    C, H, W = 2, 48, 40
+    image, coords, shape = make_kspace(C, H, W)
+    dist = torch.sqrt(coords[:, 1] ** 2 + coords[:, 2] ** 2)
+    cfg = dict(model="MultiscaleKFourier", loss="LSL", loss_opts=dict(eps=3e-3), lr=3e-4, batch_size=1000, max_epoch=2,
+               weight_decay=0.0, beta1=0.9, beta2=0.999, partition=dict(no_steps=40, no_models=4),
+               net=dict(network_input_size=32, network_output_size=2, network_depth=8, network_width=32),
+               encoder=dict(embedding="gauss", scale=2, embedding_size=16, coordinates_size=3))
+    tr = MultiscaleTrainer(cfg, image, coords, dist, None, shape, dev, seed=0)
+    _, radii = Cl.partition_kspace(image.reshape(C, H, W, 2), coords.reshape(C, H, W, 3), 40, 4)
+    np.testing.assert_allclose(tr.radii, radii, rtol=1e-6)
+    assert tr.mx.shape == (5,) and float(tr.mx[-1]) == 1.0
+    losses = [s[1] for s in tr.fit(6, log_every=1)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]

@@ -186,3 +186,19 @@ def test_random_line_and_argument_grammar():
     ref[:, cols] = True
     assert torch.equal(m, ref)
     assert U.random_line_mask(8, 8, 1.0).all()
+
+
+# ---- ring partition (clustering.py) vs vectors produced by the reference's functions -------------------
+def test_ring_partition_matches_reference():
+    from inr_mi355x import clustering as Cl
+    g = dict(np.load(os.path.join(GOLD, "clustering.npz")))
+    meta = json.load(open(os.path.join(GOLD, "clustering_meta.json")))
+    for tag, c in meta["cases"].items():
+        k, grid = torch.from_numpy(g[f"{tag}/kspace"]), torch.from_numpy(g[f"{tag}/coords"])
+        labels, radii = Cl.partition_kspace(k, grid, c["no_steps"], c["no_parts"])
+        assert np.array_equal(labels, g[f"{tag}/labels"]), tag
+        np.testing.assert_allclose(radii, g[f"{tag}/radii"], rtol=0, atol=0)
+        stats, radii2 = Cl.partition_and_stats(k, grid, c["no_steps"], c["no_parts"], "max")
+        np.testing.assert_array_equal(radii2, radii)
+        torch.testing.assert_close(stats, torch.from_numpy(g[f"{tag}/stats"]), rtol=0, atol=0)
+        assert radii[0] == 0 and radii[-1] == 5 and np.all(np.diff(radii) > 0)

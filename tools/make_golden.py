@@ -477,8 +477,36 @@ def undersampling_vectors():
         os.chdir(cwd)
 
 
+def clustering_vectors():
+    """Ring partition (clustering.py:19-135) on a small synthetic k-space.  clustering.py imports
+    models.utils at module scope only for its __main__ block (get_config / get_data_loader); that module drags in
+    h5py / torchvision, which are absent here, so an empty stand-in is registered for it -- the two functions
+    exercised below do not touch it."""
+    import matplotlib
+    matplotlib.use("Agg")
+    mu = types.ModuleType("models.utils")
+    mu.get_config = mu.get_data_loader = None
+    sys.modules.setdefault("models.utils", mu)
+    import clustering as ref_clustering
+    arrs, meta = {}, {"cases": {}}
+    for tag, (C, H, W, steps, parts) in {"a": (3, 48, 40, 40, 4), "b": (2, 64, 64, 24, 3)}.items():
+        k = synth_kspace(C, H, W, 21 + C)
+        grid = torch.stack(torch.meshgrid(torch.linspace(-1, 1, C), torch.linspace(-1, 1, H), torch.linspace(-1, 1, W),
+                                          indexing="ij"), dim=-1)
+        labels, radii = quiet(ref_clustering.partition_kspace, None, k, grid, False, steps, parts)
+        stats, radii2 = quiet(ref_clustering.partition_and_stats, None, k, grid, False, steps, parts, "max")
+        assert np.array_equal(radii, radii2)
+        arrs[f"{tag}/kspace"], arrs[f"{tag}/coords"] = npy(k), npy(grid)
+        arrs[f"{tag}/labels"], arrs[f"{tag}/radii"], arrs[f"{tag}/stats"] = np.asarray(labels), np.asarray(radii), npy(stats)
+        meta["cases"][tag] = {"shape": [C, H, W], "no_steps": steps, "no_parts": parts}
+    np.savez_compressed(os.path.join(OUT, "clustering.npz"), **arrs)
+    with open(os.path.join(OUT, "clustering_meta.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    clustering_vectors()
     undersampling_vectors()
     init_hashes()
     model_vectors()
