@@ -202,3 +202,18 @@ def test_ring_partition_matches_reference():
         np.testing.assert_array_equal(radii2, radii)
         torch.testing.assert_close(stats, torch.from_numpy(g[f"{tag}/stats"]), rtol=0, atol=0)
         assert radii[0] == 0 and radii[-1] == 5 and np.all(np.diff(radii) > 0)
+
+
+def test_ring_ensemble_assignment_and_overwrite_order():
+    """Ring -> rank map and the 'outer ring wins on shared boundary points' rule of the evaluation sweep
+    (train_variations/train_clustering.py:199-211: sequential batch_rec[ind] = output)."""
+    from inr_mi355x.train_ring_ensemble import ring_owner, winning_ring
+    assert [ring_owner(i, 4) for i in range(4)] == [0, 1, 2, 3]
+    assert [ring_owner(i, 2) for i in range(4)] == [0, 1, 0, 1]
+    radii = [0.0, 0.5, 1.0, 5.0]
+    dist = torch.tensor([0.0, 0.25, 0.5, 0.75, 1.0, 1.3, 7.0])
+    win = winning_ring(dist, radii)
+    rec = torch.full((7,), -1)
+    for i in range(3):  # the reference's sequential overwrite
+        rec[(dist >= radii[i]) & (dist <= radii[i + 1])] = i
+    assert torch.equal(win, rec) and win.tolist() == [0, 0, 1, 1, 2, 2, -1]
