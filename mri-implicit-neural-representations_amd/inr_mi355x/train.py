@@ -144,6 +144,8 @@ class INRTrainer:
         self.steps_per_epoch = math.ceil(self.n / self.bs)
         self.global_step = 0
         self._hdr_A = {}
+        if "pretrain" in config:  # train.py:117-121
+            self.load_checkpoint(torch.load(config["pretrain"], map_location=self.device))
 
     # ---- one optimizer step on batch `it` of epoch `epoch` --------------------------------------
     def _inputs(self, lo: int, hi: int):
@@ -238,16 +240,20 @@ class INRTrainer:
 
     def checkpoint(self) -> dict:
         """Same dict as train.py:247-250 ('opt' in torch.optim.Adam.state_dict() layout)."""
-        sd = self.model.state_dict()
-        state, o = {}, 0
-        for i, (off, n, shp, _c) in enumerate(self.model._layout):
-            state[i] = {"step": torch.tensor(float(self.engine.step)),
-                        "exp_avg": self.engine.exp_avg[off:off + n].view(shp).clone(),
-                        "exp_avg_sq": self.engine.exp_avg_sq[off:off + n].view(shp).clone()}
-        opt = {"state": state, "param_groups": [{"lr": self.config["lr"], "betas": (self.config["beta1"], self.config["beta2"]),
-                                                 "eps": 1e-8, "weight_decay": self.config["weight_decay"],
-                                                 "amsgrad": False, "params": list(range(len(self.model._layout)))}]}
-        return {"net": sd, "enc": self.encoder.B, "opt": opt}
+        from .checkpoint import save_dict
+        return save_dict(self.model, self.encoder, self.engine, self.config)
+
+    def load_checkpoint(self, ckpt: dict) -> None:
+        """train.py:117-121 (config['pretrain']): weights, Adam moments / step count and the encoder matrix."""
+        from .checkpoint import load_dict
+
+        def rebind(enc):
+            if self.enc_B is not None:
+                self.enc_B = enc.B.contiguous()
+            if self.is_mfn:
+                self.model._enc_B = self.enc_B  # the engine (and its Adam state) stays; B is passed per call
+
+        load_dict(self.model, self.encoder, self.engine, ckpt, rebind)
 
 
 def main():

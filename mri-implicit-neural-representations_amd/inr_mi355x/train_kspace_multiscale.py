@@ -73,6 +73,8 @@ class MultiscaleTrainer:
         self.steps_per_epoch = math.ceil(self.n / self.bs)
         self.global_step = 0
         self._cons = {}
+        if "pretrain" in config:
+            self.load_checkpoint(torch.load(config["pretrain"], map_location=self.device))
 
     def _cons_spec(self, it: int, lo: int, hi: int) -> ConsistencySpec:
         if it not in self._cons:
@@ -95,6 +97,21 @@ class MultiscaleTrainer:
         self.engine.adam_step(lr, self.config["beta1"], self.config["beta2"], 1e-8, self.config["weight_decay"])
         self.global_step += 1
         return loss
+
+    def checkpoint(self) -> dict:
+        """{'net','enc','opt'} as the reference saves it (train_kspace_multiscale.py, same as train.py:247-250)."""
+        from .checkpoint import save_dict
+        return save_dict(self.model, self.encoder, self.engine, self.config)
+
+    def load_checkpoint(self, ckpt: dict) -> None:
+        """config['pretrain'] (train_kspace_multiscale.py:124-128)."""
+        from .checkpoint import load_dict
+
+        def rebind(enc):
+            self.enc_B = enc.B.contiguous()
+            self.model._enc_B = self.enc_B
+
+        load_dict(self.model, self.encoder, self.engine, ckpt, rebind)
 
     def fit(self, max_steps: Optional[int] = None, log_every: int = 0):
         logged = []

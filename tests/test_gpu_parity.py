@@ -357,3 +357,48 @@ def test_ring_ensemble_vs_oracle_and_rank_independence(dev):
     out = tr2.step(0, 0)  # rows y = 0..3: far from the centre
     assert out[0] is None and out[2] is not None
     assert torch.equal(before, tr2.engines[0].params) and tr2.engines[0].step == 0 and tr2.engines[2].step == 1
+
+
+@pytest.mark.parametrize("model", ["SIREN", "WIRE", "Gabor"])
+def test_checkpoint_roundtrip_and_torch_adam_interchange(dev, model, tmp_path):
+    """{'net','enc','opt'} (train.py:247-250): (i) save -> new trainer with config['pretrain'] -> continue equals the
+    uninterrupted run bit for bit; (ii) the 'opt' entry loads into a stock torch.optim.Adam over the drop-in
+    model's parameters, and a checkpoint written from such an optimizer resumes in the fused trainer."""
+    import inr_mi355x as M
+    from inr_mi355x.synthetic import make_kspace
+    from inr_mi355x.train import INRTrainer
+    image, coords, shape = make_kspace(2, 24, 20)
+    wire = model == "WIRE"
+    net = dict(network_input_size=3 if wire else 32, network_output_size=2, network_depth=2 if wire else 3,
+               network_width=32, first_omega_0=10, hidden_omega_0=10, scale=5)
+    cfg = dict(model=model, loss="L2", lr=1e-3, batch_size=300, max_epoch=3, weight_decay=0.01, beta1=0.9, beta2=0.999,
+               net=net, encoder=dict(embedding="none" if wire else "gauss", scale=2, embedding_size=16,
+                                     coordinates_size=3))
+    full = INRTrainer(cfg, image, coords, shape, dev, seed=3)
+    a = INRTrainer(cfg, image, coords, shape, dev, seed=3)
+    l_full = [s[1] for s in full.fit(8, log_every=1)]
+    la = [s[1] for s in a.fit(4, log_every=1)]
+    path = str(tmp_path / "model_000004.pt")
+    torch.save(a.checkpoint(), path)
+    b = INRTrainer(dict(cfg, pretrain=path), image, coords, shape, dev, seed=99)  # different init: all from the file
+    assert b.engine.step == 4
+    b.global_step = 4
+    lb = []
+    for s in range(4, 8):
+        lb.append(float(b.step(s // b.steps_per_epoch, s % b.steps_per_epoch)))
+    assert la + lb == l_full
+    # (ii) torch.optim.Adam accepts the 'opt' entry
+    ck = torch.load(path, map_location=dev)
+    m = getattr(M, model, None) or getattr(__import__("inr_mi355x.mfn", fromlist=[model]), model + "Net")
+    torch.manual_seed(0)
+    mod = m(net).to(dev)
+    mod.load_state_dict(ck["net"])
+    opt = torch.optim.Adam(mod.parameters(), lr=cfg["lr"], betas=(0.9, 0.999), weight_decay=cfg["weight_decay"])
+    opt.load_state_dict(ck["opt"])
+    st = opt.state_dict()["state"]
+    assert len(st) == len(ck["opt"]["state"]) and all(int(v["step"]) == 4 for v in st.values())
+    ck2 = {"net": mod.state_dict(), "enc": ck["enc"], "opt": opt.state_dict()}
+    c = INRTrainer(cfg, image, coords, shape, dev, seed=7)
+    c.load_checkpoint(ck2)
+    assert c.engine.step == 4
+    assert float(c.step(4 // c.steps_per_epoch, 4 % c.steps_per_epoch)) == lb[0]
