@@ -63,8 +63,7 @@ enum inr_kind {
 enum inr_precision {
   INR_PRECISION_F32 = 0,  /* v_mfma_f32_32x32x2_f32: the parity path (1e-5 against the reference's fp32) */
   INR_PRECISION_BF16 = 1  /* v_mfma_f32_32x32x16_bf16 on bf16-rounded operands + hardware sin/cos: throughput path
-                             for SIREN + fused gauss encoder, width 129..256; inr_forward / inr_train_step only
-                             (no inr_backward), always needs the save buffer */
+                             for SIREN + fused gauss encoder, width 129..256; always needs the save buffer */
 };
 
 /* activation of the last layer */

@@ -479,7 +479,6 @@ int inr_backward(const inr_plan* plan, const float* params, const float* packed,
     return fail(INR_ERR_INVALID, "inr_backward: null argument");
   if (plan->nd.mfn_n > 0) return fail(INR_ERR_INVALID, "inr_backward: multiplicative-filter plans use inr_backward_multi");
   if (plan->nd.input == IN_GAUSS && enc_B == nullptr) return fail(INR_ERR_INVALID, "inr_backward: enc_B is null");
-  if (plan->nd.bf16) return fail(INR_ERR_UNSUPPORTED, "inr_backward: bf16 plans only have the fused inr_train_step");
   if (B <= 0) return fail(INR_ERR_INVALID, "inr_backward: B = %lld", (long long)B);
   int64_t nt, nb;
   inr_plan_launch_dims(plan, B, &nt, &nb);

@@ -342,7 +342,8 @@ __device__ __forceinline__ void dw_pass_bf16(const float* Rall, int region_strid
 }
 
 // ---------------------------------------------------------------------------------------------
-// the kernel: MODE_FWD (evaluation; save optional) or MODE_FUSED (forward + pointwise loss + backward)
+// the kernel: MODE_FWD (evaluation / first half of an unfused step), MODE_BWD (second half, from dout and the
+// forward's stash) or MODE_FUSED (forward + pointwise loss + backward)
 // ---------------------------------------------------------------------------------------------
 template <int NB, int NW, int MODE>
 __global__ __launch_bounds__(NW * 64) void inr_mlp_bf16_kernel(const NetDesc nd, const LossDesc ld, const MlpArgs a) {
@@ -375,6 +376,7 @@ __global__ __launch_bounds__(NW * 64) void inr_mlp_bf16_kernel(const NetDesc nd,
 
     // ================================ forward =================================
     INR_STAMP(0);
+    if (MODE != MODE_BWD) {
     {
       f32x16 acc[NB];
 #pragma unroll
@@ -412,7 +414,13 @@ __global__ __launch_bounds__(NW * 64) void inr_mlp_bf16_kernel(const NetDesc nd,
       g[o] = 0.f;
       if (half == 0 && valid && o < nd.out_f && a.out != nullptr) a.out[crow * nd.out_f + o] = y[o];
     }
-    if (MODE == MODE_FWD) continue;
+    if (MODE == MODE_FWD) {
+      if (half == 0) {
+#pragma unroll
+        for (int o = 0; o < 4; ++o) sv_last[o * TL + wcol] = dy[o];  // act'(z_last) for a later MODE_BWD launch
+      }
+      continue;
+    }
 
     if (half == 0 && valid && (a.mask == nullptr || a.mask[crow] != 0)) {
       float t[4] = {0.f, 0.f, 0.f, 0.f};
@@ -424,6 +432,14 @@ __global__ __launch_bounds__(NW * 64) void inr_mlp_bf16_kernel(const NetDesc nd,
       float v = 0.f;
       if (r < 4 && half == 0 && r < nd.out_f) v = g[r & 3] * dy[r & 3];
       R[swz(acc_row(r, half), col)] = v;
+    }
+    } else {  // MODE_BWD: dZ_last = dout * act'(z_last) from the forward launch's stash
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = 0.f;
+        if (r < 4 && half == 0 && r < nd.out_f && valid) v = a.dout[crow * nd.out_f + r] * sv_last[r * TL + wcol];
+        R[swz(acc_row(r, half), col)] = v;
+      }
     }
 
     // ================================ backward ================================

@@ -11,7 +11,7 @@ hipError_t launch_mlp_nb8_bf16(const NetDesc& nd, const LossDesc& ld, const MlpA
   if (nd.input != IN_GAUSS || nd.hact != ACT_SIN || a.save == nullptr) return hipErrorInvalidValue;
   if (mode == MODE_FWD) return launch_mlp_bf16<INR_NB, INR_NW, MODE_FWD>(nd, ld, a, grid, st);
   if (mode == MODE_FUSED) return launch_mlp_bf16<INR_NB, INR_NW, MODE_FUSED>(nd, ld, a, grid, st);
-  return hipErrorInvalidValue;  // no separate backward kernel: the bf16 path is the fused trainer's
+  return launch_mlp_bf16<INR_NB, INR_NW, MODE_BWD>(nd, ld, a, grid, st);
 }
 
 }  // namespace inr

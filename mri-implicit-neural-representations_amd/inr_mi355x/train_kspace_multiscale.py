@@ -137,3 +137,40 @@ class MultiscaleTrainer:
     def evaluate(self) -> float:
         ref = reconstruct(self.image, self.shape, False)
         return float(psnr(ref, reconstruct(self.predict_all(), self.shape, False)))
+
+
+def main():
+    """CLI with the reference's flags (train_kspace_multiscale.py:50-52): --config, --output_path; the fastMRI
+    loader is replaced by the synthetic k-space (--synthetic C,H,W)."""
+    import argparse
+    import json
+    import os
+    import time
+
+    from .synthetic import make_kspace
+    from .train import get_config
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", type=str, required=True)
+    ap.add_argument("--data_samples", type=str, default="")
+    ap.add_argument("--output_path", type=str, default=".")
+    ap.add_argument("--synthetic", type=str, default="15,640,368")
+    ap.add_argument("--max_steps", type=int, default=None)
+    opts = ap.parse_args()
+    config = set_default_configs(get_config(opts.config))
+    if config["model"] not in ("BoundedFourier",):
+        config["model"] = "MultiscaleKFourier"  # train_kspace_multiscale.py:93-98: anything else is the unbounded net
+    C, H, W = (int(v) for v in opts.synthetic.split(","))
+    image, coords, shape = make_kspace(C, H, W, normalization=config.get("normalization", "max"))
+    dist = torch.sqrt(coords[:, 1] ** 2 + coords[:, 2] ** 2)
+    tr = MultiscaleTrainer(config, image, coords, dist, None, shape, "cuda")
+    t0 = time.time()
+    tr.fit(opts.max_steps, log_every=config.get("log_iter", 20))
+    torch.cuda.synchronize()
+    res = {"steps": tr.global_step, "seconds": time.time() - t0, "psnr": tr.evaluate(), "radii": tr.radii}
+    os.makedirs(opts.output_path, exist_ok=True)
+    torch.save(tr.checkpoint(), os.path.join(opts.output_path, "model_%06d.pt" % tr.global_step))
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

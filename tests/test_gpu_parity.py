@@ -402,3 +402,26 @@ def test_checkpoint_roundtrip_and_torch_adam_interchange(dev, model, tmp_path):
     c.load_checkpoint(ck2)
     assert c.engine.step == 4
     assert float(c.step(4 // c.steps_per_epoch, 4 % c.steps_per_epoch)) == lb[0]
+
+
+@pytest.mark.parametrize("module,cfg,extra", [
+    ("inr_mi355x.train", "config_siren_kspace.yaml", []),
+    ("inr_mi355x.train", "config_wire_kspace.yaml", []),
+    ("inr_mi355x.train", "config_siren_radial_tv_bf16.yaml", []),
+    ("inr_mi355x.train_kspace_multiscale", "config_fourier_multiscale.yaml", []),
+])
+def test_cli_runs_the_shipped_configs(dev, module, cfg, extra, tmp_path):
+    """`python -m inr_mi355x.train --config ...` (the reference's CLI flags, train.py:255-258) on the configs/ that
+    mirror the BASELINE workloads, shrunk to a small synthetic k-space and a few steps."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=os.path.join(root, "mri-implicit-neural-representations_amd"))
+    out = subprocess.run([sys.executable, "-m", module, "--config", os.path.join(root, "configs", cfg),
+                          "--output_path", str(tmp_path), "--synthetic", "2,64,48", "--max_steps", "4"] + extra,
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res["steps"] == 4 and np.isfinite(res["psnr"])
+    ck = torch.load(os.path.join(str(tmp_path), "model_000004.pt"), map_location="cpu")
+    assert set(ck) == {"net", "enc", "opt"}
