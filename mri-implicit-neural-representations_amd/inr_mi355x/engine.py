@@ -93,7 +93,9 @@ class MLPEngine:
             raise RuntimeError(f"flat_params has {flat_params.numel()} elements, plan needs {self.n_params}")
         self.params = flat_params
         dev = flat_params.device
-        self.grads = torch.zeros(self.n_params, device=dev)
+        # one extra word behind the gradient: the data-parallel step all-reduces gradient AND loss in ONE collective
+        self.gbuf = torch.zeros(self.n_params + 1, device=dev)
+        self.grads = self.gbuf[:self.n_params]
         self.exp_avg = torch.zeros(self.n_params, device=dev)
         self.exp_avg_sq = torch.zeros(self.n_params, device=dev)
         self.packed = torch.zeros(self.packed_floats, device=dev)  # padding entries stay zero forever

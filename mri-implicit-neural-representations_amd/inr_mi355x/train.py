@@ -67,14 +67,22 @@ def shard_rows(lo: int, hi: int, rank: int, world: int):
     return lo + (rank * n) // world, lo + ((rank + 1) * n) // world
 
 
-def allreduce_step_outputs(grads: torch.Tensor, loss: torch.Tensor, world: int, group=None) -> torch.Tensor:
+def allreduce_step_outputs(grads: torch.Tensor, loss: torch.Tensor, world: int, group=None,
+                           gbuf: Optional[torch.Tensor] = None) -> torch.Tensor:
     """The one exchange step of the data-parallel path: every rank holds the partial
     sums of its contiguous row shard, already divided by the GLOBAL row count, so a plain SUM
     all-reduce (RCCL over xGMI on the GPU box, gloo in the CPU tests) of the flat fp32 gradient and
-    of the loss scalar reproduces the single-GPU step up to summation order.  In place on `grads`."""
+    of the loss scalar reproduces the single-GPU step up to summation order.  In place on `grads`.
+    ``gbuf`` = the engine's [P+1] buffer whose first P words ARE ``grads``: the loss rides in the last word and
+    the step costs one collective instead of two (the message is small, so latency is what counts)."""
     if world <= 1:
         return loss
     import torch.distributed as dist
+    if gbuf is not None:
+        assert gbuf.data_ptr() == grads.data_ptr() and gbuf.numel() == grads.numel() + 1
+        gbuf[-1:].copy_(loss.reshape(1))
+        dist.all_reduce(gbuf, op=dist.ReduceOp.SUM, group=group)
+        return gbuf[-1].clone()
     dist.all_reduce(grads, op=dist.ReduceOp.SUM, group=group)
     loss = loss.clone()
     dist.all_reduce(loss, op=dist.ReduceOp.SUM, group=group)
@@ -178,7 +186,7 @@ class INRTrainer:
             slo, shi = shard_rows(lo, hi, self.rank, self.world)
             m = self.mask[slo:shi] if self.mask is not None else None
             loss = self._fused(slo, shi, count, m, A)
-        loss = allreduce_step_outputs(self.engine.grads, loss, self.world, self.pg)
+        loss = allreduce_step_outputs(self.engine.grads, loss, self.world, self.pg, self.engine.gbuf)
         lr = self.config["lr"] * lr_factor(epoch, self.config["max_epoch"])
         self.engine.adam_step(lr, self.config["beta1"], self.config["beta2"], 1e-8, self.config["weight_decay"],
                               self.l1, self.l2)

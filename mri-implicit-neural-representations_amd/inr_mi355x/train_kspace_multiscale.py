@@ -92,7 +92,7 @@ class MultiscaleTrainer:
         loss = self.engine.train_step(self.coords[slo:shi], self.enc_B, self.image[slo:shi], self.loss,
                                       count=hi - lo, dist=self.dist[slo:shi], scale=self.scale,
                                       cons=self._cons_spec(it, lo, hi))
-        loss = allreduce_step_outputs(self.engine.grads, loss, self.world, self.pg)
+        loss = allreduce_step_outputs(self.engine.grads, loss, self.world, self.pg, self.engine.gbuf)
         lr = self.config["lr"] * lr_factor(epoch, self.config["max_epoch"])
         self.engine.adam_step(lr, self.config["beta1"], self.config["beta2"], 1e-8, self.config["weight_decay"])
         self.global_step += 1

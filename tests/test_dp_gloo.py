@@ -51,7 +51,12 @@ def _worker(rank, world, port, q):
         count = int(mask[lo:hi].sum()) if use_mask else hi - lo
         slo, shi = shard_rows(lo, hi, rank, world)
         grads, loss = _partial(sd, B_enc, coords, gt, m, slo, shi, count)
-        loss = allreduce_step_outputs(grads, loss.reshape(1), world)
+        if use_mask:  # the engine's layout: loss word behind the gradient, one collective
+            gbuf = torch.cat([grads, torch.zeros(1)])
+            grads = gbuf[:-1]
+            loss = allreduce_step_outputs(grads, loss.reshape(1), world, gbuf=gbuf)
+        else:
+            loss = allreduce_step_outputs(grads, loss.reshape(1), world)
         full_g, full_l = _partial(sd, B_enc, coords, gt, m, lo, hi, count)
         res.append((float((grads - full_g).norm() / full_g.norm()), float(abs(loss - full_l) / abs(full_l))))
     q.put((rank, res))
