@@ -340,7 +340,7 @@ int inr_plan_create(const inr_net_desc* d, inr_plan** out) {
   nd.P = poff;
   nd.slab_loss_off = goff;
   nd.slab_floats = round_up(goff + 4, 64);
-  const int ns = wire2d ? 7 : (wire ? 3 : 2);
+  const int ns = wire2d ? 7 : (wire ? 3 : (nd.bf16 ? 1 : 2));  // bf16: z only (act / act' are recomputed)
   nd.save_floats_per_tile = ns * (D - 1) * NB * 32 * TL + 4 * TL +
                             (d->input == INR_INPUT_GAUSS ? nd.L[0].Kblk * 32 * TL : 0) +
                             (wire2d ? NB * 32 * TL : 0);  // WIRE2D: copy of a layer's output gradient

@@ -11,6 +11,11 @@
 //   * operands are converted on the fly (v_cvt_pk_bf16_f32); sin/cos use the hardware v_sin/v_cos (argument in
 //     revolutions): with the matrix pipe 16x faster the layer loop is VALU-bound and the 25-instruction exact
 //     sincos of the fp32 path would cap the gain at ~2x.
+//   * the stash holds only the pre-activations z_l (copied out of the LDS image in one burst per layer): no
+//     store sits inside a GEMM loop -- on gfx9 stores and loads share the in-order vmcnt queue, so a stash store per
+//     k-step made every weight-fragment wait also a wait for the previous step's stores.  The backward half
+//     recomputes sin / cos (two hardware transcendentals) where the fp32 kernel reads them back, and the encoder
+//     features of dW_0 are regenerated from the tile's coordinates.
 // This path is NOT held to the 1e-5 parity bar (bf16 operands): tests compare it with the fp32 path at bf16
 // tolerances and bench.py reports PSNR next to the fp32 number.
 #pragma once
@@ -49,6 +54,9 @@ __device__ __forceinline__ void sincos_rev(float r, float& s, float& c) {
   c = __builtin_amdgcn_cosf(f);
 }
 
+__device__ __forceinline__ float sin_rev(float r) { return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(r)); }
+__device__ __forceinline__ float cos_rev(float r) { return __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(r)); }
+
 template <int NBM>
 __device__ __forceinline__ void load_afrag16(bf16x8 (&a)[NBM], const bf16x8* __restrict__ p) {
 #pragma unroll
@@ -68,10 +76,9 @@ __device__ __forceinline__ float gauss_feature_rev(const float* encB_lds, int s,
 template <int NB, int TL>
 __device__ __forceinline__ void fwd_layer0_gauss_bf16(f32x16 (&acc)[NB], const float* __restrict__ wp,
                                                       const float* encB_lds, int E, float x0, float x1, float x2,
-                                                      float* __restrict__ sv_enc, int wcol, int lane) {
+                                                      int lane) {
   const int half = lane >> 5;
   const float quarter = half ? 0.25f : 0.f;
-  float* sve = sv_enc + (half ? E : 0) * TL + wcol;
   const bf16x8* p = reinterpret_cast<const bf16x8*>(wp) + lane;
   const int n8 = E >> 3;
   bf16x8 A0[NB], A1[NB];
@@ -89,8 +96,6 @@ __device__ __forceinline__ void fwd_layer0_gauss_bf16(f32x16 (&acc)[NB], const f
     {
       const bf16x8 b = to_bf16x8(F0);
 #pragma unroll
-      for (int t = 0; t < 8; ++t) sve[(8 * s8 + t) * TL] = F0[t];
-#pragma unroll
       for (int m = 0; m < NB; ++m) acc[m] = mfma16(A0[m], b, acc[m]);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -100,8 +105,6 @@ __device__ __forceinline__ void fwd_layer0_gauss_bf16(f32x16 (&acc)[NB], const f
 #pragma unroll
       for (int t = 0; t < 8; ++t) F0[t] = gauss_feature_rev(encB_lds, 8 * s2 + t, x0, x1, x2, quarter);
       const bf16x8 b = to_bf16x8(F1);
-#pragma unroll
-      for (int t = 0; t < 8; ++t) sve[(8 * s1 + t) * TL] = F1[t];
 #pragma unroll
       for (int m = 0; m < NB; ++m) acc[m] = mfma16(A1[m], b, acc[m]);
       __builtin_amdgcn_sched_barrier(0);
@@ -115,25 +118,19 @@ __device__ __forceinline__ void fwd_layer0_gauss_bf16(f32x16 (&acc)[NB], const f
 // ---------------------------------------------------------------------------------------------
 template <int NB, int NBOUT, int TL>
 __device__ __forceinline__ void fwd_layer_bf16(f32x16 (&acc)[NBOUT], const float* R, const float* __restrict__ wp,
-                                               float w0, float* __restrict__ sv, int wcol, int lane) {
+                                               float w0, int lane) {
   const int half = lane >> 5, col = lane & 31;
   const bf16x8* p = reinterpret_cast<const bf16x8*>(wp) + lane;
   constexpr int n8 = NB * 2;  // K = 32*NB features, 16 per step
-  constexpr int hsz = NB * 32 * TL;
   const float krev = w0 * 0.15915494309189535f;  // w0 / (2 pi)
   const float* Rl = R + half * INR_LDS_LD + col;
-  float* svl = sv + half * TL + wcol;
   bf16x8 A0[NBOUT], A1[NBOUT];
-  float Z[8], H0[8], D0[8], H1[8], D1[8];
+  float Z[8], H0[8], H1[8];
   load_afrag16<NBOUT>(A0, p);
 #pragma unroll
   for (int t = 0; t < 8; ++t) Z[t] = Rl[(2 * t) * INR_LDS_LD];
 #pragma unroll
-  for (int t = 0; t < 8; ++t) {
-    float c;
-    sincos_rev(Z[t] * krev, H0[t], c);
-    D0[t] = w0 * c;
-  }
+  for (int t = 0; t < 8; ++t) H0[t] = sin_rev(Z[t] * krev);
 #pragma unroll
   for (int t = 0; t < 8; ++t) Z[t] = Rl[(16 + 2 * t) * INR_LDS_LD];  // step 1 (n8 >= 2)
 #pragma unroll 1
@@ -146,18 +143,9 @@ __device__ __forceinline__ void fwd_layer_bf16(f32x16 (&acc)[NBOUT], const float
     for (int t = 0; t < 8; ++t) Zn[t] = Rl[(16 * s2 + 2 * t) * INR_LDS_LD];
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      float c;
-      sincos_rev(Z[t] * krev, H1[t], c);
-      D1[t] = w0 * c;
-    }
+    for (int t = 0; t < 8; ++t) H1[t] = sin_rev(Z[t] * krev);
     {
       const bf16x8 b = to_bf16x8(H0);
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        svl[(16 * s8 + 2 * t) * TL] = H0[t];
-        svl[hsz + (16 * s8 + 2 * t) * TL] = D0[t];
-      }
 #pragma unroll
       for (int m = 0; m < NBOUT; ++m) acc[m] = mfma16(A0[m], b, acc[m]);
     }
@@ -170,18 +158,9 @@ __device__ __forceinline__ void fwd_layer_bf16(f32x16 (&acc)[NBOUT], const float
     for (int t = 0; t < 8; ++t) Zn[t] = Rl[(16 * s3 + 2 * t) * INR_LDS_LD];
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      float c;
-      sincos_rev(Z[t] * krev, H0[t], c);
-      D0[t] = w0 * c;
-    }
+    for (int t = 0; t < 8; ++t) H0[t] = sin_rev(Z[t] * krev);
     {
       const bf16x8 b = to_bf16x8(H1);
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        svl[(16 * s1 + 2 * t) * TL] = H1[t];
-        svl[hsz + (16 * s1 + 2 * t) * TL] = D1[t];
-      }
 #pragma unroll
       for (int m = 0; m < NBOUT; ++m) acc[m] = mfma16(A1[m], b, acc[m]);
     }
@@ -195,13 +174,15 @@ __device__ __forceinline__ void fwd_layer_bf16(f32x16 (&acc)[NBOUT], const float
 // backward: dH_{l-1}^T = W_l^T . dZ_l^T; HASD: dZ_l = dH_l * act'(z_l) formed on the way and written back to
 // the image (the dW pass reads it).  k extent: n8 steps of 16 image rows.
 // ---------------------------------------------------------------------------------------------
+// HASD: sv_z = stashed z_l; act'(z) = w0 cos(w0 z) is recomputed here
 template <int NB, int TL, bool HASD>
 __device__ __forceinline__ void bwd_dx_bf16(f32x16 (&acc)[NB], float* R, const float* __restrict__ wpT, int n8,
-                                            const float* __restrict__ sv_d, int wcol, int lane) {
+                                            const float* __restrict__ sv_z, float w0, int wcol, int lane) {
   const int half = lane >> 5, col = lane & 31;
   const bf16x8* p = reinterpret_cast<const bf16x8*>(wpT) + lane;
   float* Rl = R + half * INR_LDS_LD + col;
-  const float* dl = HASD ? sv_d + half * TL + wcol : nullptr;
+  const float* dl = HASD ? sv_z + half * TL + wcol : nullptr;
+  const float krev = w0 * 0.15915494309189535f;
   bf16x8 A0[NB], A1[NB];
   float G0[8], D0[8], G1[8], D1[8];
   load_afrag16<NB>(A0, p);
@@ -224,7 +205,7 @@ __device__ __forceinline__ void bwd_dx_bf16(f32x16 (&acc)[NB], float* R, const f
       float g[8];
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
-        g[t] = G0[t] * D0[t];
+        g[t] = HASD ? G0[t] * (w0 * cos_rev(D0[t] * krev)) : G0[t];
         if (HASD) Rl[(16 * s8 + 2 * t) * INR_LDS_LD] = g[t];
       }
       const bf16x8 b = to_bf16x8(g);
@@ -243,7 +224,7 @@ __device__ __forceinline__ void bwd_dx_bf16(f32x16 (&acc)[NB], float* R, const f
       float g[8];
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
-        g[t] = G1[t] * D1[t];
+        g[t] = HASD ? G1[t] * (w0 * cos_rev(D1[t] * krev)) : G1[t];
         if (HASD) Rl[(16 * s1 + 2 * t) * INR_LDS_LD] = g[t];
       }
       const bf16x8 b = to_bf16x8(g);
@@ -254,12 +235,74 @@ __device__ __forceinline__ void bwd_dx_bf16(f32x16 (&acc)[NB], float* R, const f
   }
 }
 
-// dH_0 * act'(z_0) -> image (first layer has no dX); plain coalesced stash loads
+// dZ_0 = dH_0 * w0 cos(w0 z_0) -> image (the first layer has no dX); z_0 from the stash, all loads in flight
 template <int NB, int TL>
-__device__ __forceinline__ void acc_times_d_to_lds_bf16(const f32x16 (&acc)[NB], float* R,
-                                                        const float* __restrict__ sv_d, int wcol, int lane) {
-  acc_times_d_to_lds<NB, TL, false>(acc, R, sv_d, sv_d, wcol, lane);
+__device__ __forceinline__ void acc_times_cos_to_lds(const f32x16 (&acc)[NB], float* R, const float* __restrict__ sv_z,
+                                                     float w0, int wcol, int lane) {
+  const int half = lane >> 5, col = lane & 31;
+  float* Rl = R + (4 * half) * INR_LDS_LD + col;
+  const __amdgpu_buffer_rsrc_t rs = uniform_rsrc(sv_z, NB * 32 * TL * 4);  // SGPR descriptor + one lane offset
+  const int voff = ((4 * half) * TL + wcol) * 4;
+  const float krev = w0 * 0.15915494309189535f;
+#pragma unroll
+  for (int m = 0; m < NB; ++m) {
+    float z[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int soff = (32 * m + (r & 3) + 8 * (r >> 2)) * TL * 4;
+      z[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      Rl[(32 * m + (r & 3) + 8 * (r >> 2)) * INR_LDS_LD] = acc[m][r] * (w0 * cos_rev(z[r] * krev));
+    __builtin_amdgcn_sched_barrier(0);
+  }
 }
+
+// dW B operands.  h_{l-1} = sin(w0 z_{l-1}) from the z stash ("feature on lane", 4 coordinates per fetch) ...
+template <int TL>
+struct BSrcStashSin {
+  const float* __restrict__ z;
+  float krev;
+  struct Raw {
+    f32x4 v;
+  };
+  __device__ __forceinline__ Raw fetch(int n, int q, int lane) const {
+    const int j = 32 * n + (lane & 31);
+    return Raw{*reinterpret_cast<const f32x4*>(z + j * TL + 8 * q + 4 * (lane >> 5))};
+  }
+  __device__ __forceinline__ f32x4 finish(const Raw& r) const {
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = sin_rev(r.v[e] * krev);
+    return o;
+  }
+};
+
+// ... and the gauss encoder features of dW_0, regenerated from the tile's coordinates (xs [TL][3] and the encoder
+// matrix are in LDS): feature j < E is sin(2 pi x.B_j), feature E + j its cosine.
+struct BSrcGauss {
+  const float* xs;        // LDS, [TL][3]
+  const float* encB_lds;  // LDS, [E][3]
+  int E;
+  struct Raw {
+    f32x4 v;
+  };
+  __device__ __forceinline__ Raw fetch(int n, int q, int lane) const {
+    const int j = 32 * n + (lane & 31);
+    const int s = j < E ? j : j - E;
+    const float quarter = j < E ? 0.f : 0.25f;
+    const float b0 = encB_lds[3 * s + 0], b1 = encB_lds[3 * s + 1], b2 = encB_lds[3 * s + 2];
+    const float* x = xs + 3 * (8 * q + 4 * (lane >> 5));
+    Raw r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      r.v[e] = sin_rev(fmaf(x[3 * e + 2], b2, fmaf(x[3 * e + 1], b1, fmaf(x[3 * e], b0, quarter))));
+    return r;
+  }
+  __device__ __forceinline__ f32x4 finish(const Raw& r) const { return r.v; }
+};
 
 // ---------------------------------------------------------------------------------------------
 // dW pass: MT row blocks x one 32-column block n, contraction over the tile's TL coordinates, 16 per MFMA.
@@ -349,7 +392,7 @@ template <int NB, int NW, int MODE>
 __global__ __launch_bounds__(NW * 64) void inr_mlp_bf16_kernel(const NetDesc nd, const LossDesc ld, const MlpArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int TL = NW * 32;
-  constexpr int NS = 2;
+  constexpr int NS = 1;  // stashed tensors per hidden layer: z_l
   const int tid = threadIdx.x;
   const int lane = tid & 63, w = tid >> 6;
   const int half = lane >> 5, col = lane & 31;
@@ -357,6 +400,7 @@ __global__ __launch_bounds__(NW * 64) void inr_mlp_bf16_kernel(const NetDesc nd,
   constexpr int RS = NB * 32 * INR_LDS_LD;
   float* R = lds + w * RS;
   float* encB_lds = lds + NW * RS;
+  float* xs_lds = encB_lds + 3 * nd.E;  // [TL][3] coordinates of the current tile (dW_0 regenerates the features)
   for (int i = tid; i < 3 * nd.E; i += NW * 64) encB_lds[i] = a.encB[i];
   __syncthreads();
   const int D = nd.D;
@@ -372,7 +416,17 @@ __global__ __launch_bounds__(NW * 64) void inr_mlp_bf16_kernel(const NetDesc nd,
     const bool valid = crow < a.B;
     float* sv = a.save + (size_t)(a.save_by_block ? blockIdx.x : tile) * nd.save_floats_per_tile;
     float* sv_last = sv + (size_t)NS * (D - 1) * HSZ;
-    float* sv_enc = sv_last + 4 * TL;
+    float x0 = 0.f, x1 = 0.f, x2 = 0.f;
+    if (valid) {
+      x0 = a.x[3 * crow + 0];
+      x1 = a.x[3 * crow + 1];
+      x2 = a.x[3 * crow + 2];
+    }
+    if (MODE != MODE_FWD && half == 0) {  // read by every wave's dW_0 passes, after several barriers
+      xs_lds[3 * wcol + 0] = x0;
+      xs_lds[3 * wcol + 1] = x1;
+      xs_lds[3 * wcol + 2] = x2;
+    }
 
     // ================================ forward =================================
     INR_STAMP(0);
@@ -381,14 +435,9 @@ __global__ __launch_bounds__(NW * 64) void inr_mlp_bf16_kernel(const NetDesc nd,
       f32x16 acc[NB];
 #pragma unroll
       for (int m = 0; m < NB; ++m) acc[m] = zero16();
-      float x0 = 0.f, x1 = 0.f, x2 = 0.f;
-      if (valid) {
-        x0 = a.x[3 * crow + 0];
-        x1 = a.x[3 * crow + 1];
-        x2 = a.x[3 * crow + 2];
-      }
-      fwd_layer0_gauss_bf16<NB, TL>(acc, a.packed + nd.L[0].pf_off, encB_lds, nd.E, x0, x1, x2, sv_enc, wcol, lane);
+      fwd_layer0_gauss_bf16<NB, TL>(acc, a.packed + nd.L[0].pf_off, encB_lds, nd.E, x0, x1, x2, lane);
       acc_to_lds<NB, true>(acc, R, a.packed + nd.L[0].pbias_off, lane);
+      image_copy<NB, TL, true>(R, sv, wcol, lane);  // z_0
     }
     INR_STAMP(1);
     for (int l = 1; l < D - 1; ++l) {
@@ -396,15 +445,14 @@ __global__ __launch_bounds__(NW * 64) void inr_mlp_bf16_kernel(const NetDesc nd,
       f32x16 acc[NB];
 #pragma unroll
       for (int m = 0; m < NB; ++m) acc[m] = zero16();
-      fwd_layer_bf16<NB, NB, TL>(acc, R, a.packed + Ll.pf_off, nd.L[l - 1].omega, sv + (size_t)(NS * (l - 1)) * HSZ, wcol,
-                                 lane);
+      fwd_layer_bf16<NB, NB, TL>(acc, R, a.packed + Ll.pf_off, nd.L[l - 1].omega, lane);
       acc_to_lds<NB, true>(acc, R, a.packed + Ll.pbias_off, lane);
+      image_copy<NB, TL, true>(R, sv + (size_t)l * HSZ, wcol, lane);  // z_l
       INR_STAMP(1 + l);
     }
     f32x16 accL[1];
     accL[0] = zero16();
-    fwd_layer_bf16<NB, 1, TL>(accL, R, a.packed + LL.pf_off, nd.L[D - 2].omega, sv + (size_t)(NS * (D - 2)) * HSZ, wcol,
-                              lane);
+    fwd_layer_bf16<NB, 1, TL>(accL, R, a.packed + LL.pf_off, nd.L[D - 2].omega, lane);
     float y[4], dy[4], g[4];
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
@@ -447,19 +495,19 @@ __global__ __launch_bounds__(NW * 64) void inr_mlp_bf16_kernel(const NetDesc nd,
     __syncthreads();
     INR_STAMP(11);
     {
-      BSrcStash<TL> bs{sv + (size_t)(NS * (D - 2)) * HSZ};
+      BSrcStashSin<TL> bs{sv + (size_t)(D - 2) * HSZ, nd.L[D - 2].omega * 0.15915494309189535f};
       for (int n = w; n < LL.Kblk; n += NW)
-        dw_pass_bf16<1, TL, false, BSrcStash<TL>>(lds, RS, bs, n, slab + LL.gw_off, slab + LL.gb_off, LL.M, LL.K, first,
+        dw_pass_bf16<1, TL, false, BSrcStashSin<TL>>(lds, RS, bs, n, slab + LL.gw_off, slab + LL.gb_off, LL.M, LL.K, first,
                                                   n == 0, lane);
     }
     INR_STAMP(12);
     f32x16 gacc[NB];
 #pragma unroll
     for (int m = 0; m < NB; ++m) gacc[m] = zero16();
-    bwd_dx_bf16<NB, TL, false>(gacc, R, a.packed + LL.pb_off, 1, nullptr, wcol, lane);  // rows 0..15 (4 used)
+    bwd_dx_bf16<NB, TL, false>(gacc, R, a.packed + LL.pb_off, 1, nullptr, 0.f, wcol, lane);  // rows 0..15 (4 used)
     __syncthreads();
     if (D == 2)
-      acc_times_d_to_lds_bf16<NB, TL>(gacc, R, sv + (size_t)1 * HSZ, wcol, lane);
+      acc_times_cos_to_lds<NB, TL>(gacc, R, sv, nd.L[0].omega, wcol, lane);
     else
       acc_to_lds<NB, false>(gacc, R, nullptr, lane);
     INR_STAMP(13);
@@ -467,20 +515,20 @@ __global__ __launch_bounds__(NW * 64) void inr_mlp_bf16_kernel(const NetDesc nd,
       const LayerDesc& Ll = nd.L[l];
 #pragma unroll
       for (int m = 0; m < NB; ++m) gacc[m] = zero16();
-      bwd_dx_bf16<NB, TL, true>(gacc, R, a.packed + Ll.pb_off, NB * 2, sv + (size_t)(NS * l + 1) * HSZ, wcol, lane);
+      bwd_dx_bf16<NB, TL, true>(gacc, R, a.packed + Ll.pb_off, NB * 2, sv + (size_t)l * HSZ, Ll.omega, wcol, lane);
       INR_STAMP(14 + 4 * l);
       __syncthreads();
       INR_STAMP(15 + 4 * l);
       {
-        BSrcStash<TL> bs{sv + (size_t)(NS * (l - 1)) * HSZ};
+        BSrcStashSin<TL> bs{sv + (size_t)(l - 1) * HSZ, nd.L[l - 1].omega * 0.15915494309189535f};
         for (int n = w; n < Ll.Kblk; n += NW)
-          dw_pass_bf16<NB, TL, true, BSrcStash<TL>>(lds, RS, bs, n, slab + Ll.gw_off, slab + Ll.gb_off, Ll.M, Ll.K, first,
+          dw_pass_bf16<NB, TL, true, BSrcStashSin<TL>>(lds, RS, bs, n, slab + Ll.gw_off, slab + Ll.gb_off, Ll.M, Ll.K, first,
                                                     n == 0, lane);
       }
       INR_STAMP(16 + 4 * l);
       __syncthreads();
       if (l == 1)
-        acc_times_d_to_lds_bf16<NB, TL>(gacc, R, sv + (size_t)1 * HSZ, wcol, lane);
+        acc_times_cos_to_lds<NB, TL>(gacc, R, sv, nd.L[0].omega, wcol, lane);
       else
         acc_to_lds<NB, false>(gacc, R, nullptr, lane);
       INR_STAMP(17 + 4 * l);
@@ -489,9 +537,9 @@ __global__ __launch_bounds__(NW * 64) void inr_mlp_bf16_kernel(const NetDesc nd,
       const LayerDesc& L0 = nd.L[0];
       __syncthreads();
       INR_STAMP(40);
-      BSrcStash<TL> bs{sv_enc};
+      BSrcGauss bs{xs_lds, encB_lds, nd.E};
       for (int n = w; n < L0.Kblk; n += NW)
-        dw_pass_bf16<NB, TL, true, BSrcStash<TL>>(lds, RS, bs, n, slab + L0.gw_off, slab + L0.gb_off, L0.M, L0.K, first,
+        dw_pass_bf16<NB, TL, true, BSrcGauss>(lds, RS, bs, n, slab + L0.gw_off, slab + L0.gb_off, L0.M, L0.K, first,
                                                   n == 0, lane);
       INR_STAMP(41);
       __syncthreads();
@@ -517,7 +565,7 @@ __global__ __launch_bounds__(NW * 64) void inr_mlp_bf16_kernel(const NetDesc nd,
 
 template <int NB, int NW, int MODE>
 inline hipError_t launch_mlp_bf16(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int grid, hipStream_t st) {
-  const size_t lds_bytes = ((size_t)NW * NB * 32 * INR_LDS_LD + 3 * (size_t)nd.E) * sizeof(float);
+  const size_t lds_bytes = ((size_t)NW * NB * 32 * INR_LDS_LD + 3 * (size_t)nd.E + 3 * NW * 32) * sizeof(float);
   auto k = inr_mlp_bf16_kernel<NB, NW, MODE>;
   static thread_local bool attr_set = false;
   if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;

@@ -21,12 +21,13 @@ lib = L.load()
 lib.inr_debug_set_stamp_buffer.argtypes = [C.c_void_p]
 coords = (torch.rand(B, 3) * 2 - 1).to(dev); gt = (torch.randn(B, 2) * 0.2).to(dev)
 nt, nb = eng.launch_dims(B)
-dbg = torch.zeros(nb * 4 * 64, dtype=torch.int64, device=dev)
+NWV = eng.tile_rows // 32
+dbg = torch.zeros(nb * NWV * 64, dtype=torch.int64, device=dev)
 lib.inr_debug_set_stamp_buffer(dbg.data_ptr())
 for _ in range(3):
     eng.train_step(coords, enc.B.contiguous(), gt, M.LossSpec(L.LOSS_L2_HALF))
 torch.cuda.synchronize()
-d = dbg.cpu().view(nb, 4, 64).double()
+d = dbg.cpu().view(nb, NWV, 64).double()
 names = {0: "start", 1: "fwd L0", 2: "fwd L1", 3: "fwd L2", 4: "fwd L3", 10: "fwd last+loss", 11: "sync", 12: "dW last",
          13: "dX last+store", 26: "dX L3", 27: "sync", 28: "dW L3", 29: "sync+store", 22: "dX L2", 23: "sync", 24: "dW L2",
          25: "sync+store", 18: "dX L1", 19: "sync", 20: "dW L1", 21: "sync+store", 40: "dz0+sync", 41: "dW L0", 42: "sync"}
@@ -36,5 +37,5 @@ print(f"B={B} blocks={nb} total cycles/wave: mean {tot.mean():.0f} min {tot.min(
 prev = order[0]
 for i in order[1:]:
     seg = d[:, :, i] - d[:, :, prev]
-    print(f"  {names[i]:>14s}: mean {seg.mean():9.0f}  per-wave means {[round(float(seg[:, w].mean())) for w in range(4)]}")
+    print(f"  {names[i]:>14s}: mean {seg.mean():9.0f}  per-wave means {[round(float(seg[:, w].mean())) for w in range(NWV)]}")
     prev = i
