@@ -185,8 +185,91 @@ __global__ __launch_bounds__(64) void gabor_m2_kernel(const NetDesc nd, const fl
   if (lane == 0) packed[L.pbias_off + nd.NB * 32 + j] = s;
 }
 
+// bf16 plans: slab entries are bf16 at the fp32 layout's element offsets (inr_mlp_bf16_impl.h); sums in fp32,
+// 8 entries (16 bytes) per lane per slab, fixed tree as above.
+__global__ __launch_bounds__(256) void reduce_slabs_bf16_kernel(const float* __restrict__ slabs, int n_blocks,
+                                                                int slab_floats, int P, int loss_off,
+                                                                float* __restrict__ grads,
+                                                                float* __restrict__ loss_out) {
+  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+  __shared__ float part[4][64][8];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i8 = (blockIdx.x * 64 + lane) * 8;
+  const int per = (n_blocks + 3) / 4;
+  const int b0 = w * per, b1 = (b0 + per < n_blocks) ? b0 + per : n_blocks;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (i8 < P) {
+    int b = b0;
+    for (; b + 4 <= b1; b += 4) {
+      bf16x8 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        v[u] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(slabs + (size_t)(b + u) * slab_floats) + i8);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] += (float)v[u][j];
+    }
+    for (; b < b1; ++b) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(slabs + (size_t)b * slab_floats) + i8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s[j] += (float)v[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) part[w][lane][j] = s[j];
+  __syncthreads();
+  if (w == 0 && i8 < P) {
+    for (int j = 0; j < 8 && i8 + j < P; ++j)
+      grads[i8 + j] = ((part[0][lane][j] + part[1][lane][j]) + part[2][lane][j]) + part[3][lane][j];
+  }
+  if (loss_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+    float lsum = 0.f;
+    for (int b = 0; b < n_blocks; ++b) lsum += slabs[(size_t)b * slab_floats + loss_off];
+    loss_out[0] = lsum;
+  }
+}
+
+// same for zero-padded widths (slab rows are whole 32-row blocks, so element offsets differ from flat offsets)
+__global__ __launch_bounds__(256) void reduce_slabs_bf16_any_kernel(const NetDesc nd, const float* __restrict__ slabs,
+                                                                    int n_blocks, float* __restrict__ grads,
+                                                                    float* __restrict__ loss_out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int sf = nd.slab_floats;
+  if (i < nd.P) {
+    int l;
+    VirtualPos vp;
+    float s = 0.f;
+    if (locate(nd, i, l, vp)) {
+      const LayerDesc& L = nd.L[l];
+      const size_t o = vp.n >= 1 ? (size_t)L.gw_off + (size_t)vp.row[0] * L.K + vp.col[0] : (size_t)L.gb_off + vp.bias_row;
+      for (int b = 0; b < n_blocks; ++b) s += (float)reinterpret_cast<const __bf16*>(slabs + (size_t)b * sf)[o];
+    }
+    grads[i] = s;
+  }
+  if (loss_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+    float lsum = 0.f;
+    for (int b = 0; b < n_blocks; ++b) lsum += slabs[(size_t)b * sf + nd.slab_loss_off];
+    loss_out[0] = lsum;
+  }
+}
+
 hipError_t launch_reduce_slabs(const NetDesc& nd, const float* slabs, int n_blocks, float* grads, float* loss_out,
                                const float* params, const float* packed, hipStream_t st) {
+  if (nd.bf16) {
+    bool same = true;  // slab element offsets == flat offsets (hidden width = whole row blocks, e.g. 256)
+    for (int l = 0; l < nd.ND; ++l) same = same && nd.L[l].gw_off == nd.L[l].w_off && nd.L[l].gb_off == nd.L[l].b_off;
+    if (same) {
+      const int grid = (nd.P + 511) / 512;
+      hipLaunchKernelGGL(reduce_slabs_bf16_kernel, dim3(grid), dim3(256), 0, st, slabs, n_blocks, nd.slab_floats, nd.P,
+                         nd.slab_loss_off, grads, loss_out);
+    } else {
+      const int grid = (nd.P + 255) / 256;
+      hipLaunchKernelGGL(reduce_slabs_bf16_any_kernel, dim3(grid), dim3(256), 0, st, nd, slabs, n_blocks, grads,
+                         loss_out);
+    }
+    return hipGetLastError();
+  }
   bool all_real = true;  // ... and slab layout == flat layout (not the case for MFN: L[] order != flat order)
   for (int l = 0; l < nd.ND; ++l) all_real = all_real && nd.L[l].ltype == LT_REAL && nd.L[l].gw_off == nd.L[l].w_off;
   if (all_real) {  // slab offsets == flat offsets; slab_floats % 64 == 0 keeps every slab 16-byte aligned

@@ -308,9 +308,14 @@ struct BSrcGauss {
 // dW pass: MT row blocks x one 32-column block n, contraction over the tile's TL coordinates, 16 per MFMA.
 // A = dZ "feature on lane" (two ds_read_b128 per block), B = the stashed h / encoder features.
 // ---------------------------------------------------------------------------------------------
+// The gradient slab of a bf16 plan holds bf16 partial sums (same element offsets as the fp32 layout, so the first
+// half of the slab's bytes): 258 MB of slab writes per launch were the largest single stream of a kernel that,
+// with the matrix pipe 16x faster, is bound by what it writes to HBM.  Each entry is the fp32 sum over a tile's
+// coordinates rounded once (2^-9 relative, far below the bf16 operand noise already in it); the block
+// reduction adds the slabs in fp32.
 template <int MT, int TL, bool FULLM, bool BIAS, class BSrc>
 __device__ __forceinline__ void dw_pass_bf16_impl(const float* Rall, int region_stride, BSrc& bsrc, int n,
-                                                  float* slab_w, float* slab_b, int M, int K, bool first, int lane) {
+                                                  __bf16* slab_w, __bf16* slab_b, int M, int K, bool first, int lane) {
   const int half = lane >> 5, li = lane & 31;
   f32x16 acc[MT];
   float bsum[MT];
@@ -326,8 +331,8 @@ __device__ __forceinline__ void dw_pass_bf16_impl(const float* Rall, int region_
       for (int r = 0; r < 16; ++r) {
         const int rowu = 32 * m + (r & 3) + 8 * (r >> 2);
         const bool ok = colok && (FULLM || rowu + 4 * half < M);
-        const float* rowp = slab_w + (size_t)(FULLM ? rowu : 0) * K;
-        const float v = rowp[ok ? (FULLM ? lane_off : rowu * K + lane_off) : 0];
+        const __bf16* rowp = slab_w + (size_t)(FULLM ? rowu : 0) * K;
+        const float v = (float)rowp[ok ? (FULLM ? lane_off : rowu * K + lane_off) : 0];
         acc[m][r] = ok ? v : 0.f;
       }
     }
@@ -356,28 +361,28 @@ __device__ __forceinline__ void dw_pass_bf16_impl(const float* Rall, int region_
       if (colok) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          float* rowp = slab_w + (size_t)(32 * m + (r & 3) + 8 * (r >> 2)) * K;
-          rowp[lane_off] = acc[m][r];
+          __bf16* rowp = slab_w + (size_t)(32 * m + (r & 3) + 8 * (r >> 2)) * K;
+          rowp[lane_off] = (__bf16)acc[m][r];
         }
       }
     } else {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int rowu = 32 * m + (r & 3) + 8 * (r >> 2);
-        if (colok && rowu + 4 * half < M) slab_w[(size_t)rowu * K + lane_off] = acc[m][r];
+        if (colok && rowu + 4 * half < M) slab_w[(size_t)rowu * K + lane_off] = (__bf16)acc[m][r];
       }
     }
     if (BIAS) {
       const float tot = bsum[m] + __shfl_xor(bsum[m], 32);
       const int row = 32 * m + li;
-      if (half == 0 && (FULLM || row < M)) slab_b[row] = first ? tot : slab_b[row] + tot;
+      if (half == 0 && (FULLM || row < M)) slab_b[row] = (__bf16)(first ? tot : (float)slab_b[row] + tot);
     }
   }
 }
 
 template <int MT, int TL, bool FULLM, class BSrc>
-__device__ __forceinline__ void dw_pass_bf16(const float* Rall, int region_stride, BSrc& bsrc, int n, float* slab_w,
-                                             float* slab_b, int M, int K, bool first, bool do_bias, int lane) {
+__device__ __forceinline__ void dw_pass_bf16(const float* Rall, int region_stride, BSrc& bsrc, int n, __bf16* slab_w,
+                                             __bf16* slab_b, int M, int K, bool first, bool do_bias, int lane) {
   if (do_bias)
     dw_pass_bf16_impl<MT, TL, FULLM, true, BSrc>(Rall, region_stride, bsrc, n, slab_w, slab_b, M, K, first, lane);
   else
@@ -405,7 +410,8 @@ __global__ __launch_bounds__(NW * 64) void inr_mlp_bf16_kernel(const NetDesc nd,
   __syncthreads();
   const int D = nd.D;
   constexpr int HSZ = NB * 32 * TL;
-  float* slab = (MODE != MODE_FWD) ? a.slabs + (size_t)blockIdx.x * nd.slab_floats : nullptr;
+  float* slab_f = (MODE != MODE_FWD) ? a.slabs + (size_t)blockIdx.x * nd.slab_floats : nullptr;
+  __bf16* slab = reinterpret_cast<__bf16*>(slab_f);  // bf16 entries at the fp32 layout's element offsets
   float loss_acc = 0.f;
   bool first = true;
   const LayerDesc& LL = nd.L[D - 1];
@@ -558,7 +564,7 @@ __global__ __launch_bounds__(NW * 64) void inr_mlp_bf16_kernel(const NetDesc nd,
     if (tid == 0) {
       float t = 0.f;
       for (int i = 0; i < NW; ++i) t += lds[i];
-      slab[nd.slab_loss_off] = t;
+      slab_f[nd.slab_loss_off] = t;  // fp32 word behind the (half-length) bf16 region
     }
   }
 }
