@@ -47,3 +47,20 @@ def step2():
 ms = timeit(step2, n=5, warm=2)
 res["MultiscaleKFourier_8x512_LSL_B100000"] = {"ms_per_step": ms, "samples_per_s": B / ms * 1e3, "TFLOPs": 19423232 * B / ms / 1e9, "frac_f32_mfma": 19423232 * B / ms / 1e9 / 157.3}
 print(json.dumps(res, indent=1))
+
+# the reference's shipped SIREN config (config/remote/config_siren_kspace.yaml): depth 8 / width 512, batch 100 000
+B = 100000
+torch.manual_seed(0)
+net = dict(network_input_size=512, network_output_size=2, network_depth=8, network_width=512, last_tanh=True)
+enc = M.Positional_Encoder(dict(embedding="gauss", scale=4, embedding_size=256, coordinates_size=3), device=dev)
+model = M.SIREN(net).to(dev); eng = model.fused_engine(256)
+coords = (torch.rand(B, 3) * 2 - 1).to(dev); gt = (torch.randn(B, 2) * 0.2).to(dev)
+spec = M.LossSpec(L.LOSS_L2_HALF)
+def step():
+    eng.train_step(coords, enc.B.contiguous(), gt, spec); eng.adam_step(3e-5)
+ms = timeit(step, n=10)
+mac = 512 * 512 + 6 * 512 * 512 + 512 * 2
+flop = 2 * (3 * mac - 512 * 512)
+res["SIREN_8x512_L2_B100000"] = {"ms_per_step": ms, "samples_per_s": B / ms * 1e3, "TFLOPs": flop * B / ms / 1e9,
+                                 "frac_f32_mfma": flop * B / ms / 1e9 / 157.3}
+print(json.dumps(res, indent=1))
