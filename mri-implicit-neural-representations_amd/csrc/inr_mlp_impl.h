@@ -253,7 +253,7 @@ __device__ __forceinline__ void fwd_layer0_gauss(f32x16 (&acc)[NB], const float*
 }
 
 // forward, layer 0, input matrix x [B,K0] in memory (what model.forward receives, train.py:169)
-template <int NB>
+template <int NB, int NBT = NB>
 __device__ __forceinline__ void fwd_layer0_x(f32x16 (&acc)[NB], const float* __restrict__ wp,
                                              const float* __restrict__ xrow, bool valid, int K0, int Kpad8,
                                              int lane) {
@@ -265,7 +265,7 @@ __device__ __forceinline__ void fwd_layer0_x(f32x16 (&acc)[NB], const float* __r
 #pragma unroll 1
   for (int s4 = 0; s4 < n4; ++s4) {
     const int nx = (s4 + 1 < n4) ? (s4 + 1) : s4;
-    load_afrag<NB>(a_nxt, p + (size_t)nx * NB * 64);
+    load_afrag<NB>(a_nxt, p + (size_t)nx * NBT * 64);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int k = 2 * (4 * s4 + e) + half;
@@ -378,7 +378,7 @@ __device__ __forceinline__ void fwd_group(f32x16 (&acc)[NBOUT], const f32x4 (&a_
   }
 }
 
-template <int NB, int NBOUT, int TL, int HACT, bool SAVE>
+template <int NB, int NBOUT, int TL, int HACT, bool SAVE, int NBT = NBOUT>
 __device__ __forceinline__ void fwd_layer(f32x16 (&acc)[NBOUT], const float* R, const float* __restrict__ wp,
                                           const ActParams& ap, float* __restrict__ sv, int wcol, int lane) {
   const int half = lane >> 5, col = lane & 31;
@@ -401,9 +401,9 @@ __device__ __forceinline__ void fwd_layer(f32x16 (&acc)[NBOUT], const float* R, 
   for (int s4 = 0; s4 < n4; s4 += 2) {
     const int n2 = (s4 + 2 < n4) ? (s4 + 2) : s4;
     const int n3 = (s4 + 3 < n4) ? (s4 + 3) : s4;
-    fwd_group<NBOUT, TL, HACT, SAVE>(acc, A0, A1, p + (size_t)(s4 + 1) * NBOUT * 64, Z, ZP, ZO, ZQ, Rcol, n2, s4, ap,
+    fwd_group<NBOUT, TL, HACT, SAVE>(acc, A0, A1, p + (size_t)(s4 + 1) * NBT * 64, Z, ZP, ZO, ZQ, Rcol, n2, s4, ap,
                                      half, svl, hsz, H0, D0, E0, F0, G0, H1, D1, E1, F1, G1);
-    fwd_group<NBOUT, TL, HACT, SAVE>(acc, A1, A0, p + (size_t)n2 * NBOUT * 64, Z, ZP, ZO, ZQ, Rcol, n3, s4 + 1, ap,
+    fwd_group<NBOUT, TL, HACT, SAVE>(acc, A1, A0, p + (size_t)n2 * NBT * 64, Z, ZP, ZO, ZQ, Rcol, n3, s4 + 1, ap,
                                      half, svl, hsz, H1, D1, E1, F1, G1, H0, D0, E0, F0, G0);
   }
 }

@@ -1,0 +1,252 @@
+// inr_mlp_wide_impl.h -- SIREN / FFN with 257..512 hidden features (16 row blocks; the reference's shipped
+// config/remote/config_siren_kspace.yaml is 8 x 512) with TWO waves per group of 32 coordinates.
+//
+// Same idea as inr_mfn_wide_impl.h: a 512 x 32 fp32 image is 73.7 KB, a workgroup holds two, and with one wave per
+// image only two SIMDs of the CU work.  Waves (g, hh) = (wave >> 1, wave & 1) share the image of coordinate group
+// g and split every GEMM by output rows (row blocks [8 hh, 8 hh + 8)).  Both waves of a pair form the lazy
+// activation of all 512 input rows (VALU work doubles, ~10% of the MFMA time at this width), wave hh = 0 writes
+// the stash; dZ = dH * act' becomes a separate owner-rows pass; the last layer (one row block) runs on hh = 0.
+// Arithmetic, stash and slab layouts are those of inr_mlp_impl.h.
+#pragma once
+#include "inr_mlp_impl.h"
+
+namespace inr {
+
+template <int TL>
+__device__ __forceinline__ void rows_times(float* R, const float* __restrict__ fac, int r0, int wcol, int lane) {
+  const int half = lane >> 5, col = lane & 31;
+#pragma unroll 8
+  for (int r = r0 + half; r < r0 + 256; r += 2) R[swz(r, col)] *= fac[r * TL + wcol];
+}
+
+template <int INMODE, int HACT, int MODE>
+__global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, const LossDesc ld, const MlpArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int NB = 16, MT = 8, NG = 2, NW = 4, NS = 2;
+  constexpr int TL = NG * 32;
+  constexpr int RS = NB * 32 * INR_LDS_LD;
+  constexpr int HSZ = NB * 32 * TL;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, w = tid >> 6;
+  const int g = w >> 1, hh = w & 1, m0 = MT * hh;
+  const int half = lane >> 5, col = lane & 31;
+  const int wcol = g * 32 + col;
+  float* R = lds + g * RS;
+  float* Rown = R + m0 * 32 * INR_LDS_LD;
+  float* encB_lds = lds + NG * RS;
+  if (INMODE == IN_GAUSS) {
+    for (int i = tid; i < 3 * nd.E; i += NW * 64) encB_lds[i] = a.encB[i];
+    __syncthreads();
+  }
+  const int D = nd.D;
+  float* slab = (MODE != MODE_FWD) ? a.slabs + (size_t)blockIdx.x * nd.slab_floats : nullptr;
+  float loss_acc = 0.f;
+  bool first = true;
+  const LayerDesc& LL = nd.L[D - 1];
+  const size_t aoff = (size_t)m0 * 256;
+
+  for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+    const long long row0 = (long long)tile * TL;
+    const long long crow = row0 + wcol;
+    const bool valid = crow < a.B;
+    const bool saving = (MODE != MODE_FWD) || (a.save != nullptr);
+    float* sv = a.save;
+    if (saving) sv += (size_t)(a.save_by_block ? blockIdx.x : tile) * nd.save_floats_per_tile;
+    float* sv_last = sv + (size_t)NS * (D - 1) * HSZ;
+    float* sv_enc = sv_last + 4 * TL;
+    const bool stash = saving && hh == 0;  // one wave of the pair writes the (shared) lazy-activation stash
+
+    // ================================ forward =================================
+    if (MODE != MODE_BWD) {
+      {
+        f32x16 acc[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = zero16();
+        const LayerDesc& L0 = nd.L[0];
+        if (INMODE == IN_GAUSS) {
+          float x0 = 0.f, x1 = 0.f, x2 = 0.f;
+          if (valid) {
+            x0 = a.x[3 * crow + 0];
+            x1 = a.x[3 * crow + 1];
+            x2 = a.x[3 * crow + 2];
+          }
+          const float two_pi = 6.283185307179586f;
+          if (stash)
+            fwd_layer0_gauss<MT, TL, true, NB>(acc, a.packed + L0.pf_off + aoff, encB_lds, nd.E, two_pi * x0, two_pi * x1,
+                                               two_pi * x2, sv_enc, wcol, lane);
+          else
+            fwd_layer0_gauss<MT, TL, false, NB>(acc, a.packed + L0.pf_off + aoff, encB_lds, nd.E, two_pi * x0,
+                                                two_pi * x1, two_pi * x2, nullptr, wcol, lane);
+        } else {
+          fwd_layer0_x<MT, NB>(acc, a.packed + L0.pf_off + aoff, a.x + (size_t)(valid ? crow : 0) * L0.K, valid, L0.K,
+                               L0.Kpad8, lane);
+        }
+        acc_to_lds<MT, true>(acc, Rown, a.packed + L0.pbias_off + m0 * 32, lane);
+      }
+      __syncthreads();  // z_0 complete
+      for (int l = 1; l < D - 1; ++l) {
+        const LayerDesc& Ll = nd.L[l];
+        const ActParams ap{nd.L[l - 1].omega, nd.L[l - 1].s0};
+        f32x16 acc[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = zero16();
+        float* sh = sv + (size_t)(NS * (l - 1)) * HSZ;
+        if (stash)
+          fwd_layer<NB, MT, TL, HACT, true, NB>(acc, R, a.packed + Ll.pf_off + aoff, ap, sh, wcol, lane);
+        else
+          fwd_layer<NB, MT, TL, HACT, false, NB>(acc, R, a.packed + Ll.pf_off + aoff, ap, nullptr, wcol, lane);
+        __syncthreads();  // both waves of the pair have read z_{l-1}
+        acc_to_lds<MT, true>(acc, Rown, a.packed + Ll.pbias_off + m0 * 32, lane);
+        __syncthreads();  // z_l complete
+      }
+      float g4[4] = {0.f, 0.f, 0.f, 0.f}, dy[4] = {0.f, 0.f, 0.f, 0.f};
+      if (hh == 0) {  // last layer: one row block
+        f32x16 accL[1];
+        accL[0] = zero16();
+        const ActParams ap{nd.L[D - 2].omega, nd.L[D - 2].s0};
+        float* sh = sv + (size_t)(NS * (D - 2)) * HSZ;
+        if (saving)
+          fwd_layer<NB, 1, TL, HACT, true>(accL, R, a.packed + LL.pf_off, ap, sh, wcol, lane);
+        else
+          fwd_layer<NB, 1, TL, HACT, false>(accL, R, a.packed + LL.pf_off, ap, nullptr, wcol, lane);
+        float y[4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+          float z = accL[0][o];
+          if (o < nd.out_f) z += a.packed[LL.pbias_off + o];
+          act_fwd_rt(nd.last_act, z, nd.w0, y[o], dy[o]);
+          if (half == 0 && valid && o < nd.out_f && a.out != nullptr) a.out[crow * nd.out_f + o] = y[o];
+        }
+        if (MODE == MODE_FWD) {
+          if (saving && half == 0) {
+#pragma unroll
+            for (int o = 0; o < 4; ++o) sv_last[o * TL + wcol] = dy[o];
+          }
+        } else if (half == 0 && valid && (a.mask == nullptr || a.mask[crow] != 0)) {
+          float t[4] = {0.f, 0.f, 0.f, 0.f};
+          for (int o = 0; o < nd.out_f; ++o) t[o] = a.gt[crow * nd.out_f + o];
+          loss_acc += loss_row(ld, nd.out_f, y, t, g4);
+        }
+      }
+      __syncthreads();  // the last layer has read z_{D-2}: rows may be overwritten (dZ_last / the next tile's z_0)
+      if (MODE == MODE_FUSED) {
+        if (hh == 0) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float v = 0.f;
+            if (r < 4 && half == 0 && r < nd.out_f) v = g4[r & 3] * dy[r & 3];
+            R[swz(acc_row(r, half), col)] = v;
+          }
+        }
+      }
+    }
+
+    // ================================ backward ================================
+    if (MODE != MODE_FWD) {
+      if (MODE == MODE_BWD && hh == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = 0.f;
+          if (r < 4 && half == 0 && r < nd.out_f && valid) v = a.dout[crow * nd.out_f + r] * sv_last[r * TL + wcol];
+          R[swz(acc_row(r, half), col)] = v;
+        }
+      }
+      __syncthreads();  // every group's dZ_last is in LDS
+      {
+        BSrcStash<TL> bs{sv + (size_t)(NS * (D - 2)) * HSZ};
+        for (int n = w; n < LL.Kblk; n += NW)
+          dw_pass<1, TL, false, BSrcStash<TL>>(lds, RS, bs, n, slab + LL.gw_off, slab + LL.gb_off, LL.M, LL.K, first,
+                                               n == 0, lane);
+      }
+      f32x16 gacc[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) gacc[m] = zero16();
+      bwd_dx<MT, TL, false, false, NB>(gacc, R, a.packed + LL.pb_off + aoff, LL.Mpad8, nullptr, wcol, lane);
+      __syncthreads();  // all reads of dZ_last are done
+      if (D == 2)
+        acc_times_d_to_lds<MT, TL, false>(gacc, Rown, sv + (size_t)1 * HSZ + (size_t)m0 * 32 * TL,
+                                          sv + (size_t)1 * HSZ + (size_t)m0 * 32 * TL, wcol, lane);  // dZ_0 (own rows)
+      else
+        acc_to_lds<MT, false>(gacc, Rown, nullptr, lane);  // dH_{D-2} (own rows)
+      for (int l = D - 2; l >= 1; --l) {
+        const LayerDesc& Ll = nd.L[l];
+        __syncthreads();  // dH_l complete
+        rows_times<TL>(R, sv + (size_t)(NS * l + 1) * HSZ, 256 * hh, wcol, lane);  // own rows: dZ_l = dH_l * act'
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < MT; ++m) gacc[m] = zero16();
+        bwd_dx<MT, TL, false, false, NB>(gacc, R, a.packed + Ll.pb_off + aoff, Ll.Mpad8, nullptr, wcol, lane);
+        {
+          BSrcStash<TL> bs{sv + (size_t)(NS * (l - 1)) * HSZ};
+          for (int it = w; it < 2 * Ll.Kblk; it += NW) {  // (column block, row half) items over the four waves
+            const int n = it >> 1, c = it & 1;
+            dw_pass<MT, TL, true, BSrcStash<TL>>(lds + c * MT * 32 * INR_LDS_LD, RS, bs, n,
+                                                 slab + Ll.gw_off + (size_t)c * 256 * Ll.K, slab + Ll.gb_off + c * 256,
+                                                 Ll.M, Ll.K, first, n == 0, lane);
+          }
+        }
+        __syncthreads();  // dZ_l has been read by every dW pass and dX
+        if (l == 1)
+          acc_times_d_to_lds<MT, TL, false>(gacc, Rown, sv + (size_t)1 * HSZ + (size_t)m0 * 32 * TL,
+                                            sv + (size_t)1 * HSZ + (size_t)m0 * 32 * TL, wcol, lane);
+        else
+          acc_to_lds<MT, false>(gacc, Rown, nullptr, lane);
+      }
+      {
+        const LayerDesc& L0 = nd.L[0];
+        __syncthreads();  // dZ_0 complete
+        if (INMODE == IN_GAUSS) {
+          BSrcStash<TL> bs{sv_enc};
+          for (int it = w; it < 2 * L0.Kblk; it += NW) {
+            const int n = it >> 1, c = it & 1;
+            dw_pass<MT, TL, true, BSrcStash<TL>>(lds + c * MT * 32 * INR_LDS_LD, RS, bs, n,
+                                                 slab + L0.gw_off + (size_t)c * 256 * L0.K, slab + L0.gb_off + c * 256,
+                                                 L0.M, L0.K, first, n == 0, lane);
+          }
+        } else {
+          BSrcX bs{a.x, row0, a.B, L0.K};
+          for (int it = w; it < 2 * L0.Kblk; it += NW) {
+            const int n = it >> 1, c = it & 1;
+            dw_pass<MT, TL, true, BSrcX>(lds + c * MT * 32 * INR_LDS_LD, RS, bs, n,
+                                         slab + L0.gw_off + (size_t)c * 256 * L0.K, slab + L0.gb_off + c * 256, L0.M,
+                                         L0.K, first, n == 0, lane);
+          }
+        }
+        __syncthreads();
+      }
+      first = false;
+    }
+  }
+
+  if (MODE == MODE_FUSED) {
+    float v = loss_acc;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    __syncthreads();
+    if (lane == 0) lds[w] = v;
+    __syncthreads();
+    if (tid == 0) {
+      float t = 0.f;
+      for (int i = 0; i < NW; ++i) t += lds[i];
+      slab[nd.slab_loss_off] = t;
+    }
+  }
+}
+
+template <int INMODE, int HACT, int MODE>
+inline hipError_t launch_mlp_wide(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int grid, hipStream_t st) {
+  const size_t lds_bytes = ((size_t)2 * 16 * 32 * INR_LDS_LD + (INMODE == IN_GAUSS ? 3 * (size_t)nd.E : 0)) * sizeof(float);
+  auto k = inr_mlp_wide_kernel<INMODE, HACT, MODE>;
+  static thread_local bool attr_set = false;
+  if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds_bytes, st, nd, ld, a);
+  return hipGetLastError();
+}
+
+}  // namespace inr
