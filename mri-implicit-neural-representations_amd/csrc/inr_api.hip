@@ -229,7 +229,7 @@ int inr_plan_create(const inr_net_desc* d, inr_plan** out) {
     if (NB < 0)
       return fail(INR_ERR_UNSUPPORTED, "inr_plan_create: WIRE with %d complex hidden features (kernels are built for "
                   "up to 192 = 384 interleaved rows, network_width 256 gives 181; WIRE2D: up to 256)", d->width);
-    NW = NB == 12 ? 3 : (NB == 16 ? 2 : 4);
+    NW = (NB == 12 || NB == 16) ? 2 : 4;  // 12 / 16 blocks: 64-coordinate tiles, two waves per coordinate group
     if (wire2d && 2 * D - 1 > INR_MAX_LAYERS)
       return fail(INR_ERR_INVALID, "inr_plan_create: WIRE2D depth %d", d->depth);
     if (d->input != INR_INPUT_X)

@@ -8,9 +8,9 @@ namespace inr {
 template <int INMODE, int HACT>
 static hipError_t dispatch(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int mode, int grid, hipStream_t st) {
   switch (mode) {
-    case MODE_FWD: return launch_mlp_wide<INMODE, HACT, MODE_FWD>(nd, ld, a, grid, st);
-    case MODE_BWD: return launch_mlp_wide<INMODE, HACT, MODE_BWD>(nd, ld, a, grid, st);
-    default: return launch_mlp_wide<INMODE, HACT, MODE_FUSED>(nd, ld, a, grid, st);
+    case MODE_FWD: return launch_mlp_wide<16, INMODE, HACT, MODE_FWD>(nd, ld, a, grid, st);
+    case MODE_BWD: return launch_mlp_wide<16, INMODE, HACT, MODE_BWD>(nd, ld, a, grid, st);
+    default: return launch_mlp_wide<16, INMODE, HACT, MODE_FUSED>(nd, ld, a, grid, st);
   }
 }
 

@@ -1,5 +1,6 @@
 // inr_mlp_wide_impl.h -- SIREN / FFN with 257..512 hidden features (16 row blocks; the reference's shipped
-// config/remote/config_siren_kspace.yaml is 8 x 512) with TWO waves per group of 32 coordinates.
+// config/remote/config_siren_kspace.yaml is 8 x 512) and WIRE with 129..192 complex features (12 blocks of
+// interleaved rows; network_width 256 -> 181) with TWO waves per group of 32 coordinates.
 //
 // Same idea as inr_mfn_wide_impl.h: a 512 x 32 fp32 image is 73.7 KB, a workgroup holds two, and with one wave per
 // image only two SIMDs of the CU work.  Waves (g, hh) = (wave >> 1, wave & 1) share the image of coordinate group
@@ -12,17 +13,31 @@
 
 namespace inr {
 
-template <int TL>
-__device__ __forceinline__ void rows_times(float* R, const float* __restrict__ fac, int r0, int wcol, int lane) {
+// owner-rows pass dZ = dH * act'(z) on image rows [r0, r0 + RH) of this wave's coordinate column.
+// PAIR (WIRE): rows (2i, 2i+1) hold (p, q) = dL/d(y_r, y_i); dZ[row] = p * dA[row] + q * dB[row]
+template <int TL, int RH, bool PAIR>
+__device__ __forceinline__ void rows_times(float* R, const float* __restrict__ dA, const float* __restrict__ dB, int r0,
+                                           int wcol, int lane) {
   const int half = lane >> 5, col = lane & 31;
+  if (PAIR) {
+#pragma unroll 4
+    for (int r = r0 + 2 * half; r < r0 + RH; r += 4) {  // this lane-half's pairs
+      const float p = R[swz(r, col)], q = R[swz(r + 1, col)];
+      R[swz(r, col)] = fmaf(p, dA[r * TL + wcol], q * dB[r * TL + wcol]);
+      R[swz(r + 1, col)] = fmaf(p, dA[(r + 1) * TL + wcol], q * dB[(r + 1) * TL + wcol]);
+    }
+  } else {
 #pragma unroll 8
-  for (int r = r0 + half; r < r0 + 256; r += 2) R[swz(r, col)] *= fac[r * TL + wcol];
+    for (int r = r0 + half; r < r0 + RH; r += 2) R[swz(r, col)] *= dA[r * TL + wcol];
+  }
 }
 
-template <int INMODE, int HACT, int MODE>
+template <int NB, int INMODE, int HACT, int MODE>
 __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, const LossDesc ld, const MlpArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int NB = 16, MT = 8, NG = 2, NW = 4, NS = 2;
+  constexpr bool PAIR = HACT == ACT_GABOR;
+  constexpr int MT = NB / 2, NG = 2, NW = 4, NS = PAIR ? 3 : 2;
+  constexpr int RH = MT * 32;  // image rows per wave of a pair
   constexpr int TL = NG * 32;
   constexpr int RS = NB * 32 * INR_LDS_LD;
   constexpr int HSZ = NB * 32 * TL;
@@ -164,14 +179,15 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
       bwd_dx<MT, TL, false, false, NB>(gacc, R, a.packed + LL.pb_off + aoff, LL.Mpad8, nullptr, wcol, lane);
       __syncthreads();  // all reads of dZ_last are done
       if (D == 2)
-        acc_times_d_to_lds<MT, TL, false>(gacc, Rown, sv + (size_t)1 * HSZ + (size_t)m0 * 32 * TL,
-                                          sv + (size_t)1 * HSZ + (size_t)m0 * 32 * TL, wcol, lane);  // dZ_0 (own rows)
+        acc_times_d_to_lds<MT, TL, PAIR>(gacc, Rown, sv + (size_t)1 * HSZ + (size_t)m0 * 32 * TL,
+                                         sv + (size_t)2 * HSZ + (size_t)m0 * 32 * TL, wcol, lane);  // dZ_0 (own rows)
       else
         acc_to_lds<MT, false>(gacc, Rown, nullptr, lane);  // dH_{D-2} (own rows)
       for (int l = D - 2; l >= 1; --l) {
         const LayerDesc& Ll = nd.L[l];
         __syncthreads();  // dH_l complete
-        rows_times<TL>(R, sv + (size_t)(NS * l + 1) * HSZ, 256 * hh, wcol, lane);  // own rows: dZ_l = dH_l * act'
+        rows_times<TL, RH, PAIR>(R, sv + (size_t)(NS * l + 1) * HSZ, sv + (size_t)(NS * l + 2) * HSZ, RH * hh, wcol,
+                                 lane);  // own rows: dZ_l = dH_l * act'
         __syncthreads();
 #pragma unroll
         for (int m = 0; m < MT; ++m) gacc[m] = zero16();
@@ -181,14 +197,14 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
           for (int it = w; it < 2 * Ll.Kblk; it += NW) {  // (column block, row half) items over the four waves
             const int n = it >> 1, c = it & 1;
             dw_pass<MT, TL, true, BSrcStash<TL>>(lds + c * MT * 32 * INR_LDS_LD, RS, bs, n,
-                                                 slab + Ll.gw_off + (size_t)c * 256 * Ll.K, slab + Ll.gb_off + c * 256,
+                                                 slab + Ll.gw_off + (size_t)c * RH * Ll.K, slab + Ll.gb_off + c * RH,
                                                  Ll.M, Ll.K, first, n == 0, lane);
           }
         }
         __syncthreads();  // dZ_l has been read by every dW pass and dX
         if (l == 1)
-          acc_times_d_to_lds<MT, TL, false>(gacc, Rown, sv + (size_t)1 * HSZ + (size_t)m0 * 32 * TL,
-                                            sv + (size_t)1 * HSZ + (size_t)m0 * 32 * TL, wcol, lane);
+          acc_times_d_to_lds<MT, TL, PAIR>(gacc, Rown, sv + (size_t)1 * HSZ + (size_t)m0 * 32 * TL,
+                                           sv + (size_t)2 * HSZ + (size_t)m0 * 32 * TL, wcol, lane);
         else
           acc_to_lds<MT, false>(gacc, Rown, nullptr, lane);
       }
@@ -200,7 +216,7 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
           for (int it = w; it < 2 * L0.Kblk; it += NW) {
             const int n = it >> 1, c = it & 1;
             dw_pass<MT, TL, true, BSrcStash<TL>>(lds + c * MT * 32 * INR_LDS_LD, RS, bs, n,
-                                                 slab + L0.gw_off + (size_t)c * 256 * L0.K, slab + L0.gb_off + c * 256,
+                                                 slab + L0.gw_off + (size_t)c * RH * L0.K, slab + L0.gb_off + c * RH,
                                                  L0.M, L0.K, first, n == 0, lane);
           }
         } else {
@@ -208,7 +224,7 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
           for (int it = w; it < 2 * L0.Kblk; it += NW) {
             const int n = it >> 1, c = it & 1;
             dw_pass<MT, TL, true, BSrcX>(lds + c * MT * 32 * INR_LDS_LD, RS, bs, n,
-                                         slab + L0.gw_off + (size_t)c * 256 * L0.K, slab + L0.gb_off + c * 256, L0.M,
+                                         slab + L0.gw_off + (size_t)c * RH * L0.K, slab + L0.gb_off + c * RH, L0.M,
                                          L0.K, first, n == 0, lane);
           }
         }
@@ -233,10 +249,10 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
   }
 }
 
-template <int INMODE, int HACT, int MODE>
+template <int NB, int INMODE, int HACT, int MODE>
 inline hipError_t launch_mlp_wide(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int grid, hipStream_t st) {
-  const size_t lds_bytes = ((size_t)2 * 16 * 32 * INR_LDS_LD + (INMODE == IN_GAUSS ? 3 * (size_t)nd.E : 0)) * sizeof(float);
-  auto k = inr_mlp_wide_kernel<INMODE, HACT, MODE>;
+  const size_t lds_bytes = ((size_t)2 * NB * 32 * INR_LDS_LD + (INMODE == IN_GAUSS ? 3 * (size_t)nd.E : 0)) * sizeof(float);
+  auto k = inr_mlp_wide_kernel<NB, INMODE, HACT, MODE>;
   static thread_local bool attr_set = false;
   if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
   if (!attr_set) {
