@@ -46,7 +46,6 @@ def step2():
     eng.train_step(coords, enc.B.contiguous(), gt, spec, dist=dist, scale=0.5, cons=cons); eng.adam_step(3e-4)
 ms = timeit(step2, n=5, warm=2)
 res["MultiscaleKFourier_8x512_LSL_B100000"] = {"ms_per_step": ms, "samples_per_s": B / ms * 1e3, "TFLOPs": 19423232 * B / ms / 1e9, "frac_f32_mfma": 19423232 * B / ms / 1e9 / 157.3}
-print(json.dumps(res, indent=1))
 
 # the reference's shipped SIREN config (config/remote/config_siren_kspace.yaml): depth 8 / width 512, batch 100 000
 B = 100000
