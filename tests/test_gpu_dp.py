@@ -1,0 +1,95 @@
+"""Data-parallel path on the real kernels -- ``-m gpu``: two processes share cuda:0 and exchange through gloo (the
+collective semantics are torch.distributed's; the driver's multi-GPU runs use nccl = RCCL with the same calls).
+Each rank runs the product trainers with (rank, world = 2); the result must equal the single-process run up to
+summation order: fused SIREN step, masked / per-coil TV step with its halo row, the multiscale step with its
+globally-normalised consistency term, and the ring ensemble's assembled prediction."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+NET = dict(network_input_size=32, network_output_size=2, network_depth=3, network_width=32, last_tanh=True)
+ENC = dict(embedding="gauss", scale=2, embedding_size=16, coordinates_size=3)
+BASE = dict(loss="L2", lr=1e-3, max_epoch=2, weight_decay=0.0, beta1=0.9, beta2=0.999, net=NET, encoder=ENC)
+SHAPE = (2, 24, 20)
+
+
+def _cases():
+    return {
+        "siren": dict(BASE, model="SIREN", batch_size=333),
+        "tv": dict(BASE, model="SIREN", batch_size=1, per_coil=True, use_tv=True, undersampling="grid-2*2"),
+        "fourier": dict(BASE, model="Fourier", batch_size=400),
+        "multiscale": dict(BASE, model="MultiscaleKFourier", loss="LSL", loss_opts=dict(eps=3e-3), batch_size=400,
+                           partition=dict(no_steps=20, no_models=4),
+                           net=dict(NET, network_depth=8)),
+        "ensemble": dict(BASE, model="SIREN", batch_size=SHAPE[1] * SHAPE[2], partition=dict(no_steps=20, no_models=3)),
+    }
+
+
+def _run(case, rank, world, pg=None):
+    from inr_mi355x.synthetic import make_kspace
+    from inr_mi355x.train import INRTrainer
+    from inr_mi355x.train_kspace_multiscale import MultiscaleTrainer
+    from inr_mi355x.train_ring_ensemble import RingEnsembleTrainer
+    cfg = _cases()[case]
+    image, coords, shape = make_kspace(*SHAPE)
+    dev = torch.device("cuda:0")
+    if case == "multiscale":
+        dist = torch.sqrt(coords[:, 1] ** 2 + coords[:, 2] ** 2)
+        tr = MultiscaleTrainer(cfg, image, coords, dist, None, shape, dev, seed=1, rank=rank, world=world, process_group=pg)
+    elif case == "ensemble":
+        tr = RingEnsembleTrainer(cfg, image, coords, shape, dev, seed=1, rank=rank, world=world, process_group=pg)
+        tr.fit(4)
+        return [], tr.predict_all().cpu()
+    else:
+        tr = INRTrainer(cfg, image, coords, shape, dev, seed=1, rank=rank, world=world, process_group=pg)
+    losses = [s[1] for s in tr.fit(5, log_every=1)]
+    return losses, tr.engine.params.detach().cpu().clone()
+
+
+def _worker(rank, world, port, case, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        losses, params = _run(case, rank, world)
+        q.put((rank, losses, params.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["siren", "tv", "fourier", "multiscale", "ensemble"])
+def test_two_ranks_equal_one(case):
+    assert torch.cuda.is_available()
+    ref_losses, ref_params = _run(case, 0, 1)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, case, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        rank, losses, params = q.get(timeout=300)
+        got[rank] = (losses, params)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        losses, params = got[rank]
+        np.testing.assert_allclose(np.array(losses), np.array(ref_losses), rtol=2e-5, err_msg=f"{case} rank {rank}")
+        if case == "ensemble":  # assembled [N,2] prediction: identical on both ranks and equal to the 1-rank sweep
+            np.testing.assert_allclose(params, ref_params.numpy(), rtol=1e-5, atol=1e-6)
+        else:  # replicated weights after 5 steps
+            np.testing.assert_allclose(params, ref_params.numpy(), rtol=2e-4, atol=2e-6, err_msg=f"{case} rank {rank}")
+    if case != "ensemble":  # replicas stay bitwise identical: same reduced gradient, same Adam
+        np.testing.assert_array_equal(got[0][1], got[1][1])
