@@ -425,3 +425,40 @@ def test_cli_runs_the_shipped_configs(dev, module, cfg, extra, tmp_path):
     assert res["steps"] == 4 and np.isfinite(res["psnr"])
     ck = torch.load(os.path.join(str(tmp_path), "model_000004.pt"), map_location="cpu")
     assert set(ck) == {"net", "enc", "opt"}
+
+
+def test_full_baseline_size_properties(dev):
+    """BASELINE config 2 at its real size (640x368x15 = 3 532 800 coordinates, SIREN 5x256, batch 25 000), through
+    properties that need no oracle run: (i) gradient additivity -- the fused step on a batch equals the sum of the
+    fused steps on a ragged split of it (same global count); (ii) tiling invariance -- the full-grid forward sweep
+    does not depend on the chunking; (iii) run-to-run determinism; (iv) PSNR of the fit target against itself."""
+    import inr_mi355x as M
+    from inr_mi355x import _lib as L
+    from inr_mi355x.evalchain import psnr, reconstruct
+    from inr_mi355x.synthetic import make_kspace
+    from inr_mi355x.train import INRTrainer
+    image, coords, shape = make_kspace(15, 640, 368, seed=1234, normalization="coil")
+    assert coords.shape[0] == 3532800
+    cfg = dict(model="SIREN", loss="L2", lr=3e-5, batch_size=25000, max_epoch=1000, weight_decay=0.0, beta1=0.9,
+               beta2=0.999, net=FULL_NET, encoder=FULL_ENC)
+    tr = INRTrainer(cfg, image, coords, shape, dev, seed=0)
+    assert tr.steps_per_epoch == 142
+    eng, spec = tr.engine, M.LossSpec(L.LOSS_L2_HALF)
+    lo, hi, cut = 1_000_000, 1_025_000, 1_010_037
+    x, gt = tr.coords, tr.image
+    l_all = float(eng.train_step(x[lo:hi], tr.enc_B, gt[lo:hi], spec, count=25000))
+    g_all = eng.grads.clone()
+    l_a = float(eng.train_step(x[lo:cut], tr.enc_B, gt[lo:cut], spec, count=25000))
+    g_a = eng.grads.clone()
+    l_b = float(eng.train_step(x[cut:hi], tr.enc_B, gt[cut:hi], spec, count=25000))
+    g_sum = g_a + eng.grads
+    assert abs(l_a + l_b - l_all) <= 2e-6 * abs(l_all)
+    assert rel_l2(g_sum, g_all) < 2e-6
+    eng.train_step(x[lo:hi], tr.enc_B, gt[lo:hi], spec, count=25000)
+    assert torch.equal(eng.grads, g_all)  # (iii)
+    out_a = tr.predict_all(chunk=1 << 18)
+    out_b = tr.predict_all(chunk=100_003)
+    assert out_a.shape == (3532800, 2) and torch.equal(out_a, out_b)  # (ii): rows are independent of their tile
+    ref = reconstruct(tr.image, shape, False)
+    assert ref.shape == (640, 368) and float(psnr(ref, ref)) > 80  # (iv): the reference psnr carries an eps in the MSE
+    assert np.isfinite(tr.evaluate())
