@@ -183,6 +183,12 @@ int inr_backward(const inr_plan* plan, const float* params, const float* packed,
 int inr_loss_grad(const inr_loss_desc* loss, const float* out, const float* gt, const float* kcoords,
                   const uint8_t* mask, int64_t B, float* loss_out, float* dout, void* stream);
 
+/* Multi-head form for the multiscale loop (train_kspace_multiscale.py:176-195): outs / douts are [n_heads][B][2]
+ * (what inr_forward_multi writes / inr_backward_multi reads); the pointwise terms (scale * loss_fn, summed over
+ * heads) see the rows with mask != 0, ConsistencyLoss (cons_* fields, metrics/losses.py:315-324) every row. */
+int inr_loss_grad_multi(const inr_loss_desc* loss, const float* outs, const float* gt, const float* dist,
+                        const uint8_t* mask, int32_t n_heads, int64_t B, float* loss_out, float* douts, void* stream);
+
 /* Replaces tv_loss (metrics/losses.py:326-343) + its autograd on one coil's predicted k-space
  * (train.py:173-175, train_kspace_multiscale.py:173-175; per-coil batches from
  * MRICoilWrapperDataset, data/nerp_datasets.py:397-441):

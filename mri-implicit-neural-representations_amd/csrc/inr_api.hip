@@ -536,6 +536,23 @@ int inr_loss_grad(const inr_loss_desc* loss, const float* out, const float* gt, 
   return INR_OK;
 }
 
+int inr_loss_grad_multi(const inr_loss_desc* loss, const float* outs, const float* gt, const float* dist,
+                        const uint8_t* mask, int32_t n_heads, int64_t B, float* loss_out, float* douts, void* stream) {
+  if (loss == nullptr || outs == nullptr || gt == nullptr || loss_out == nullptr || douts == nullptr)
+    return fail(INR_ERR_INVALID, "inr_loss_grad_multi: null argument");
+  if (loss->kind < INR_LOSS_L2_HALF || loss->kind > INR_LOSS_HDR)
+    return fail(INR_ERR_INVALID, "inr_loss_grad_multi: loss kind %d", loss->kind);
+  if (n_heads < 1 || n_heads > INR_MAX_HEADS || B <= 0)
+    return fail(INR_ERR_INVALID, "inr_loss_grad_multi: n_heads %d, B %lld", n_heads, (long long)B);
+  if (loss->cons_w != 0.f && dist == nullptr)
+    return fail(INR_ERR_INVALID, "inr_loss_grad_multi: the consistency term needs dist");
+  LossDesc ld;
+  to_loss_desc(loss, &ld);
+  hipError_t e = inr::launch_loss_grad_multi(ld, outs, gt, dist, mask, n_heads, B, loss_out, douts, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "inr_loss_grad_multi");
+  return INR_OK;
+}
+
 int inr_tv_grad(const float* out, int64_t R, int64_t R_own, int64_t W, int64_t H, float weight,
                 float* loss_out, float* dout, void* stream) {
   if (out == nullptr || loss_out == nullptr || dout == nullptr) return fail(INR_ERR_INVALID, "inr_tv_grad: null argument");

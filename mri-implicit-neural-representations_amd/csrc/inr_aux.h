@@ -27,6 +27,9 @@ hipError_t launch_encode_gauss(const float* coords, const float* encB, long long
                                hipStream_t st);
 hipError_t launch_loss_grad(const LossDesc& ld, const float* out, const float* gt, const float* kcoords,
                             const uint8_t* mask, long long B, float* loss_out, float* dout, hipStream_t st);
+hipError_t launch_loss_grad_multi(const LossDesc& ld, const float* outs, const float* gt, const float* dist,
+                                  const uint8_t* mask, int NH, long long B, float* loss_out, float* douts,
+                                  hipStream_t st);
 hipError_t launch_tv_grad(const float* out, long long R, long long R_own, long long W, float cw, float ch,
                           float* loss_out, float* dout, hipStream_t st);
 

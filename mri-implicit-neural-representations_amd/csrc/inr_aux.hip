@@ -504,6 +504,55 @@ hipError_t launch_loss_grad(const LossDesc& ld_in, const float* out, const float
   return hipGetLastError();
 }
 
+// Multi-head version (tier 1 of the multiscale loop, train_kspace_multiscale.py:176-195): outs / douts [NH][B][2],
+// pointwise terms on sampled rows, ConsistencyLoss on every row (mfn_loss_row).
+__global__ __launch_bounds__(256) void loss_grad_multi_kernel(const LossDesc ld, const float* __restrict__ outs,
+                                                              const float* __restrict__ gt,
+                                                              const float* __restrict__ dist,
+                                                              const uint8_t* __restrict__ mask, int NH, long long B,
+                                                              float* __restrict__ loss_out, float* __restrict__ douts) {
+  __shared__ float red[256];
+  const long long per = (B + LOSS_BLOCKS - 1) / LOSS_BLOCKS;
+  const long long lo = (long long)blockIdx.x * per;
+  const long long hi = lo + per < B ? lo + per : B;
+  float acc = 0.f;
+  for (long long r = lo + threadIdx.x; r < hi; r += 256) {
+    float y[INR_MAX_HEADS][4], g[INR_MAX_HEADS][4];
+#pragma unroll
+    for (int k = 0; k < INR_MAX_HEADS; ++k)
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        y[k][o] = (k < NH && o < 2) ? outs[((size_t)k * B + r) * 2 + o] : 0.f;
+        g[k][o] = 0.f;
+      }
+    const float t[4] = {gt[2 * r], gt[2 * r + 1], 0.f, 0.f};
+    acc += mfn_loss_row(ld, NH, 2, y, t, dist != nullptr ? dist[r] : 0.f, g, mask == nullptr || mask[r] != 0);
+#pragma unroll
+    for (int k = 0; k < INR_MAX_HEADS; ++k)
+      if (k < NH) {
+        douts[((size_t)k * B + r) * 2] = g[k][0];
+        douts[((size_t)k * B + r) * 2 + 1] = g[k][1];
+      }
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s >= 1; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss_out[1 + blockIdx.x] = red[0];
+}
+
+hipError_t launch_loss_grad_multi(const LossDesc& ld_in, const float* outs, const float* gt, const float* dist,
+                                  const uint8_t* mask, int NH, long long B, float* loss_out, float* douts,
+                                  hipStream_t st) {
+  LossDesc ld = ld_in;
+  hipLaunchKernelGGL(loss_grad_multi_kernel, dim3(LOSS_BLOCKS), dim3(256), 0, st, ld, outs, gt, dist, mask, NH, B,
+                     loss_out, douts);
+  hipLaunchKernelGGL(loss_fold_kernel, dim3(1), dim3(1), 0, st, loss_out);
+  return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------
 // Total-variation regulariser on one coil's predicted k-space image (metrics/losses.py tv_loss;
 // train.py:172-175):  w * ( mean|img[:, :-1] - img[:, 1:]| + mean|img[:-1] - img[1:]| ) over

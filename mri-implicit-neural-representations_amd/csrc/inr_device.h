@@ -198,4 +198,37 @@ __device__ __forceinline__ float loss_row(const LossDesc& ld, int out_f, const f
   return loss;
 }
 
+// ---------------------------------------------------------------------------------------------
+// multiscale loss of one coordinate (train_kspace_multiscale.py:164-195): sum over heads of
+// scale * loss_fn(o_k, gt) on SAMPLED rows (:176-182: out[mask], gt[mask]) + cons_w * ConsistencyLoss
+// (losses.py:315-324) on every row.  y[k][o] in, g[k][o] out.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float mfn_loss_row(const LossDesc& ld, int n_heads, int out_f, const float (&y)[INR_MAX_HEADS][4],
+                                              const float* t, float dist, float (&g)[INR_MAX_HEADS][4], bool sampled) {
+  float loss = 0.f;
+#pragma unroll
+  for (int k = 0; k < INR_MAX_HEADS; ++k) {
+    if (k < n_heads && sampled) {
+      float gk[4] = {0.f, 0.f, 0.f, 0.f};
+      loss += ld.scale * loss_row(ld, out_f, y[k], t, gk);
+#pragma unroll
+      for (int o = 0; o < 4; ++o) g[k][o] = ld.scale * gk[o];
+    }
+  }
+  if (ld.cons_w != 0.f) {
+#pragma unroll
+    for (int i = 0; i + 1 < INR_MAX_HEADS; ++i) {
+      if (i + 1 < n_heads && ld.cons_inv[i] != 0.f && (dist < ld.cons_lo[i] || dist > ld.cons_hi[i])) {
+        for (int o = 0; o < ld.cons_chan; ++o) {
+          const float e = y[i + 1][o] - y[i][o];  // first tensor is detached: gradient to head i+1 only
+          loss += ld.cons_w * e * e * ld.cons_inv[i];
+          g[i + 1][o] += ld.cons_w * 2.f * e * ld.cons_inv[i];
+        }
+      }
+    }
+  }
+  return loss;
+}
+
+
 }  // namespace inr

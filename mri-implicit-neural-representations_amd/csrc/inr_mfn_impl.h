@@ -260,37 +260,6 @@ __device__ __forceinline__ void dwf_layer(const float* lds, int RS, const float*
 }
 
 // ---------------------------------------------------------------------------------------------
-// multiscale loss of one coordinate (train_kspace_multiscale.py:164-195): sum over heads of
-// scale * loss_fn(o_k, gt) + cons_w * ConsistencyLoss (losses.py:315-324).  y[k][o] in, g[k][o] out.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float mfn_loss_row(const LossDesc& ld, int n_heads, int out_f, const float (&y)[INR_MAX_HEADS][4],
-                                              const float* t, float dist, float (&g)[INR_MAX_HEADS][4]) {
-  float loss = 0.f;
-#pragma unroll
-  for (int k = 0; k < INR_MAX_HEADS; ++k) {
-    if (k < n_heads) {
-      float gk[4] = {0.f, 0.f, 0.f, 0.f};
-      loss += ld.scale * loss_row(ld, out_f, y[k], t, gk);
-#pragma unroll
-      for (int o = 0; o < 4; ++o) g[k][o] = ld.scale * gk[o];
-    }
-  }
-  if (ld.cons_w != 0.f) {
-#pragma unroll
-    for (int i = 0; i + 1 < INR_MAX_HEADS; ++i) {
-      if (i + 1 < n_heads && ld.cons_inv[i] != 0.f && (dist < ld.cons_lo[i] || dist > ld.cons_hi[i])) {
-        for (int o = 0; o < ld.cons_chan; ++o) {
-          const float e = y[i + 1][o] - y[i][o];  // first tensor is detached: gradient to head i+1 only
-          loss += ld.cons_w * e * e * ld.cons_inv[i];
-          g[i + 1][o] += ld.cons_w * 2.f * e * ld.cons_inv[i];
-        }
-      }
-    }
-  }
-  return loss;
-}
-
-// ---------------------------------------------------------------------------------------------
 // Wide stages in register-sized chunks: the 16 row blocks of the 512-wide shape are accumulated 8 at a
 // time (the B operand is streamed twice), so a GEMM phase holds 256 accumulator + 64 A-fragment
 // registers instead of 256 + 128 and stays inside the 512-register file without scratch.
@@ -471,10 +440,10 @@ __global__ __launch_bounds__(NW * 64) void inr_mfn_kernel(const NetDesc nd, cons
             y[k][o] = k < NH ? HG[swz(8 + 4 * k + o, col)] : 0.f;
             g[k][o] = 0.f;
           }
-        if (valid && (a.mask == nullptr || a.mask[crow] != 0)) {
+        if (valid) {
           float t[4] = {0.f, 0.f, 0.f, 0.f};
           for (int o = 0; o < nd.out_f; ++o) t[o] = a.gt[crow * nd.out_f + o];
-          loss_acc += mfn_loss_row(ld, NH, nd.out_f, y, t, dist, g);
+          loss_acc += mfn_loss_row(ld, NH, nd.out_f, y, t, dist, g, a.mask == nullptr || a.mask[crow] != 0);
         }
 #pragma unroll
         for (int k = 0; k < INR_MAX_HEADS; ++k)

@@ -55,6 +55,7 @@ SYMBOLS = {
     "inr_forward": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, _P, _P, _P]),
     "inr_backward": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, _P, _P, _P, _P, _P]),
     "inr_loss_grad": (C.c_int, [C.POINTER(LossDesc), _P, _P, _P, _P, C.c_int64, _P, _P, _P]),
+    "inr_loss_grad_multi": (C.c_int, [C.POINTER(LossDesc), _P, _P, _P, _P, C.c_int32, C.c_int64, _P, _P, _P]),
     "inr_tv_grad": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_float, _P, _P, _P]),
     "inr_train_step": (C.c_int, [_P, C.POINTER(LossDesc), _P, _P, _P, _P, _P, _P, C.c_int64, _P, _P, _P, _P, _P]),
     "inr_plan_heads": (C.c_int, [_P, C.POINTER(C.c_int32)]),

@@ -265,13 +265,9 @@ class MFNEngine(MLPEngine):
                                             _ptr(self.grads, "grads"), self._stream()))
         return self.grads
 
-    def train_step(self, coords: torch.Tensor, enc_B: torch.Tensor, gt: torch.Tensor, spec: LossSpec,
-                   count: Optional[int] = None, mask: Optional[torch.Tensor] = None, hdr_A: float = 0.0,
-                   dist: Optional[torch.Tensor] = None, scale: float = 1.0,
-                   cons: Optional[ConsistencySpec] = None):
-        B = coords.shape[0]
-        _, nb = self.launch_dims(B)
-        ld = self.loss_desc(spec, B if count is None else count, hdr_A)
+    def multi_loss_desc(self, spec: LossSpec, count: int, hdr_A: float = 0.0, scale: float = 1.0,
+                        cons: Optional[ConsistencySpec] = None) -> L.LossDesc:
+        ld = self.loss_desc(spec, count, hdr_A)
         ld.scale = scale
         if cons is not None:
             ld.cons_w = cons.weight
@@ -280,6 +276,28 @@ class MFNEngine(MLPEngine):
                 ld.cons_lo[i], ld.cons_hi[i] = float(lo), float(hi)
             for i, v in enumerate(cons.inv_counts[:4]):
                 ld.cons_inv[i] = float(v)
+        return ld
+
+    def loss_grad_multi(self, spec: LossSpec, outs: torch.Tensor, gt: torch.Tensor, count: int,
+                        mask: Optional[torch.Tensor] = None, dist: Optional[torch.Tensor] = None, scale: float = 1.0,
+                        cons: Optional[ConsistencySpec] = None):
+        """Tier-1 multiscale loss (train_kspace_multiscale.py:176-195) on outs [n_heads,B,2]: returns (loss scalar
+        view, douts [n_heads,B,2]).  Pointwise terms on rows with mask != 0, consistency on every row."""
+        NH, B = outs.shape[0], outs.shape[1]
+        douts = torch.empty_like(outs)
+        ld = self.multi_loss_desc(spec, count, 0.0, scale, cons)
+        L.check(self.lib.inr_loss_grad_multi(C.byref(ld), _ptr(outs, "outs"), _ptr(gt, "gt"), _ptr(dist, "dist"),
+                                             _ptr(mask, "mask", torch.uint8), NH, B, _ptr(self._loss, "loss"),
+                                             _ptr(douts, "douts"), self._stream()))
+        return self._loss[0], douts
+
+    def train_step(self, coords: torch.Tensor, enc_B: torch.Tensor, gt: torch.Tensor, spec: LossSpec,
+                   count: Optional[int] = None, mask: Optional[torch.Tensor] = None, hdr_A: float = 0.0,
+                   dist: Optional[torch.Tensor] = None, scale: float = 1.0,
+                   cons: Optional[ConsistencySpec] = None):
+        B = coords.shape[0]
+        _, nb = self.launch_dims(B)
+        ld = self.multi_loss_desc(spec, B if count is None else count, hdr_A, scale, cons)
         L.check(self.lib.inr_train_step_multi(self.plan, C.byref(ld), _ptr(self.params, "params"),
                                               _ptr(self.packed, "packed"), _ptr(coords, "coords"),
                                               _ptr(enc_B, "enc_B"), _ptr(gt, "gt"), _ptr(dist, "dist"),

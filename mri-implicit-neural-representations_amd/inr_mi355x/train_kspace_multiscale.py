@@ -31,7 +31,7 @@ def create_pairs(values: Sequence[float], multiplication_factor: int):
 class MultiscaleTrainer:
     def __init__(self, config: dict, image: torch.Tensor, coords: torch.Tensor, dist: torch.Tensor,
                  radii: Optional[Sequence[float]], shape, device, seed: int = 0, rank: int = 0, world: int = 1,
-                 process_group=None):
+                 process_group=None, mask: Optional[torch.Tensor] = None, mask_seed: Optional[int] = None):
         config = set_default_configs(dict(config))
         if radii is None:  # train_kspace_multiscale.py:73-84
             from .clustering import partition_and_stats
@@ -64,12 +64,27 @@ class MultiscaleTrainer:
         self.engine = self.model._engine()
         self.enc_B = self.encoder.B.contiguous()
         self.pairs = create_pairs(list(radii), 1)
+        # undersampling / per-coil batches / TV as in the single-scale loop (models/utils.py:102-123;
+        # train_kspace_multiscale.py:173-182)
+        self.image_full = image.to(self.device).contiguous()
+        from .undersampling import Undersampler, parse_undersampling_argument
+        method, uparams = parse_undersampling_argument(config["undersampling"])
+        if mask is None and method is not None and method.lower() != "none":
+            C, H, W = int(shape[0]), int(shape[1]), int(shape[2])
+            masked, _, gm = Undersampler(method, seed=mask_seed).apply(image.reshape(C, H, W, 2).cpu(), uparams)
+            image, mask = masked.reshape(-1, 2), gm[:, 0].contiguous()
+        self.mask_cpu = mask
+        self.mask = mask.to(torch.uint8).to(self.device).contiguous() if mask is not None else None
+        self.per_coil = bool(config["per_coil"])
+        self.use_tv = bool(config["use_tv"])  # here TV does not depend on a mask (train_kspace_multiscale.py:173)
+        if self.use_tv and not self.per_coil:
+            raise ValueError("use_tv needs per_coil batches: tv_loss views the batch as one [H,W,2] coil")
         self.n = coords.shape[0]
         self.coords = coords.to(self.device).contiguous()
         self.image = image.to(self.device).contiguous()
         self.dist_cpu = dist.reshape(-1).contiguous()
         self.dist = self.dist_cpu.to(self.device)
-        self.bs = int(config["batch_size"])
+        self.bs = int(shape[1] * shape[2]) if self.per_coil else int(config["batch_size"])
         self.steps_per_epoch = math.ceil(self.n / self.bs)
         self.global_step = 0
         self._cons = {}
@@ -86,12 +101,42 @@ class MultiscaleTrainer:
             self._cons[it] = ConsistencySpec(0.1, self.pairs, inv + [0.0], 2)
         return self._cons[it]
 
+    def _tv_step(self, it: int, lo: int, hi: int, count: int) -> torch.Tensor:
+        """Per-coil step with TV on the last head (train_kspace_multiscale.py:164-195 with use_tv): forward (stashing)
+        -> multi-head loss gradient -> TV gradient added to the last head's -> backward.  Data parallel by image rows
+        with a one-row halo, as INRTrainer._tv_step: the halo row only serves the vertical TV pair -- it is masked out
+        of the pointwise terms and moved to dist = 0 (inside every disc) for the consistency term."""
+        H, W = int(self.shape[1]), int(self.shape[2])
+        y0, y1 = shard_rows(0, H, self.rank, self.world)
+        if y1 == y0:
+            self.engine.grads.zero_()
+            return torch.zeros((), device=self.device)
+        ye = min(y1 + 1, H)
+        slo, sown, shi = lo + y0 * W, lo + y1 * W, lo + ye * W
+        x, d = self.coords[slo:shi], self.dist[slo:shi]
+        outs = self.engine.forward(x, self.enc_B, save=True, dist=d)
+        m = torch.ones(shi - slo, dtype=torch.uint8, device=self.device) if self.mask is None else self.mask[slo:shi].clone()
+        d_loss = d
+        if shi > sown:
+            m[sown - slo:] = 0
+            d_loss = d.clone()
+            d_loss[sown - slo:] = 0
+        _, douts = self.engine.loss_grad_multi(self.loss, outs, self.image[slo:shi], count, mask=m, dist=d_loss,
+                                               scale=self.scale, cons=self._cons_spec(it, lo, hi))
+        loss = self.engine.tv_grad(outs[-1], douts[-1], y1 - y0, W, H)  # adds to the loss word and to douts[-1]
+        self.engine.backward(x, self.enc_B, douts, dist=d)
+        return loss
+
     def step(self, epoch: int, it: int) -> torch.Tensor:
         lo, hi = it * self.bs, min((it + 1) * self.bs, self.n)
-        slo, shi = shard_rows(lo, hi, self.rank, self.world)
-        loss = self.engine.train_step(self.coords[slo:shi], self.enc_B, self.image[slo:shi], self.loss,
-                                      count=hi - lo, dist=self.dist[slo:shi], scale=self.scale,
-                                      cons=self._cons_spec(it, lo, hi))
+        count = hi - lo if self.mask_cpu is None else int(self.mask_cpu[lo:hi].sum())
+        if self.use_tv:
+            loss = self._tv_step(it, lo, hi, count)
+        else:
+            slo, shi = shard_rows(lo, hi, self.rank, self.world)
+            loss = self.engine.train_step(self.coords[slo:shi], self.enc_B, self.image[slo:shi], self.loss,
+                                          count=count, mask=None if self.mask is None else self.mask[slo:shi],
+                                          dist=self.dist[slo:shi], scale=self.scale, cons=self._cons_spec(it, lo, hi))
         loss = allreduce_step_outputs(self.engine.grads, loss, self.world, self.pg, self.engine.gbuf)
         lr = self.config["lr"] * lr_factor(epoch, self.config["max_epoch"])
         self.engine.adam_step(lr, self.config["beta1"], self.config["beta2"], 1e-8, self.config["weight_decay"])
@@ -135,7 +180,7 @@ class MultiscaleTrainer:
 
     @torch.no_grad()
     def evaluate(self) -> float:
-        ref = reconstruct(self.image, self.shape, False)
+        ref = reconstruct(self.image_full, self.shape, False)
         return float(psnr(ref, reconstruct(self.predict_all(), self.shape, False)))
 
 

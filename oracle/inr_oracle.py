@@ -737,9 +737,11 @@ def create_pairs(radii, n: int = 1):
 
 
 def train_multiscale(config: dict, sd, enc_B, coords: Tensor, image: Tensor, dist: Tensor, radii,
-                     max_steps: int, record=None):
-    """The loop of train_kspace_multiscale.py:164-195 (no undersampling, no TV) for
-    model in {MultiscaleKFourier, BoundedFourier}; loss in {L2, L1, LSL->LogSpaceLoss}."""
+                     max_steps: int, record=None, mask: Optional[Tensor] = None, grid_hw=None):
+    """The loop of train_kspace_multiscale.py:164-195 for model in {MultiscaleKFourier, BoundedFourier}; loss in
+    {L2, L1, LSL->LogSpaceLoss}.  ``mask`` [N] bool: undersampling (:176-182: the pointwise terms see the sampled
+    rows, ConsistencyLoss and TV all rows); ``config['per_coil']`` with ``grid_hw``: one coil per step, plus
+    tv_loss on the last head when ``config['use_tv']`` (:173-175)."""
     model = config["model"]
     model = {"Fourier": "MultiscaleKFourier"}.get(model, model)
     net = config["net"]
@@ -765,7 +767,14 @@ def train_multiscale(config: dict, sd, enc_B, coords: Tensor, image: Tensor, dis
             x = encode(kc, enc_B, config["encoder"]["embedding"])
             outs = model_forward(model, sd, x, net, dist_to_center=d, boundaries=pairs_model)
             loss = 0.1 * loss_consistency(outs, d, pairs)
+            if config.get("use_tv", False):
+                loss = loss + loss_tv(outs[-1].view(grid_hw[0], grid_hw[1], 2))
+            if mask is not None:
+                m = mask[lo:hi]
+                gt = gt[m]
             for out in outs:  # limit_kspace is a no-op: every head sees the full gt
+                if mask is not None:
+                    out = out[m]
                 if kind == "L2":
                     loss = loss + loss_l2_half(out, gt)
                 elif kind == "L1":

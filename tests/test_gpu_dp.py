@@ -27,6 +27,9 @@ def _cases():
         "multiscale": dict(BASE, model="MultiscaleKFourier", loss="LSL", loss_opts=dict(eps=3e-3), batch_size=400,
                            partition=dict(no_steps=20, no_models=4),
                            net=dict(NET, network_depth=8)),
+        "multiscale_tv": dict(BASE, model="MultiscaleKFourier", loss="LSL", loss_opts=dict(eps=3e-3), batch_size=1,
+                              per_coil=True, use_tv=True, undersampling="grid-2*2",
+                              partition=dict(no_steps=20, no_models=4), net=dict(NET, network_depth=8)),
         "ensemble": dict(BASE, model="SIREN", batch_size=SHAPE[1] * SHAPE[2], partition=dict(no_steps=20, no_models=3)),
     }
 
@@ -39,7 +42,7 @@ def _run(case, rank, world, pg=None):
     cfg = _cases()[case]
     image, coords, shape = make_kspace(*SHAPE)
     dev = torch.device("cuda:0")
-    if case == "multiscale":
+    if case in ("multiscale", "multiscale_tv"):
         dist = torch.sqrt(coords[:, 1] ** 2 + coords[:, 2] ** 2)
         tr = MultiscaleTrainer(cfg, image, coords, dist, None, shape, dev, seed=1, rank=rank, world=world, process_group=pg)
     elif case == "ensemble":
@@ -64,7 +67,7 @@ def _worker(rank, world, port, case, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case", ["siren", "tv", "fourier", "multiscale", "ensemble"])
+@pytest.mark.parametrize("case", ["siren", "tv", "fourier", "multiscale", "multiscale_tv", "ensemble"])
 def test_two_ranks_equal_one(case):
     assert torch.cuda.is_available()
     ref_losses, ref_params = _run(case, 0, 1)

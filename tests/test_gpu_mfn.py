@@ -236,3 +236,29 @@ def test_multiscale_trainer_computes_its_radii(dev):
     assert tr.mx.shape == (5,) and float(tr.mx[-1]) == 1.0
     losses = [s[1] for s in tr.fit(6, log_every=1)]
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+
+
+def test_multiscale_percoil_mask_tv_golden(dev):
+    """Per-coil batches + grid undersampling + TV on the last head in the multiscale loop
+    (train_kspace_multiscale.py:164-195 with use_tv and a mask): reference-driven trajectory; the trainer builds the
+    mask and the zero-filled k-space from the config string and runs the unfused forward / multi-head loss / TV /
+    backward step."""
+    from inr_mi355x.train_kspace_multiscale import MultiscaleTrainer
+    arrs = _load("trajectory_ms.npz")
+    meta = json.load(open(os.path.join(GOLD, "trajectory_ms_meta.json")))
+    cfg = meta["cases"]["MS_percoil_tv"]
+    C, H, W = meta["shape"]
+    coords, image, dist = _t(arrs["coords"]), _t(arrs["image"]), _t(arrs["dist"])
+    tr = MultiscaleTrainer(cfg, image, coords, dist, meta["radii"], (C, H, W), dev, seed=meta["seed"])
+    assert tr.use_tv and tr.bs == H * W and torch.equal(tr.mask_cpu, _t(arrs["mask"]))
+    got = np.array([s[1] for s in tr.fit(log_every=1)])
+    np.testing.assert_allclose(got, arrs["MS_percoil_tv/losses"], rtol=5e-5)
+    torch.testing.assert_close(tr.predict_all().cpu(), _t(arrs["MS_percoil_tv/final_out"]), rtol=1e-3, atol=5e-5)
+    # masked but fused (no TV): the fused kernel's mask gates the pointwise terms only, like the tier-1 loss kernel
+    cfg2 = dict(cfg, use_tv=False)
+    a = MultiscaleTrainer(cfg2, image, coords, dist, meta["radii"], (C, H, W), dev, seed=meta["seed"])
+    sd = {k: v.detach().cpu().clone() for k, v in a.model.state_dict().items()}
+    want = O.train_multiscale(cfg2, sd, a.encoder.B.cpu(), coords, image * _t(arrs["mask"])[:, None], dist, meta["radii"],
+                              4, mask=_t(arrs["mask"]), grid_hw=(H, W))
+    got2 = np.array([s[1] for s in a.fit(4, log_every=1)])
+    np.testing.assert_allclose(got2, np.array(want), rtol=5e-5)

@@ -247,11 +247,18 @@ def test_multiscale_trajectories_golden(golden_dir):
     arrs = _load(golden_dir, "trajectory_ms.npz")
     meta = json.load(open(os.path.join(golden_dir, "trajectory_ms_meta.json")))
     coords, image, dist = _t(arrs["coords"]), _t(arrs["image"]), _t(arrs["dist"])
+    C, H, W = meta["shape"]
     for tag, cfg in meta["cases"].items():
         torch.manual_seed(meta["seed"])
         B = O.encoder_init(cfg["encoder"])
         sd = O.init_model(cfg["model"], cfg["net"])
-        losses = O.train_multiscale(cfg, sd, B, coords, image, dist, meta["radii"], meta["steps"])
+        if tag == "MS_percoil_tv":  # per-coil batches + grid mask + TV on the last head
+            mask = _t(arrs["mask"])
+            losses = O.train_multiscale(cfg, sd, B, coords, image * mask[:, None], dist, meta["radii"], 10 ** 6,
+                                        mask=mask, grid_hw=(H, W))
+            assert len(losses) == cfg["max_epoch"] * C
+        else:
+            losses = O.train_multiscale(cfg, sd, B, coords, image, dist, meta["radii"], meta["steps"])
         np.testing.assert_allclose(np.array(losses), arrs[tag + "/losses"], rtol=2e-4, err_msg=tag)
         pairs_model = O.create_pairs(meta["radii"], 2)
         with torch.no_grad():

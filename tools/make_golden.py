@@ -406,6 +406,46 @@ def multiscale_trajectory():
         arrs[tag + "/losses"] = np.array(losses, dtype=np.float64)
         with torch.no_grad():
             arrs[tag + "/final_out"] = npy(model(coords=encoder.embedding(coords), dist_to_center=dist)[-1])
+    # per-coil batches + grid undersampling + TV on the last head (train_kspace_multiscale.py:164-195 with
+    # use_tv and len(mask_coords) != 0): TV sees train_output[-1] of ALL rows, the consistency term all rows,
+    # the pointwise terms the sampled rows
+    mask2d = torch.zeros(H, W, dtype=torch.bool)
+    mask2d[::2, ::3] = True
+    mask = mask2d.reshape(1, -1).expand(C, -1).reshape(-1)
+    masked_image = image * mask[:, None]
+    arrs["mask"] = mask.numpy()
+    cfg = dict(model="MultiscaleKFourier", loss="LSL", lr=3e-4, batch_size=1, max_epoch=4, weight_decay=0.0, beta1=0.9,
+               beta2=0.999, per_coil=True, use_tv=True, undersampling="grid-2*3",
+               loss_opts=dict(hdr_eps=3e-3, hdr_ff_sigma=2, hdr_ff_factor=0.5),
+               net=dict(network_input_size=16, network_output_size=2, network_depth=8, network_width=32),
+               encoder=dict(embedding="gauss", scale=2, embedding_size=8, coordinates_size=3))
+    cases["MS_percoil_tv"] = cfg
+    torch.manual_seed(4)
+    encoder = Positional_Encoder(cfg["encoder"], device="cpu")
+    model = quiet(MultiscaleKFourier, cfg["net"])
+    optim = torch.optim.Adam(model.parameters(), lr=cfg["lr"], betas=(0.9, 0.999), weight_decay=0.0)
+    loss_fn = LogSpaceLoss(cfg["loss_opts"])
+    loss_cons = ConsistencyLoss(pairs)
+    sched = LambdaLR(optim, lambda x: 0.2 ** min(x / cfg["max_epoch"], 1))
+    losses = []
+    for epoch in range(cfg["max_epoch"]):
+        for c in range(C):
+            sl = slice(c * H * W, (c + 1) * H * W)
+            kc, gt, d, m = coords[sl], masked_image[sl], dist[sl], mask[sl]
+            outs = model(coords=encoder.embedding(kc), dist_to_center=d)
+            optim.zero_grad()
+            loss = tv_loss(outs[-1].view((H, W, 2)))
+            gt_m = gt[m]
+            loss = loss + 0.1 * loss_cons(outs, d)
+            for o in outs:
+                loss = loss + 0.5 * loss_fn(o[m], gt_m)
+            loss.backward()
+            optim.step()
+            losses.append(float(loss.detach()))
+        sched.step()
+    arrs["MS_percoil_tv/losses"] = np.array(losses, dtype=np.float64)
+    with torch.no_grad():
+        arrs["MS_percoil_tv/final_out"] = npy(model(coords=encoder.embedding(coords), dist_to_center=dist)[-1])
     np.savez_compressed(os.path.join(OUT, "trajectory_ms.npz"), **arrs)
     with open(os.path.join(OUT, "trajectory_ms_meta.json"), "w") as f:
         json.dump({"shape": [C, H, W], "cases": cases, "seed": 4, "steps": 8, "radii": radii}, f, indent=1, sort_keys=True)
