@@ -54,6 +54,19 @@ __device__ __forceinline__ void sincos_rev(float r, float& s, float& c) {
   c = __builtin_amdgcn_cosf(f);
 }
 
+// The z stash is fp16 (10 mantissa bits: the recomputed phase w0*z is off by <= 30|z| 2^-11 ~ 0.015|z| rad, the
+// size of the bf16 operand rounding already present; bf16 would triple that) -- half the bytes of the stream that,
+// with the slabs, paces this kernel.
+typedef _Float16 zst_t;
+typedef _Float16 zst4 __attribute__((ext_vector_type(4)));
+
+template <int NB, int TL>
+__device__ __forceinline__ void image_to_zstash(const float* R, zst_t* __restrict__ G, int wcol, int lane) {
+  const int half = lane >> 5, col = lane & 31;
+#pragma unroll 8
+  for (int r = half; r < NB * 32; r += 2) G[r * TL + wcol] = (zst_t)R[swz(r, col)];
+}
+
 __device__ __forceinline__ float sin_rev(float r) { return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(r)); }
 __device__ __forceinline__ float cos_rev(float r) { return __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(r)); }
 
@@ -177,11 +190,11 @@ __device__ __forceinline__ void fwd_layer_bf16(f32x16 (&acc)[NBOUT], const float
 // HASD: sv_z = stashed z_l; act'(z) = w0 cos(w0 z) is recomputed here
 template <int NB, int TL, bool HASD>
 __device__ __forceinline__ void bwd_dx_bf16(f32x16 (&acc)[NB], float* R, const float* __restrict__ wpT, int n8,
-                                            const float* __restrict__ sv_z, float w0, int wcol, int lane) {
+                                            const zst_t* __restrict__ sv_z, float w0, int wcol, int lane) {
   const int half = lane >> 5, col = lane & 31;
   const bf16x8* p = reinterpret_cast<const bf16x8*>(wpT) + lane;
   float* Rl = R + half * INR_LDS_LD + col;
-  const float* dl = HASD ? sv_z + half * TL + wcol : nullptr;
+  const zst_t* dl = HASD ? sv_z + half * TL + wcol : nullptr;
   const float krev = w0 * 0.15915494309189535f;
   bf16x8 A0[NB], A1[NB];
   float G0[8], D0[8], G1[8], D1[8];
@@ -189,7 +202,7 @@ __device__ __forceinline__ void bwd_dx_bf16(f32x16 (&acc)[NB], float* R, const f
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
     G0[t] = Rl[(2 * t) * INR_LDS_LD];
-    D0[t] = HASD ? dl[(2 * t) * TL] : 1.f;
+    D0[t] = HASD ? (float)dl[(2 * t) * TL] : 1.f;
   }
 #pragma unroll 1
   for (int s8 = 0; s8 < n8; s8 += 2) {
@@ -198,7 +211,7 @@ __device__ __forceinline__ void bwd_dx_bf16(f32x16 (&acc)[NB], float* R, const f
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       G1[t] = Rl[(16 * s1 + 2 * t) * INR_LDS_LD];
-      D1[t] = HASD ? dl[(16 * s1 + 2 * t) * TL] : 1.f;
+      D1[t] = HASD ? (float)dl[(16 * s1 + 2 * t) * TL] : 1.f;
     }
     __builtin_amdgcn_sched_barrier(0);
     {
@@ -218,7 +231,7 @@ __device__ __forceinline__ void bwd_dx_bf16(f32x16 (&acc)[NB], float* R, const f
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
         G0[t] = Rl[(16 * s2 + 2 * t) * INR_LDS_LD];
-        D0[t] = HASD ? dl[(16 * s2 + 2 * t) * TL] : 1.f;
+        D0[t] = HASD ? (float)dl[(16 * s2 + 2 * t) * TL] : 1.f;
       }
       __builtin_amdgcn_sched_barrier(0);
       float g[8];
@@ -237,20 +250,20 @@ __device__ __forceinline__ void bwd_dx_bf16(f32x16 (&acc)[NB], float* R, const f
 
 // dZ_0 = dH_0 * w0 cos(w0 z_0) -> image (the first layer has no dX); z_0 from the stash, all loads in flight
 template <int NB, int TL>
-__device__ __forceinline__ void acc_times_cos_to_lds(const f32x16 (&acc)[NB], float* R, const float* __restrict__ sv_z,
+__device__ __forceinline__ void acc_times_cos_to_lds(const f32x16 (&acc)[NB], float* R, const zst_t* __restrict__ sv_z,
                                                      float w0, int wcol, int lane) {
   const int half = lane >> 5, col = lane & 31;
   float* Rl = R + (4 * half) * INR_LDS_LD + col;
-  const __amdgpu_buffer_rsrc_t rs = uniform_rsrc(sv_z, NB * 32 * TL * 4);  // SGPR descriptor + one lane offset
-  const int voff = ((4 * half) * TL + wcol) * 4;
+  const __amdgpu_buffer_rsrc_t rs = uniform_rsrc(sv_z, NB * 32 * TL * 2);  // SGPR descriptor + one lane offset
+  const int voff = ((4 * half) * TL + wcol) * 2;
   const float krev = w0 * 0.15915494309189535f;
 #pragma unroll
   for (int m = 0; m < NB; ++m) {
     float z[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int soff = (32 * m + (r & 3) + 8 * (r >> 2)) * TL * 4;
-      z[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+      const int soff = (32 * m + (r & 3) + 8 * (r >> 2)) * TL * 2;
+      z[r] = (float)__builtin_bit_cast(zst_t, __builtin_amdgcn_raw_buffer_load_b16(rs, voff, soff, 0));
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -263,19 +276,19 @@ __device__ __forceinline__ void acc_times_cos_to_lds(const f32x16 (&acc)[NB], fl
 // dW B operands.  h_{l-1} = sin(w0 z_{l-1}) from the z stash ("feature on lane", 4 coordinates per fetch) ...
 template <int TL>
 struct BSrcStashSin {
-  const float* __restrict__ z;
+  const zst_t* __restrict__ z;
   float krev;
   struct Raw {
-    f32x4 v;
+    zst4 v;
   };
   __device__ __forceinline__ Raw fetch(int n, int q, int lane) const {
     const int j = 32 * n + (lane & 31);
-    return Raw{*reinterpret_cast<const f32x4*>(z + j * TL + 8 * q + 4 * (lane >> 5))};
+    return Raw{*reinterpret_cast<const zst4*>(z + j * TL + 8 * q + 4 * (lane >> 5))};
   }
   __device__ __forceinline__ f32x4 finish(const Raw& r) const {
     f32x4 o;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = sin_rev(r.v[e] * krev);
+    for (int e = 0; e < 4; ++e) o[e] = sin_rev((float)r.v[e] * krev);
     return o;
   }
 };
@@ -421,7 +434,8 @@ __global__ __launch_bounds__(NW * 64) void inr_mlp_bf16_kernel(const NetDesc nd,
     const long long crow = row0 + wcol;
     const bool valid = crow < a.B;
     float* sv = a.save + (size_t)(a.save_by_block ? blockIdx.x : tile) * nd.save_floats_per_tile;
-    float* sv_last = sv + (size_t)NS * (D - 1) * HSZ;
+    float* sv_last = sv + (size_t)NS * (D - 1) * HSZ;  // (the fp16 z tensors use half of their slots)
+    zst_t* svz = reinterpret_cast<zst_t*>(sv);           // z_l at svz + l * HSZ
     float x0 = 0.f, x1 = 0.f, x2 = 0.f;
     if (valid) {
       x0 = a.x[3 * crow + 0];
@@ -443,7 +457,7 @@ __global__ __launch_bounds__(NW * 64) void inr_mlp_bf16_kernel(const NetDesc nd,
       for (int m = 0; m < NB; ++m) acc[m] = zero16();
       fwd_layer0_gauss_bf16<NB, TL>(acc, a.packed + nd.L[0].pf_off, encB_lds, nd.E, x0, x1, x2, lane);
       acc_to_lds<NB, true>(acc, R, a.packed + nd.L[0].pbias_off, lane);
-      image_copy<NB, TL, true>(R, sv, wcol, lane);  // z_0
+      image_to_zstash<NB, TL>(R, svz, wcol, lane);  // z_0
     }
     INR_STAMP(1);
     for (int l = 1; l < D - 1; ++l) {
@@ -453,7 +467,7 @@ __global__ __launch_bounds__(NW * 64) void inr_mlp_bf16_kernel(const NetDesc nd,
       for (int m = 0; m < NB; ++m) acc[m] = zero16();
       fwd_layer_bf16<NB, NB, TL>(acc, R, a.packed + Ll.pf_off, nd.L[l - 1].omega, lane);
       acc_to_lds<NB, true>(acc, R, a.packed + Ll.pbias_off, lane);
-      image_copy<NB, TL, true>(R, sv + (size_t)l * HSZ, wcol, lane);  // z_l
+      image_to_zstash<NB, TL>(R, svz + (size_t)l * HSZ, wcol, lane);  // z_l
       INR_STAMP(1 + l);
     }
     f32x16 accL[1];
@@ -501,7 +515,7 @@ __global__ __launch_bounds__(NW * 64) void inr_mlp_bf16_kernel(const NetDesc nd,
     __syncthreads();
     INR_STAMP(11);
     {
-      BSrcStashSin<TL> bs{sv + (size_t)(D - 2) * HSZ, nd.L[D - 2].omega * 0.15915494309189535f};
+      BSrcStashSin<TL> bs{svz + (size_t)(D - 2) * HSZ, nd.L[D - 2].omega * 0.15915494309189535f};
       for (int n = w; n < LL.Kblk; n += NW)
         dw_pass_bf16<1, TL, false, BSrcStashSin<TL>>(lds, RS, bs, n, slab + LL.gw_off, slab + LL.gb_off, LL.M, LL.K, first,
                                                   n == 0, lane);
@@ -513,7 +527,7 @@ __global__ __launch_bounds__(NW * 64) void inr_mlp_bf16_kernel(const NetDesc nd,
     bwd_dx_bf16<NB, TL, false>(gacc, R, a.packed + LL.pb_off, 1, nullptr, 0.f, wcol, lane);  // rows 0..15 (4 used)
     __syncthreads();
     if (D == 2)
-      acc_times_cos_to_lds<NB, TL>(gacc, R, sv, nd.L[0].omega, wcol, lane);
+      acc_times_cos_to_lds<NB, TL>(gacc, R, svz, nd.L[0].omega, wcol, lane);
     else
       acc_to_lds<NB, false>(gacc, R, nullptr, lane);
     INR_STAMP(13);
@@ -521,12 +535,12 @@ __global__ __launch_bounds__(NW * 64) void inr_mlp_bf16_kernel(const NetDesc nd,
       const LayerDesc& Ll = nd.L[l];
 #pragma unroll
       for (int m = 0; m < NB; ++m) gacc[m] = zero16();
-      bwd_dx_bf16<NB, TL, true>(gacc, R, a.packed + Ll.pb_off, NB * 2, sv + (size_t)l * HSZ, Ll.omega, wcol, lane);
+      bwd_dx_bf16<NB, TL, true>(gacc, R, a.packed + Ll.pb_off, NB * 2, svz + (size_t)l * HSZ, Ll.omega, wcol, lane);
       INR_STAMP(14 + 4 * l);
       __syncthreads();
       INR_STAMP(15 + 4 * l);
       {
-        BSrcStashSin<TL> bs{sv + (size_t)(l - 1) * HSZ, nd.L[l - 1].omega * 0.15915494309189535f};
+        BSrcStashSin<TL> bs{svz + (size_t)(l - 1) * HSZ, nd.L[l - 1].omega * 0.15915494309189535f};
         for (int n = w; n < Ll.Kblk; n += NW)
           dw_pass_bf16<NB, TL, true, BSrcStashSin<TL>>(lds, RS, bs, n, slab + Ll.gw_off, slab + Ll.gb_off, Ll.M, Ll.K, first,
                                                     n == 0, lane);
@@ -534,7 +548,7 @@ __global__ __launch_bounds__(NW * 64) void inr_mlp_bf16_kernel(const NetDesc nd,
       INR_STAMP(16 + 4 * l);
       __syncthreads();
       if (l == 1)
-        acc_times_cos_to_lds<NB, TL>(gacc, R, sv, nd.L[0].omega, wcol, lane);
+        acc_times_cos_to_lds<NB, TL>(gacc, R, svz, nd.L[0].omega, wcol, lane);
       else
         acc_to_lds<NB, false>(gacc, R, nullptr, lane);
       INR_STAMP(17 + 4 * l);
