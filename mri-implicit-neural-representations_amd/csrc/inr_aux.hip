@@ -186,42 +186,42 @@ __global__ __launch_bounds__(64) void gabor_m2_kernel(const NetDesc nd, const fl
 }
 
 // bf16 plans: slab entries are bf16 at the fp32 layout's element offsets (inr_mlp_bf16_impl.h); sums in fp32,
-// 8 entries (16 bytes) per lane per slab, fixed tree as above.
+// 4 entries (8 bytes) per lane per slab and 8 slabs in flight, fixed tree as above (the kernel is latency-bound:
+// it needs as many workgroups and outstanding loads as the fp32 one to reach the same bytes per second).
 __global__ __launch_bounds__(256) void reduce_slabs_bf16_kernel(const float* __restrict__ slabs, int n_blocks,
                                                                 int slab_floats, int P, int loss_off,
                                                                 float* __restrict__ grads,
                                                                 float* __restrict__ loss_out) {
-  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-  __shared__ float part[4][64][8];
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  __shared__ f32x4 part[4][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int i8 = (blockIdx.x * 64 + lane) * 8;
+  const int i4 = (blockIdx.x * 64 + lane) * 4;
   const int per = (n_blocks + 3) / 4;
   const int b0 = w * per, b1 = (b0 + per < n_blocks) ? b0 + per : n_blocks;
-  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (i8 < P) {
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (i4 < P) {
     int b = b0;
-    for (; b + 4 <= b1; b += 4) {
-      bf16x8 v[4];
+    for (; b + 8 <= b1; b += 8) {
+      bf16x4 v[8];
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-        v[u] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(slabs + (size_t)(b + u) * slab_floats) + i8);
+      for (int u = 0; u < 8; ++u)
+        v[u] = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(slabs + (size_t)(b + u) * slab_floats) + i4);
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < 8; ++u)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s[j] += (float)v[u][j];
+        for (int j = 0; j < 4; ++j) s[j] += (float)v[u][j];
     }
     for (; b < b1; ++b) {
-      const bf16x8 v = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(slabs + (size_t)b * slab_floats) + i8);
+      const bf16x4 v = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(slabs + (size_t)b * slab_floats) + i4);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) s[j] += (float)v[j];
+      for (int j = 0; j < 4; ++j) s[j] += (float)v[j];
     }
   }
-#pragma unroll
-  for (int j = 0; j < 8; ++j) part[w][lane][j] = s[j];
+  part[w][lane] = s;
   __syncthreads();
-  if (w == 0 && i8 < P) {
-    for (int j = 0; j < 8 && i8 + j < P; ++j)
-      grads[i8 + j] = ((part[0][lane][j] + part[1][lane][j]) + part[2][lane][j]) + part[3][lane][j];
+  if (w == 0 && i4 < P) {
+    const f32x4 t = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+    for (int j = 0; j < 4 && i4 + j < P; ++j) grads[i4 + j] = t[j];
   }
   if (loss_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
     float lsum = 0.f;
@@ -260,7 +260,7 @@ hipError_t launch_reduce_slabs(const NetDesc& nd, const float* slabs, int n_bloc
     bool same = true;  // slab element offsets == flat offsets (hidden width = whole row blocks, e.g. 256)
     for (int l = 0; l < nd.ND; ++l) same = same && nd.L[l].gw_off == nd.L[l].w_off && nd.L[l].gb_off == nd.L[l].b_off;
     if (same) {
-      const int grid = (nd.P + 511) / 512;
+      const int grid = (nd.P + 255) / 256;
       hipLaunchKernelGGL(reduce_slabs_bf16_kernel, dim3(grid), dim3(256), 0, st, slabs, n_blocks, nd.slab_floats, nd.P,
                          nd.slab_loss_off, grads, loss_out);
     } else {
