@@ -413,13 +413,14 @@ __device__ __forceinline__ void fwd_layer(f32x16 (&acc)[NBOUT], const float* R, 
 // the second Linear of a layer; its epilogue leaves the orth pre-activations and u^2+v^2 of each pair in the
 // stash slots the next layer's lazy activation reads.
 // ---------------------------------------------------------------------------------------------
-template <int NB, int TL>
+// NBK: row blocks of h (the k extent); NBT: row blocks of the whole packed image (stride between k-groups)
+template <int NB, int TL, int NBK = NB, int NBT = NB>
 __device__ __forceinline__ void gemm_stash_nat(f32x16 (&acc)[NB], const float* __restrict__ wp,
                                                const float* __restrict__ sv_h, int wcol, int lane) {
   const int half = lane >> 5;
   const float* svl = sv_h + half * TL + wcol;
   const f32x4* p = reinterpret_cast<const f32x4*>(wp) + lane;
-  constexpr int n4 = NB * 4;
+  constexpr int n4 = NBK * 4;
   f32x4 A0[NB], A1[NB];
   float B0[4], B1[4];
   load_afrag<NB>(A0, p);
@@ -428,7 +429,7 @@ __device__ __forceinline__ void gemm_stash_nat(f32x16 (&acc)[NB], const float* _
 #pragma unroll 1
   for (int s4 = 0; s4 < n4; s4 += 2) {
     const int n2 = (s4 + 2 < n4) ? (s4 + 2) : s4;
-    load_afrag<NB>(A1, p + (size_t)(s4 + 1) * NB * 64);
+    load_afrag<NB>(A1, p + (size_t)(s4 + 1) * NBT * 64);
 #pragma unroll
     for (int e = 0; e < 4; ++e) B1[e] = svl[(8 * (s4 + 1) + 2 * e) * TL];
     __builtin_amdgcn_sched_barrier(0);
@@ -437,7 +438,7 @@ __device__ __forceinline__ void gemm_stash_nat(f32x16 (&acc)[NB], const float* _
 #pragma unroll
       for (int m = 0; m < NB; ++m) acc[m] = mfma32(A0[m][e], B0[e], acc[m]);
     __builtin_amdgcn_sched_barrier(0);
-    load_afrag<NB>(A0, p + (size_t)n2 * NB * 64);
+    load_afrag<NB>(A0, p + (size_t)n2 * NBT * 64);
 #pragma unroll
     for (int e = 0; e < 4; ++e) B0[e] = svl[(8 * n2 + 2 * e) * TL];
     __builtin_amdgcn_sched_barrier(0);
@@ -450,11 +451,11 @@ __device__ __forceinline__ void gemm_stash_nat(f32x16 (&acc)[NB], const float* _
 }
 
 // registers (2p, 2p+1) of a lane are the (u, v) rows of one complex feature
-template <int NB, int TL>
+template <int NB, int TL, int NBT = NB>
 __device__ __forceinline__ void orth_epilogue(const f32x16 (&acc)[NB], const float* __restrict__ bias,
                                               float* __restrict__ svO, int wcol, int lane) {
   const int half = lane >> 5;
-  constexpr int hsz = NB * 32 * TL;
+  constexpr int hsz = NBT * 32 * TL;
   float* so = svO + (4 * half) * TL + wcol;
   const float* bl = bias + 4 * half;
 #pragma unroll

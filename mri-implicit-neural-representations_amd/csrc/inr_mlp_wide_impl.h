@@ -32,11 +32,25 @@ __device__ __forceinline__ void rows_times(float* R, const float* __restrict__ d
   }
 }
 
+// own rows of the image <-> global scratch [rows][TL] (WIRE2D: a layer's output gradient is needed twice)
+template <int TL, int RH, bool TO_GLOBAL>
+__device__ __forceinline__ void rows_copy(float* R, float* __restrict__ G, int r0, int wcol, int lane) {
+  const int half = lane >> 5, col = lane & 31;
+#pragma unroll 8
+  for (int r = r0 + half; r < r0 + RH; r += 2) {
+    if (TO_GLOBAL)
+      G[r * TL + wcol] = R[swz(r, col)];
+    else
+      R[swz(r, col)] = G[r * TL + wcol];
+  }
+}
+
 template <int NB, int INMODE, int HACT, int MODE>
 __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, const LossDesc ld, const MlpArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr bool PAIR = HACT == ACT_GABOR;
-  constexpr int MT = NB / 2, NG = 2, NW = 4, NS = PAIR ? 3 : 2;
+  constexpr bool G2D = HACT == ACT_GABOR2D;  // WIRE2D: second Linear (scale_orth) per layer, L[orth0 + l]
+  constexpr bool PAIR = HACT == ACT_GABOR || G2D;
+  constexpr int MT = NB / 2, NG = 2, NW = 4, NS = G2D ? 7 : (PAIR ? 3 : 2);
   constexpr int RH = MT * 32;  // image rows per wave of a pair
   constexpr int TL = NG * 32;
   constexpr int RS = NB * 32 * INR_LDS_LD;
@@ -64,11 +78,12 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
     const long long row0 = (long long)tile * TL;
     const long long crow = row0 + wcol;
     const bool valid = crow < a.B;
-    const bool saving = (MODE != MODE_FWD) || (a.save != nullptr);
+    const bool saving = G2D || (MODE != MODE_FWD) || (a.save != nullptr);  // WIRE2D: the API insists on a buffer
     float* sv = a.save;
     if (saving) sv += (size_t)(a.save_by_block ? blockIdx.x : tile) * nd.save_floats_per_tile;
     float* sv_last = sv + (size_t)NS * (D - 1) * HSZ;
     float* sv_enc = sv_last + 4 * TL;
+    float* sv_g = sv_last + 4 * TL;  // WIRE2D (never gauss): copy of a layer's output gradient [NB*32][TL]
     const bool stash = saving && hh == 0;  // one wave of the pair writes the (shared) lazy-activation stash
 
     // ================================ forward =================================
@@ -97,8 +112,17 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
                                L0.Kpad8, lane);
         }
         acc_to_lds<MT, true>(acc, Rown, a.packed + L0.pbias_off + m0 * 32, lane);
+        if (G2D) {  // orth_0 = V_0 x + c_0 (own rows) -> stash slots 5, 6 of layer 0
+          const LayerDesc& O0 = nd.L[nd.orth0];
+#pragma unroll
+          for (int m = 0; m < MT; ++m) acc[m] = zero16();
+          fwd_layer0_x<MT, NB>(acc, a.packed + O0.pf_off + aoff, a.x + (size_t)(valid ? crow : 0) * O0.K, valid, O0.K,
+                               O0.Kpad8, lane);
+          orth_epilogue<MT, TL, NB>(acc, a.packed + O0.pbias_off + m0 * 32, sv + (size_t)5 * HSZ + (size_t)m0 * 32 * TL,
+                                    wcol, lane);
+        }
       }
-      __syncthreads();  // z_0 complete
+      __syncthreads();  // z_0 (and orth_0) complete
       for (int l = 1; l < D - 1; ++l) {
         const LayerDesc& Ll = nd.L[l];
         const ActParams ap{nd.L[l - 1].omega, nd.L[l - 1].s0};
@@ -109,10 +133,18 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
         if (stash)
           fwd_layer<NB, MT, TL, HACT, true, NB>(acc, R, a.packed + Ll.pf_off + aoff, ap, sh, wcol, lane);
         else
-          fwd_layer<NB, MT, TL, HACT, false, NB>(acc, R, a.packed + Ll.pf_off + aoff, ap, nullptr, wcol, lane);
-        __syncthreads();  // both waves of the pair have read z_{l-1}
+          fwd_layer<NB, MT, TL, HACT, false, NB>(acc, R, a.packed + Ll.pf_off + aoff, ap, G2D ? sh : nullptr, wcol, lane);  // WIRE2D reads orth terms from sh
+        __syncthreads();  // both waves of the pair have read z_{l-1}; h_{l-1} is in the stash
         acc_to_lds<MT, true>(acc, Rown, a.packed + Ll.pbias_off + m0 * 32, lane);
-        __syncthreads();  // z_l complete
+        if (G2D) {  // orth_l = V_l h_{l-1} + c_l (own rows) with h_{l-1} back from the stash -> slots 5, 6 of layer l
+          const LayerDesc& Ol = nd.L[nd.orth0 + l];
+#pragma unroll
+          for (int m = 0; m < MT; ++m) acc[m] = zero16();
+          gemm_stash_nat<MT, TL, NB, NB>(acc, a.packed + Ol.pf_off + aoff, sh, wcol, lane);
+          orth_epilogue<MT, TL, NB>(acc, a.packed + Ol.pbias_off + m0 * 32,
+                                    sv + (size_t)(NS * l + 5) * HSZ + (size_t)m0 * 32 * TL, wcol, lane);
+        }
+        __syncthreads();  // z_l (and orth_l) complete
       }
       float g4[4] = {0.f, 0.f, 0.f, 0.f}, dy[4] = {0.f, 0.f, 0.f, 0.f};
       if (hh == 0) {  // last layer: one row block
@@ -186,6 +218,7 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
       for (int l = D - 2; l >= 1; --l) {
         const LayerDesc& Ll = nd.L[l];
         __syncthreads();  // dH_l complete
+        if (G2D) rows_copy<TL, RH, true>(R, sv_g, RH * hh, wcol, lane);  // needed again for the orth Linear
         rows_times<TL, RH, PAIR>(R, sv + (size_t)(NS * l + 1) * HSZ, sv + (size_t)(NS * l + 2) * HSZ, RH * hh, wcol,
                                  lane);  // own rows: dZ_l = dH_l * act'
         __syncthreads();
@@ -202,6 +235,21 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
           }
         }
         __syncthreads();  // dZ_l has been read by every dW pass and dX
+        if (G2D) {  // second Linear of the layer: dZ_orth = J_orth dH_l, dH_{l-1} += V_l^T dZ_orth, dV_l
+          const LayerDesc& Ol = nd.L[nd.orth0 + l];
+          rows_copy<TL, RH, false>(R, sv_g, RH * hh, wcol, lane);
+          rows_times<TL, RH, true>(R, sv + (size_t)(NS * l + 3) * HSZ, sv + (size_t)(NS * l + 4) * HSZ, RH * hh, wcol, lane);
+          __syncthreads();
+          bwd_dx<MT, TL, false, false, NB>(gacc, R, a.packed + Ol.pb_off + aoff, Ol.Mpad8, nullptr, wcol, lane);
+          BSrcStash<TL> bs{sv + (size_t)(NS * (l - 1)) * HSZ};
+          for (int it = w; it < 2 * Ol.Kblk; it += NW) {
+            const int n = it >> 1, c = it & 1;
+            dw_pass<MT, TL, true, BSrcStash<TL>>(lds + c * MT * 32 * INR_LDS_LD, RS, bs, n,
+                                                 slab + Ol.gw_off + (size_t)c * RH * Ol.K, slab + Ol.gb_off + c * RH,
+                                                 Ol.M, Ol.K, first, n == 0, lane);
+          }
+          __syncthreads();
+        }
         if (l == 1)
           acc_times_d_to_lds<MT, TL, PAIR>(gacc, Rown, sv + (size_t)1 * HSZ + (size_t)m0 * 32 * TL,
                                            sv + (size_t)2 * HSZ + (size_t)m0 * 32 * TL, wcol, lane);
@@ -226,6 +274,19 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
             dw_pass<MT, TL, true, BSrcX>(lds + c * MT * 32 * INR_LDS_LD, RS, bs, n,
                                          slab + L0.gw_off + (size_t)c * RH * L0.K, slab + L0.gb_off + c * RH, L0.M,
                                          L0.K, first, n == 0, lane);
+          }
+          if (G2D) {  // dV_0 from dZ_0,orth = J_orth,0 dH_0 (the accumulators still hold dH_0)
+            const LayerDesc& O0 = nd.L[nd.orth0];
+            __syncthreads();
+            acc_times_d_to_lds<MT, TL, true>(gacc, Rown, sv + (size_t)3 * HSZ + (size_t)m0 * 32 * TL,
+                                             sv + (size_t)4 * HSZ + (size_t)m0 * 32 * TL, wcol, lane);
+            __syncthreads();
+            for (int it = w; it < 2 * O0.Kblk; it += NW) {
+              const int n = it >> 1, c = it & 1;
+              dw_pass<MT, TL, true, BSrcX>(lds + c * MT * 32 * INR_LDS_LD, RS, bs, n,
+                                           slab + O0.gw_off + (size_t)c * RH * O0.K, slab + O0.gb_off + c * RH, O0.M,
+                                           O0.K, first, n == 0, lane);
+            }
           }
         }
         __syncthreads();

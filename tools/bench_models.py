@@ -62,4 +62,19 @@ mac = 512 * 512 + 6 * 512 * 512 + 512 * 2
 flop = 2 * (3 * mac - 512 * 512)
 res["SIREN_8x512_L2_B100000"] = {"ms_per_step": ms, "samples_per_s": B / ms * 1e3, "TFLOPs": flop * B / ms / 1e9,
                                  "frac_f32_mfma": flop * B / ms / 1e9 / 157.3}
+# the reference's shipped WIRE2D config (config/remote/config_wire2d_kspace.yaml): depth 3 / width 256 (not reduced)
+B = 25000
+torch.manual_seed(0)
+net = dict(network_input_size=3, network_output_size=2, network_depth=3, network_width=256, first_omega_0=30, hidden_omega_0=30, scale=15)
+model = M.WIRE2D(net).to(dev); eng = model._engine()
+coords = (torch.rand(B, 3) * 2 - 1).to(dev); gt = (torch.randn(B, 2) * 0.2).to(dev)
+spec = M.LossSpec(L.LOSS_L2_HALF)
+def step():
+    eng.train_step(coords, None, gt, spec); eng.adam_step(1e-4)
+ms = timeit(step, n=10)
+mac = 4 * (2 * (3 * 256) // 4 * 4 // 4) + 0  # first layer: real 3 x 256, two Linears (negligible)
+cmac = 3 * 2 * 256 * 256 + 256 * 2             # complex MACs: 3 hidden layers x 2 Linears + last
+flop = 8 * cmac * 3                            # 8 FLOP per complex MAC, fwd + dW + dX
+res["WIRE2D_3x256_L2_B25000"] = {"ms_per_step": ms, "samples_per_s": B / ms * 1e3, "TFLOPs": flop * B / ms / 1e9,
+                                 "frac_f32_mfma": flop * B / ms / 1e9 / 157.3}
 print(json.dumps(res, indent=1))
