@@ -141,13 +141,21 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    # INR_BENCH_REHEARSAL=1: every rank on cuda:0 over gloo -- to rehearse the N > 1 code path on a one-GPU box
+    # (numbers from such a run mean nothing; the driver's multi-GPU runs use one GPU per rank over nccl = RCCL)
+    rehearsal = os.environ.get("INR_BENCH_REHEARSAL", "0") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     pg = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from inr_mi355x.synthetic import make_kspace
     from inr_mi355x.train import INRTrainer
