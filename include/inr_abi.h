@@ -95,11 +95,13 @@ enum inr_loss {
 typedef struct inr_net_desc {
   int32_t kind;         /* enum inr_kind */
   int32_t in_features;  /* net.network_input_size */
-  int32_t width;        /* hidden features: net.network_width for SIREN/FFN (32 or 256); for WIRE the number of
-                           COMPLEX hidden features, int(network_width / sqrt(2)) (networks.py:228): <= 32 or 181 */
+  int32_t width;        /* hidden features: net.network_width for SIREN / FFN / MFN / WIRE2D (1..512; WIRE2D counts
+                           complex features, <= 256); for WIRE the number of COMPLEX hidden features,
+                           int(network_width / sqrt(2)) (networks.py:228), <= 192.  Widths between the built
+                           block counts run zero-padded. */
   int32_t depth;        /* net.network_depth as the reference counts it: all Linear layers for SIREN/FFN,
                            hidden complex layers only for WIRE (total Linear = depth + 2) */
-  int32_t out_features; /* net.network_output_size, <= 32 */
+  int32_t out_features; /* net.network_output_size, 1..4 */
   int32_t last_act;     /* enum inr_act */
   int32_t input;        /* enum inr_input */
   int32_t enc_size;     /* E (encoder.embedding_size) when input == INR_INPUT_GAUSS */
