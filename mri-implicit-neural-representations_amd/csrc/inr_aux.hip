@@ -89,7 +89,18 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const NetDesc nd, con
           s *= vp.sign[0];
         } else {
           const size_t o1 = (size_t)L.gw_off + (size_t)vp.row[1] * L.K + vp.col[1];
-          for (int b = 0; b < n_blocks; ++b)
+          int b = 0;
+          for (; b + 4 <= n_blocks; b += 4) {  // 8 independent loads in flight; fixed summation order
+            float u[4], v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              u[k] = slabs[(size_t)(b + k) * sf + o0];
+              v[k] = slabs[(size_t)(b + k) * sf + o1];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s += vp.sign[0] * u[k] + vp.sign[1] * v[k];
+          }
+          for (; b < n_blocks; ++b)
             s += vp.sign[0] * slabs[(size_t)b * sf + o0] + vp.sign[1] * slabs[(size_t)b * sf + o1];
         }
       } else if (vp.bias_row >= 0) {
