@@ -32,6 +32,50 @@ __device__ __forceinline__ void rows_times(float* R, const float* __restrict__ d
   }
 }
 
+// WIRE, eager activation: the owner of row blocks [m0, m0+MT) holds both rows of every complex feature in registers
+// (2p, 2p+1), so the Gabor wavelet (one sincos + one exp per feature, networks.py:199-204) and the four Jacobian
+// entries of the pair are formed ONCE -- the lazy form evaluates them in both lane halves of both waves of the pair
+// (4x the transcendentals).  Writes y into the image rows (the next GEMM's plain B operand) and y, dA, dB to the
+// stash rows (Rown / sv_* already point at this wave's rows).
+template <int MT, int TL>
+__device__ __forceinline__ void wire_epilogue(const f32x16 (&acc)[MT], const float* __restrict__ bias, float* Rown,
+                                              float* __restrict__ sv_h, float* __restrict__ sv_dA,
+                                              float* __restrict__ sv_dB, bool save, float omega, float s0, int wcol,
+                                              int lane) {
+  const int half = lane >> 5, col = lane & 31;
+  float* Rl = Rown + (4 * half) * INR_LDS_LD + col;
+  const int so = (4 * half) * TL + wcol;
+  const float* bl = bias + 4 * half;
+  const float s2 = s0 * s0;
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(bl + 32 * m + 8 * g);
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int row = 32 * m + 8 * g + 2 * p;  // Re row (+ 4*half folded into Rl / so); Im row = row + 1
+        const float za = acc[m][4 * g + 2 * p] + b4[2 * p], zb = acc[m][4 * g + 2 * p + 1] + b4[2 * p + 1];
+        float sn, cs;
+        sincos_cw(omega * za, sn, cs);
+        const float E = expf(-omega * zb - s2 * (za * za + zb * zb));
+        const float yr = E * cs, yi = E * sn;
+        Rl[row * INR_LDS_LD] = yr;
+        Rl[(row + 1) * INR_LDS_LD] = yi;
+        if (save) {
+          const float ka = -2.f * s2 * za, kb = -omega - 2.f * s2 * zb;
+          sv_h[so + row * TL] = yr;
+          sv_h[so + (row + 1) * TL] = yi;
+          sv_dA[so + row * TL] = fmaf(ka, yr, -omega * yi);  // d y_r / d a
+          sv_dB[so + row * TL] = fmaf(ka, yi, omega * yr);   // d y_i / d a
+          sv_dA[so + (row + 1) * TL] = kb * yr;              // d y_r / d b
+          sv_dB[so + (row + 1) * TL] = kb * yi;              // d y_i / d b
+        }
+      }
+    }
+  }
+}
+
 // own rows of the image <-> global scratch [rows][TL] (WIRE2D: a layer's output gradient is needed twice)
 template <int TL, int RH, bool TO_GLOBAL>
 __device__ __forceinline__ void rows_copy(float* R, float* __restrict__ G, int r0, int wcol, int lane) {
@@ -50,6 +94,7 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr bool G2D = HACT == ACT_GABOR2D;  // WIRE2D: second Linear (scale_orth) per layer, L[orth0 + l]
   constexpr bool PAIR = HACT == ACT_GABOR || G2D;
+  constexpr bool EAGER = HACT == ACT_GABOR;  // WIRE: the image holds activations y, formed by the row owners
   constexpr int MT = NB / 2, NG = 2, NW = 4, NS = G2D ? 7 : (PAIR ? 3 : 2);
   constexpr int RH = MT * 32;  // image rows per wave of a pair
   constexpr int TL = NG * 32;
@@ -111,7 +156,12 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
           fwd_layer0_x<MT, NB>(acc, a.packed + L0.pf_off + aoff, a.x + (size_t)(valid ? crow : 0) * L0.K, valid, L0.K,
                                L0.Kpad8, lane);
         }
-        acc_to_lds<MT, true>(acc, Rown, a.packed + L0.pbias_off + m0 * 32, lane);
+        if (EAGER)
+          wire_epilogue<MT, TL>(acc, a.packed + L0.pbias_off + m0 * 32, Rown, sv + (size_t)m0 * 32 * TL,
+                                sv + (size_t)1 * HSZ + (size_t)m0 * 32 * TL, sv + (size_t)2 * HSZ + (size_t)m0 * 32 * TL,
+                                saving, L0.omega, L0.s0, wcol, lane);
+        else
+          acc_to_lds<MT, true>(acc, Rown, a.packed + L0.pbias_off + m0 * 32, lane);
         if (G2D) {  // orth_0 = V_0 x + c_0 (own rows) -> stash slots 5, 6 of layer 0
           const LayerDesc& O0 = nd.L[nd.orth0];
 #pragma unroll
@@ -130,12 +180,20 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
 #pragma unroll
         for (int m = 0; m < MT; ++m) acc[m] = zero16();
         float* sh = sv + (size_t)(NS * (l - 1)) * HSZ;
-        if (stash)
+        if (EAGER)  // plain GEMM on the activations in the image
+          bwd_dx<MT, TL, false, false, NB>(acc, R, a.packed + Ll.pf_off + aoff, NB * 32, nullptr, wcol, lane);
+        else if (stash)
           fwd_layer<NB, MT, TL, HACT, true, NB>(acc, R, a.packed + Ll.pf_off + aoff, ap, sh, wcol, lane);
         else
           fwd_layer<NB, MT, TL, HACT, false, NB>(acc, R, a.packed + Ll.pf_off + aoff, ap, G2D ? sh : nullptr, wcol, lane);  // WIRE2D reads orth terms from sh
         __syncthreads();  // both waves of the pair have read z_{l-1}; h_{l-1} is in the stash
-        acc_to_lds<MT, true>(acc, Rown, a.packed + Ll.pbias_off + m0 * 32, lane);
+        if (EAGER) {
+          float* so = sv + (size_t)(NS * l) * HSZ + (size_t)m0 * 32 * TL;
+          wire_epilogue<MT, TL>(acc, a.packed + Ll.pbias_off + m0 * 32, Rown, so, so + HSZ, so + 2 * (size_t)HSZ, saving,
+                                Ll.omega, Ll.s0, wcol, lane);
+        } else {
+          acc_to_lds<MT, true>(acc, Rown, a.packed + Ll.pbias_off + m0 * 32, lane);
+        }
         if (G2D) {  // orth_l = V_l h_{l-1} + c_l (own rows) with h_{l-1} back from the stash -> slots 5, 6 of layer l
           const LayerDesc& Ol = nd.L[nd.orth0 + l];
 #pragma unroll
@@ -152,7 +210,9 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
         accL[0] = zero16();
         const ActParams ap{nd.L[D - 2].omega, nd.L[D - 2].s0};
         float* sh = sv + (size_t)(NS * (D - 2)) * HSZ;
-        if (saving)
+        if (EAGER)
+          bwd_dx<1, TL, false, false>(accL, R, a.packed + LL.pf_off, NB * 32, nullptr, wcol, lane);
+        else if (saving)
           fwd_layer<NB, 1, TL, HACT, true>(accL, R, a.packed + LL.pf_off, ap, sh, wcol, lane);
         else
           fwd_layer<NB, 1, TL, HACT, false>(accL, R, a.packed + LL.pf_off, ap, nullptr, wcol, lane);
