@@ -72,7 +72,9 @@ enum inr_act {
   INR_ACT_SIN = 1,     /* sin(w0 z): hidden SIREN layers; last layer if network_last_linear False */
   INR_ACT_TANH = 2,    /* last_tanh: True, networks.py:94-95 */
   INR_ACT_RELU = 3,    /* FFN hidden, networks.py:57-60 */
-  INR_ACT_SIGMOID = 4  /* FFN output, networks.py:63 */
+  INR_ACT_SIGMOID = 4, /* FFN output, networks.py:63 */
+  INR_ACT_CTANH = 7    /* WIRE2D last_tanh: torch.nn.Tanh() on the complex output before .real (wire2d.py:106-107,
+                          113-117); out_features <= 2 */
 };
 
 /* how the first layer's input is produced */

@@ -234,7 +234,12 @@ int inr_plan_create(const inr_net_desc* d, inr_plan** out) {
       return fail(INR_ERR_INVALID, "inr_plan_create: WIRE2D depth %d", d->depth);
     if (d->input != INR_INPUT_X)
       return fail(INR_ERR_UNSUPPORTED, "inr_plan_create: WIRE takes raw coordinates (input must be INR_INPUT_X)");
-    if (d->last_act != INR_ACT_ID) return fail(INR_ERR_INVALID, "inr_plan_create: WIRE's output is linear");
+    if (d->last_act == INR_ACT_CTANH) {
+      if (!wire2d || d->out_features > 2)
+        return fail(INR_ERR_UNSUPPORTED, "inr_plan_create: INR_ACT_CTANH is WIRE2D's last_tanh, out_features <= 2");
+    } else if (d->last_act != INR_ACT_ID) {
+      return fail(INR_ERR_INVALID, "inr_plan_create: WIRE's output is linear (or INR_ACT_CTANH for WIRE2D)");
+    }
   } else {
     if (NB < 0)
       return fail(INR_ERR_UNSUPPORTED, "inr_plan_create: width %d (kernels are built for widths 1..512)", d->width);
@@ -249,7 +254,7 @@ int inr_plan_create(const inr_net_desc* d, inr_plan** out) {
   } else if (d->input != INR_INPUT_X) {
     return fail(INR_ERR_INVALID, "inr_plan_create: input mode %d", d->input);
   }
-  if (d->last_act < INR_ACT_ID || d->last_act > INR_ACT_SIGMOID)
+  if ((d->last_act < INR_ACT_ID || d->last_act > INR_ACT_SIGMOID) && !(wire2d && d->last_act == INR_ACT_CTANH))
     return fail(INR_ERR_INVALID, "inr_plan_create: last_act %d", d->last_act);
   if (d->precision != INR_PRECISION_F32 && d->precision != INR_PRECISION_BF16)
     return fail(INR_ERR_INVALID, "inr_plan_create: precision %d", d->precision);
@@ -284,8 +289,9 @@ int inr_plan_create(const inr_net_desc* d, inr_plan** out) {
     const bool orth = wire2d && t != nd.ND - 1 && (t & 1);
     LayerDesc& L = nd.L[orth ? nd.orth0 + l : l];
     const bool first = l == 0, last = l == D - 1;
+    const bool ctanh_last = last && d->last_act == INR_ACT_CTANH;  // complex output kept: (Re, Im) row pairs
     L.K = first ? d->in_features : hid;
-    L.M = last ? d->out_features : hid;
+    L.M = last ? (ctanh_last ? 2 * d->out_features : d->out_features) : hid;
     // hidden-to-hidden products run over all NB*32 image rows (padding rows carry zero weights)
     L.Kpad8 = first ? round_up(L.K, 8) : NB * 32;
     L.Kblk = first ? (L.K + 31) / 32 : NB;  // hidden images always span all NB blocks (zero padding)
@@ -310,7 +316,9 @@ int inr_plan_create(const inr_net_desc* d, inr_plan** out) {
       L.omega = d->hidden_omega_0;
       L.s0 = d->scale_0;
     } else {
-      L.ltype = LT_WIRE_LAST;  // complex Linear, output.real (networks.py:247-258)
+      // complex Linear, output.real (networks.py:247-258): only the real rows exist -- unless a complex Tanh sits
+      // before .real (WIRE2D last_tanh), which needs the imaginary rows too: the hidden-layer mapping
+      L.ltype = ctanh_last ? LT_WIRE_HIDDEN : LT_WIRE_LAST;
       L.wn = d->out_features * d->width * 2;
       L.bn = d->out_features * 2;
     }

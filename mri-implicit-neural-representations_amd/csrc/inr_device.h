@@ -18,6 +18,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define ACT_RELU 3
 #define ACT_SIGMOID 4
 #define ACT_GABOR 5   // WIRE complex Gabor wavelet on interleaved (Re, Im) rows; hidden layers only
+#define ACT_CTANH 7   // last layer only: Re(tanh(a + jb)) of a complex output (WIRE2D last_tanh, wire2d.py:106-107,113-117)
 #define ACT_GABOR2D 6 // WIRE2D (wire2d.py:49-60): the same with a second Linear `scale_orth` per layer feeding the
                       // Gaussian window; L[orth0 + l] describes that Linear of layer l
 

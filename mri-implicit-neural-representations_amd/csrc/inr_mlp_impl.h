@@ -94,6 +94,37 @@ __device__ __forceinline__ void act_gabor2d(float za, float zb, float o, float q
   dB2 = ko * yi;
 }
 
+__device__ __forceinline__ void act_fwd_rt(int act, float z, float w0, float& h, float& d);
+
+// WIRE2D last_tanh: torch.nn.Tanh() on the complex output, then .real.  tanh(a + jb) = (sinh 2a + j sin 2b) /
+// (cosh 2a + cos 2b) = t_r + j t_i;  y = t_r,  dy/da = Re(1 - tanh^2) = 1 - t_r^2 + t_i^2,  dy/db = 2 t_r t_i.
+__device__ __forceinline__ void act_ctanh(float a, float b, float& y, float& dya, float& dyb) {
+  const float e = expf(2.f * a), ei = 1.f / e;
+  float s2, c2;
+  sincos_cw(2.f * b, s2, c2);
+  const float inv = 1.f / (0.5f * (e + ei) + c2);
+  const float tr = 0.5f * (e - ei) * inv, ti = s2 * inv;
+  y = tr;
+  dya = 1.f - tr * tr + ti * ti;
+  dyb = 2.f * tr * ti;
+}
+
+// last-layer epilogue shared by the fused kernels: z[r] = the lane's first four accumulator rows (+ bias).  Real
+// outputs: y[o] = act(z[o]), one image row per output.  ACT_CTANH: rows (2o, 2o+1) = (Re, Im) of output o.
+// drow[r] = d y / d z[r];  returns the number of image rows that carry a gradient.
+__device__ __forceinline__ int last_layer_act(int last_act, int out_f, float w0, const float (&z)[4], float (&y)[4],
+                                              float (&drow)[4]) {
+  if (last_act == ACT_CTANH) {
+#pragma unroll
+    for (int o = 0; o < 2; ++o) act_ctanh(z[2 * o], z[2 * o + 1], y[o], drow[2 * o], drow[2 * o + 1]);
+    y[2] = y[3] = 0.f;
+    return 2 * out_f;
+  }
+#pragma unroll
+  for (int o = 0; o < 4; ++o) act_fwd_rt(last_act, z[o], w0, y[o], drow[o]);
+  return out_f;
+}
+
 __device__ __forceinline__ void act_fwd_rt(int act, float z, float w0, float& h, float& d) {
   switch (act) {
     case ACT_SIN: act_fwd<ACT_SIN>(z, w0, h, d); break;
@@ -843,15 +874,19 @@ __global__ __launch_bounds__(NW * 64) void inr_mlp_kernel(const NetDesc nd, cons
         else
           fwd_layer<NB, 1, TL, HACT, false>(accL, R, a.packed + LL.pf_off, ap, nullptr, wcol, lane);
       }
-      float y[4], dy[4], g[4];
+      float zl[4], y[4], dy[4], g[4];
+      const bool ctanh = nd.last_act == ACT_CTANH;
+      const int nrows_in = ctanh ? 2 * nd.out_f : nd.out_f;
 #pragma unroll
       for (int o = 0; o < 4; ++o) {
-        float z = accL[0][o];
-        if (o < nd.out_f) z += a.packed[LL.pbias_off + o];
-        act_fwd_rt(nd.last_act, z, nd.w0, y[o], dy[o]);
+        zl[o] = accL[0][o];
+        if (o < nrows_in) zl[o] += a.packed[LL.pbias_off + o];
         g[o] = 0.f;
-        if (half == 0 && valid && o < nd.out_f && a.out != nullptr) a.out[crow * nd.out_f + o] = y[o];
       }
+      const int nrows = last_layer_act(nd.last_act, nd.out_f, nd.w0, zl, y, dy);  // dy[r]: per image row
+#pragma unroll
+      for (int o = 0; o < 4; ++o)
+        if (half == 0 && valid && o < nd.out_f && a.out != nullptr) a.out[crow * nd.out_f + o] = y[o];
       if (MODE == MODE_FWD) {
         if (saving && half == 0) {
 #pragma unroll
@@ -868,7 +903,7 @@ __global__ __launch_bounds__(NW * 64) void inr_mlp_kernel(const NetDesc nd, cons
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           float v = 0.f;
-          if (r < 4 && half == 0 && r < nd.out_f) v = g[r & 3] * dy[r & 3];
+          if (r < 4 && half == 0 && r < nrows) v = g[ctanh ? (r & 3) >> 1 : (r & 3)] * dy[r & 3];
           R[swz(acc_row(r, half), col)] = v;
         }
       }
@@ -881,7 +916,9 @@ __global__ __launch_bounds__(NW * 64) void inr_mlp_kernel(const NetDesc nd, cons
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           float v = 0.f;
-          if (r < 4 && half == 0 && r < nd.out_f && valid) v = a.dout[crow * nd.out_f + r] * sv_last[r * TL + wcol];
+          const bool ct = nd.last_act == ACT_CTANH;
+          if (r < 4 && half == 0 && r < (ct ? 2 * nd.out_f : nd.out_f) && valid)
+            v = a.dout[crow * nd.out_f + (ct ? (r & 3) >> 1 : (r & 3))] * sv_last[(r & 3) * TL + wcol];
           R[swz(acc_row(r, half), col)] = v;
         }
       }

@@ -205,6 +205,7 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
         __syncthreads();  // z_l (and orth_l) complete
       }
       float g4[4] = {0.f, 0.f, 0.f, 0.f}, dy[4] = {0.f, 0.f, 0.f, 0.f};
+      int nrows_last = nd.out_f;
       if (hh == 0) {  // last layer: one row block
         f32x16 accL[1];
         accL[0] = zero16();
@@ -216,14 +217,17 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
           fwd_layer<NB, 1, TL, HACT, true>(accL, R, a.packed + LL.pf_off, ap, sh, wcol, lane);
         else
           fwd_layer<NB, 1, TL, HACT, false>(accL, R, a.packed + LL.pf_off, ap, nullptr, wcol, lane);
-        float y[4];
+        float zl[4], y[4];
+        const bool ctanh = nd.last_act == ACT_CTANH;
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
-          float z = accL[0][o];
-          if (o < nd.out_f) z += a.packed[LL.pbias_off + o];
-          act_fwd_rt(nd.last_act, z, nd.w0, y[o], dy[o]);
-          if (half == 0 && valid && o < nd.out_f && a.out != nullptr) a.out[crow * nd.out_f + o] = y[o];
+          zl[o] = accL[0][o];
+          if (o < (ctanh ? 2 * nd.out_f : nd.out_f)) zl[o] += a.packed[LL.pbias_off + o];
         }
+        nrows_last = last_layer_act(nd.last_act, nd.out_f, nd.w0, zl, y, dy);
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+          if (half == 0 && valid && o < nd.out_f && a.out != nullptr) a.out[crow * nd.out_f + o] = y[o];
         if (MODE == MODE_FWD) {
           if (saving && half == 0) {
 #pragma unroll
@@ -241,7 +245,8 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             float v = 0.f;
-            if (r < 4 && half == 0 && r < nd.out_f) v = g4[r & 3] * dy[r & 3];
+            if (r < 4 && half == 0 && r < nrows_last)
+              v = g4[nd.last_act == ACT_CTANH ? (r & 3) >> 1 : (r & 3)] * dy[r & 3];
             R[swz(acc_row(r, half), col)] = v;
           }
         }
@@ -254,7 +259,9 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           float v = 0.f;
-          if (r < 4 && half == 0 && r < nd.out_f && valid) v = a.dout[crow * nd.out_f + r] * sv_last[r * TL + wcol];
+          const bool ct = nd.last_act == ACT_CTANH;
+          if (r < 4 && half == 0 && r < (ct ? 2 * nd.out_f : nd.out_f) && valid)
+            v = a.dout[crow * nd.out_f + (ct ? (r & 3) >> 1 : (r & 3))] * sv_last[(r & 3) * TL + wcol];
           R[swz(acc_row(r, half), col)] = v;
         }
       }

@@ -295,12 +295,11 @@ class _GaborLayer2DShell(nn.Module):
 class WIRE2D(_FlatModel):
     """wire2d.py:62-117.  ComplexGaborLayer2D (:3-60): y = exp(j w0 lin) * exp(-s0^2 (|lin|^2 + |orth|^2)) with a
     second Linear ``scale_orth`` per layer; the hidden width is NOT reduced (:76); output is the real part.
-    ``last_tanh`` (a complex Tanh before ``.real``, :106-107) has no kernel yet and raises."""
+    ``last_tanh`` puts ``torch.nn.Tanh()`` on the complex output before ``.real`` (:106-107, :113-117)."""
 
     def __init__(self, params):
         super().__init__()
-        if params.get("last_tanh", False):
-            raise NotImplementedError("WIRE2D last_tanh (complex Tanh before .real)")
+        self.last_tanh = bool(params.get("last_tanh", False))
         self.hidden_layers = params["network_depth"]
         self.hidden_features = params["network_width"]
         self.in_features = params["network_input_size"]
@@ -330,5 +329,5 @@ class WIRE2D(_FlatModel):
         if input_mode != L.INPUT_X:
             raise NotImplementedError("WIRE2D takes raw coordinates (encoder.embedding: none)")
         return MLPEngine(L.KIND_WIRE2D, self.in_features, self.hidden_features, self.hidden_layers, self.out_features,
-                         L.ACT_ID, L.INPUT_X, 0, 0.0, float(self.first_omega_0), float(self.hidden_omega_0),
-                         float(self.scale))
+                         L.ACT_CTANH if self.last_tanh else L.ACT_ID, L.INPUT_X, 0, 0.0, float(self.first_omega_0),
+                         float(self.hidden_omega_0), float(self.scale))

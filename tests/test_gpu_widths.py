@@ -110,13 +110,15 @@ def test_wire_widths(dev, width):
     _check(out, loss, eng.grads.cpu(), r32, r64)
 
 
+@pytest.mark.parametrize("last_tanh", [False, True])
 @pytest.mark.parametrize("width", [8, 24, 64, 100, 256])
-def test_wire2d_widths(dev, width):
-    """WIRE2D keeps network_width complex features (wire2d.py:76): 16 .. 512 interleaved rows."""
+def test_wire2d_widths(dev, width, last_tanh):
+    """WIRE2D keeps network_width complex features (wire2d.py:76): 16 .. 512 interleaved rows; with and without
+    the complex Tanh before .real (last_tanh)."""
     import inr_mi355x as M
     from inr_mi355x import _lib as L
     net = dict(network_input_size=3, network_output_size=2, network_depth=2, network_width=width,
-               first_omega_0=10, hidden_omega_0=10, scale=5)
+               first_omega_0=10, hidden_omega_0=10, scale=5, last_tanh=last_tanh)
     torch.manual_seed(width)
     mdl = M.WIRE2D(net)
     sd = {k: v.clone() for k, v in mdl.state_dict().items()}

@@ -40,7 +40,7 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.mark.parametrize("name", ["WIRE", "WIRE2D"])
+@pytest.mark.parametrize("name", ["WIRE", "WIRE2D", "WIRE2D_tanh"])
 def test_wire_tier1_golden(dev, name):
     """Drop-in WIRE / WIRE2D + stock torch.optim.Adam on complex Parameters vs the reference's vectors."""
     import inr_mi355x as M
@@ -50,7 +50,7 @@ def test_wire_tier1_golden(dev, name):
     x, gt = _t(arrs["x"]).to(dev), _t(arrs["gt"]).to(dev)
     for wd_tag, wd in (("wd0", 0.0), ("wd1", meta["wd1"])):
         torch.manual_seed(meta["seed"])
-        model = getattr(M, name)(meta["net"])
+        model = getattr(M, name.split("_")[0])(meta["net"])
         sd = model.state_dict()
         gold_keys = [k[3:] for k in arrs if k.startswith("sd/")]
         assert list(sd.keys()) == gold_keys
@@ -84,7 +84,7 @@ def test_wire_tier1_golden(dev, name):
                                                msg=lambda m: f"{wd_tag} step{step} {k}: {m}")
 
 
-@pytest.mark.parametrize("name", ["WIRE", "WIRE2D"])
+@pytest.mark.parametrize("name", ["WIRE", "WIRE2D", "WIRE2D_tanh"])
 def test_wire_tier2_fused_golden(dev, name):
     import inr_mi355x as M
     from inr_mi355x import _lib as L
@@ -94,7 +94,7 @@ def test_wire_tier2_fused_golden(dev, name):
     x, gt = _t(arrs["x"]).to(dev), _t(arrs["gt"]).to(dev)
     for wd_tag, wd in (("wd0", 0.0), ("wd1", meta["wd1"])):
         torch.manual_seed(meta["seed"])
-        model = getattr(M, name)(meta["net"]).to(dev)
+        model = getattr(M, name.split("_")[0])(meta["net"]).to(dev)
         eng = model._engine()
         for step in range(1, 4):
             loss = eng.train_step(x, None, gt, M.LossSpec(L.LOSS_L2_HALF))

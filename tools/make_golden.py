@@ -72,6 +72,8 @@ TINY = {
                  first_omega_0=30, hidden_omega_0=30, scale=15),
     "WIRE2D": dict(network_input_size=3, network_output_size=2, network_depth=2, network_width=32,
                    first_omega_0=20, hidden_omega_0=20, scale=10),
+    "WIRE2D_tanh": dict(network_input_size=3, network_output_size=2, network_depth=2, network_width=32,
+                        first_omega_0=20, hidden_omega_0=20, scale=10, last_tanh=True),
     "Fourier": dict(network_input_size=16, network_output_size=2, network_depth=3, network_width=32),
     "Gabor": dict(network_input_size=16, network_output_size=2, network_depth=3, network_width=32),
     "KGabor": dict(network_input_size=16, network_output_size=2, network_depth=3, network_width=32),
@@ -95,7 +97,7 @@ FULL = {
 
 
 def model_kind(name):
-    return {"SIREN_tanh": "SIREN", "SIREN_raw3": "SIREN", "SIREN4": "SIREN"}.get(name, name)
+    return {"SIREN_tanh": "SIREN", "SIREN_raw3": "SIREN", "SIREN4": "SIREN", "WIRE2D_tanh": "WIRE2D"}.get(name, name)
 
 
 def build(name, net, seed, enc=None):
