@@ -91,7 +91,8 @@ enum inr_loss {
   INR_LOSS_L1_HALF = 1, /* 0.5 * torch.nn.L1Loss()    train.py:92,182 */
   INR_LOSS_TANH = 2,    /* TanhL2Loss                 metrics/losses.py:130-139 */
   INR_LOSS_LOGSPACE = 3,/* LogSpaceLoss               metrics/losses.py:214-223 */
-  INR_LOSS_HDR = 4      /* HDRLoss_FF (separable form) metrics/losses.py:236-264 */
+  INR_LOSS_HDR = 4,     /* HDRLoss_FF (separable form) metrics/losses.py:236-264 */
+  INR_LOSS_MSLE_HALF = 5 /* 0.5 * MSLELoss()           metrics/losses.py:18-27; train.py:84,182 */
 };
 
 typedef struct inr_net_desc {

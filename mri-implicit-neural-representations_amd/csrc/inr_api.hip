@@ -534,7 +534,7 @@ int inr_loss_grad(const inr_loss_desc* loss, const float* out, const float* gt, 
                   const uint8_t* mask, int64_t B, float* loss_out, float* dout, void* stream) {
   if (loss == nullptr || out == nullptr || gt == nullptr || loss_out == nullptr || dout == nullptr)
     return fail(INR_ERR_INVALID, "inr_loss_grad: null argument");
-  if (loss->kind < INR_LOSS_L2_HALF || loss->kind > INR_LOSS_HDR)
+  if (loss->kind < INR_LOSS_L2_HALF || loss->kind > INR_LOSS_MSLE_HALF)
     return fail(INR_ERR_INVALID, "inr_loss_grad: loss kind %d", loss->kind);
   if (B <= 0) return fail(INR_ERR_INVALID, "inr_loss_grad: B = %lld", (long long)B);
   LossDesc ld;
@@ -548,7 +548,7 @@ int inr_loss_grad_multi(const inr_loss_desc* loss, const float* outs, const floa
                         const uint8_t* mask, int32_t n_heads, int64_t B, float* loss_out, float* douts, void* stream) {
   if (loss == nullptr || outs == nullptr || gt == nullptr || loss_out == nullptr || douts == nullptr)
     return fail(INR_ERR_INVALID, "inr_loss_grad_multi: null argument");
-  if (loss->kind < INR_LOSS_L2_HALF || loss->kind > INR_LOSS_HDR)
+  if (loss->kind < INR_LOSS_L2_HALF || loss->kind > INR_LOSS_MSLE_HALF)
     return fail(INR_ERR_INVALID, "inr_loss_grad_multi: loss kind %d", loss->kind);
   if (n_heads < 1 || n_heads > INR_MAX_HEADS || B <= 0)
     return fail(INR_ERR_INVALID, "inr_loss_grad_multi: n_heads %d, B %lld", n_heads, (long long)B);
@@ -583,7 +583,7 @@ int inr_train_step(const inr_plan* plan, const inr_loss_desc* loss, const float*
   if (plan->nd.mfn_n > 0)
     return fail(INR_ERR_INVALID, "inr_train_step: multiplicative-filter plans use inr_train_step_multi");
   if (plan->nd.input == IN_GAUSS && enc_B == nullptr) return fail(INR_ERR_INVALID, "inr_train_step: enc_B is null");
-  if (loss->kind < INR_LOSS_L2_HALF || loss->kind > INR_LOSS_HDR)
+  if (loss->kind < INR_LOSS_L2_HALF || loss->kind > INR_LOSS_MSLE_HALF)
     return fail(INR_ERR_INVALID, "inr_train_step: loss kind %d", loss->kind);
   if (loss->kind >= INR_LOSS_LOGSPACE && plan->nd.out_f != 2)
     return fail(INR_ERR_INVALID, "inr_train_step: complex-row losses need out_features == 2");
@@ -704,7 +704,7 @@ int inr_train_step_multi(const inr_plan* plan, const inr_loss_desc* loss, const 
       enc_B == nullptr || gt == nullptr || save == nullptr || slabs == nullptr || loss_out == nullptr)
     return fail(INR_ERR_INVALID, "inr_train_step_multi: null argument");
   if (plan->nd.mfn_n == 0) return fail(INR_ERR_INVALID, "inr_train_step_multi: not a multiplicative-filter plan");
-  if (loss->kind < INR_LOSS_L2_HALF || loss->kind > INR_LOSS_HDR)
+  if (loss->kind < INR_LOSS_L2_HALF || loss->kind > INR_LOSS_MSLE_HALF)
     return fail(INR_ERR_INVALID, "inr_train_step_multi: loss kind %d", loss->kind);
   if ((loss->cons_w != 0.f || plan->nd.bounded) && dist == nullptr)
     return fail(INR_ERR_INVALID, "inr_train_step_multi: the consistency term / bounded linears need dist");

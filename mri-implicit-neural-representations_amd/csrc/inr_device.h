@@ -38,6 +38,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define LOSS_TANH 2
 #define LOSS_LOGSPACE 3
 #define LOSS_HDR 4
+#define LOSS_MSLE_HALF 5
 
 struct LayerDesc {
   int K, M;          // in / out features of the (virtual) real matrix the kernel multiplies
@@ -184,6 +185,14 @@ __device__ __forceinline__ float loss_row(const LossDesc& ld, int out_f, const f
     loss = (er * er + ei * ei) * q;
     g[0] = 2.f * er * q;
     g[1] = 2.f * ei * q;
+  } else if (ld.kind == LOSS_MSLE_HALF) {  // 0.5 * MSLELoss (losses.py:18-27; train.py:84,182): MSE of log(. + 1 + 1e-9)
+    const float s = inv / (float)out_f;
+    for (int o = 0; o < out_f; ++o) {
+      const float ay = (y[o] + 1.f) + 1e-9f;
+      const float e = logf(ay) - logf((t[o] + 1.f) + 1e-9f);
+      loss += 0.5f * e * e * s;
+      g[o] = e / ay * s;
+    }
   } else {  // LOSS_HDR: HDRLoss_FF, separable form (losses.py:236-264)
     const float er = y[0] - t[0], ei = y[1] - t[1];
     const float ya2 = y[0] * y[0] + y[1] * y[1];

@@ -17,7 +17,7 @@ PRECISION_F32, PRECISION_BF16 = 0, 1
 ACT_ID, ACT_SIN, ACT_TANH, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3, 4
 ACT_CTANH = 7  # WIRE2D last_tanh: complex Tanh before .real
 INPUT_X, INPUT_GAUSS = 0, 1
-LOSS_L2_HALF, LOSS_L1_HALF, LOSS_TANH, LOSS_LOGSPACE, LOSS_HDR = 0, 1, 2, 3, 4
+LOSS_L2_HALF, LOSS_L1_HALF, LOSS_TANH, LOSS_LOGSPACE, LOSS_HDR, LOSS_MSLE_HALF = 0, 1, 2, 3, 4, 5
 LOSS_WORDS = 128  # floats a loss_out buffer must hold (word 0 = loss, 1..64 = ordered partials)
 
 

@@ -223,7 +223,7 @@ def test_persistent_blocks_and_determinism(dev):
     assert rel_l2(g_a.cpu(), ref_grad) < 1e-5
 
 
-@pytest.mark.parametrize("kind", ["L1", "tanh", "LogSpace", "HDR"])
+@pytest.mark.parametrize("kind", ["L1", "tanh", "LogSpace", "HDR", "MSLE"])
 def test_losses_fused_and_tier1(dev, kind):
     """Pointwise losses: fused in-kernel evaluation and inr_loss_grad agree with the oracle's autograd."""
     import inr_mi355x as M
@@ -241,7 +241,8 @@ def test_losses_fused_and_tier1(dev, kind):
     f = torch.exp(-(coords[:, 1] ** 2 + coords[:, 2] ** 2) / (2 * 2.0 ** 2))
     A = float(torch.mean((1 - f) ** 2))
     loss = {"L1": lambda: O.loss_l1_half(out, gt), "tanh": lambda: O.loss_tanh(out, gt)[0],
-            "LogSpace": lambda: O.loss_logspace(out, gt, opts), "HDR": lambda: O.loss_hdr(out, gt, coords, opts)[0]}[kind]()
+            "LogSpace": lambda: O.loss_logspace(out, gt, opts), "HDR": lambda: O.loss_hdr(out, gt, coords, opts)[0],
+            "MSLE": lambda: 0.5 * O.loss_msle(out, gt)}[kind]()
     ref_grad = torch.cat([x.reshape(-1) for x in torch.autograd.grad(loss, list(params.values()), retain_graph=True)])
     (ref_dout,) = torch.autograd.grad(loss, out)
     spec = M.LossSpec.from_config({"loss": kind, "loss_opts": opts})
