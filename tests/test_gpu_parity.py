@@ -463,3 +463,22 @@ def test_full_baseline_size_properties(dev):
     ref = reconstruct(tr.image, shape, False)
     assert ref.shape == (640, 368) and float(psnr(ref, ref)) > 80  # (iv): the reference psnr carries an eps in the MSE
     assert np.isfinite(tr.evaluate())
+
+
+def test_full_size_trajectory_vs_oracle(dev):
+    """BASELINE config 2 for real: SIREN 5x256 / gauss-512, 25 000-coordinate batches of the synthetic 640x368x15 k-space,
+    six Adam steps through INRTrainer against the oracle's restatement of the train.py loop on the same rows (the
+    oracle only ever sees the first 150 000 rows, which is all six sequential batches touch)."""
+    from inr_mi355x.synthetic import make_kspace
+    from inr_mi355x.train import INRTrainer
+    image, coords, shape = make_kspace(15, 640, 368, seed=1234, normalization="coil")
+    cfg = dict(model="SIREN", loss="L2", lr=3e-5, batch_size=25000, max_epoch=1000, weight_decay=0.0, beta1=0.9,
+               beta2=0.999, net=FULL_NET, encoder=FULL_ENC)
+    tr = INRTrainer(cfg, image, coords, shape, dev, seed=0)
+    sd = {k: v.detach().cpu().clone() for k, v in tr.model.state_dict().items()}
+    n = 6 * 25000
+    want = O.train_single_scale(cfg, sd, tr.encoder.B.cpu(), coords[:n], image[:n], 6)
+    got = np.array([s[1] for s in tr.fit(6, log_every=1)])
+    np.testing.assert_allclose(got, np.array(want), rtol=1e-5)
+    flat = torch.cat([sd[k].reshape(-1) for k in tr.model.state_dict().keys()])
+    assert rel_l2(tr.engine.params.cpu(), flat) < 1e-5
