@@ -162,10 +162,12 @@ static int create_mfn_plan(const inr_net_desc* d, inr_plan** out) {
     LayerDesc& L = nd.L[l];
     const bool filter = l <= n || l >= nd.mu0;
     const bool mu = l >= nd.mu0;
+    const bool head = l >= 2 * n + 1 && l < nd.mu0;
+    // hidden-width layers keep whole 32-row blocks in the slab (the plain dW pass stores them without a bounds test)
     L.gw_off = goff;
-    goff += L.M * L.K;
+    goff += (head ? L.M : NB * 32) * L.K;
     L.gb_off = goff;
-    goff += mu ? 2 * NB * 32 : L.M;  // LT_GABOR_MU: [s0 | T], NB*32 apart
+    goff += mu ? 2 * NB * 32 : (head ? L.M : NB * 32);  // LT_GABOR_MU: [s0 | T], NB*32 apart
     L.pf_off = (int)pk;
     pk += (int64_t)L.Kpad8 * L.Mblk * 32;
     if (!filter) {
@@ -179,7 +181,8 @@ static int create_mfn_plan(const inr_net_desc* d, inr_plan** out) {
   }
   nd.slab_loss_off = goff;
   nd.slab_floats = round_up(goff + 4, 64);
-  nd.save_floats_per_tile = 3 * nd.mfn_stages * NB * 32 * TL + nd.L[0].Kblk * 32 * TL + (gabor ? TL : 0);
+  // stash: [f | l cos u | h] per stage, encoder features, |x|^2 [TL], and (512-wide kernel) a copy of g_h [NB*32][TL]
+  nd.save_floats_per_tile = 3 * nd.mfn_stages * NB * 32 * TL + nd.L[0].Kblk * 32 * TL + TL + (NB == 16 ? NB * 32 * TL : 0);
   p->packed_floats = pk;
   *out = p;
   return INR_OK;
@@ -603,9 +606,6 @@ int inr_train_step(const inr_plan* plan, const inr_loss_desc* loss, const float*
   a.B = B;
   a.n_tiles = (int)nt;
   a.save_by_block = 1;
-#ifdef INR_STAMPS
-  a.dbg = g_stamp_buf;
-#endif
   LossDesc ld;
   to_loss_desc(loss, &ld);
   int rc = launch(plan, ld, a, 2, (int)nb, (hipStream_t)stream);

@@ -194,6 +194,49 @@ def test_mfn_full_size_vs_oracle(dev, shape):
     assert abs(float(loss) - float(l64)) <= max(10 * abs(float(l32) - float(l64)), 2e-5 * abs(float(l64)))
 
 
+@pytest.mark.parametrize("kind", ["multiscale", "gabor", "bounded"])
+def test_wide_mfn_persistent_blocks_additivity(dev, kind):
+    """The 512-wide kernel at a batch where every workgroup walks several tiles (40 000 rows = 625 tiles on 256
+    workgroups): its slabs carry running sums from tile to tile.  Gradient and loss must equal the sum over three
+    pieces that fit one tile per workgroup -- the path test_mfn_full_size_vs_oracle pins against the oracle."""
+    import inr_mi355x as M
+    from inr_mi355x import _lib as L
+    from inr_mi355x.mfn import GaborNet, MultiscaleKFourier, MultiscaleBoundedFourier
+    net = dict(network_input_size=512, network_output_size=2, network_depth=8 if kind != "gabor" else 3,
+               network_width=512)
+    enc_cfg = dict(embedding="gauss", scale=4, embedding_size=256, coordinates_size=3)
+    torch.manual_seed(0)
+    enc = M.Positional_Encoder(enc_cfg, device=dev)
+    cls = dict(multiscale=MultiscaleKFourier, gabor=GaborNet,
+               bounded=lambda n_: MultiscaleBoundedFourier(n_, boundaries=META["BoundedFourier"]["bounds8"]))[kind]
+    model = cls(net).to(dev).bind_encoder(enc)
+    eng = model._engine()
+    B = 40000
+    g = torch.Generator().manual_seed(1)
+    coords = (torch.rand(B, 3, generator=g) * 2 - 1).to(dev)
+    gt = (torch.randn(B, 2, generator=g) * 0.2).to(dev)
+    dist = torch.sqrt(coords[:, 1] ** 2 + coords[:, 2] ** 2).contiguous()
+    spec = M.LossSpec(L.LOSS_L2_HALF)
+    nt, nb = eng.launch_dims(B)
+    assert nt > 2 * nb
+    kw = dict(dist=dist) if kind != "gabor" else {}
+
+    def step(lo, hi):
+        k = {n: v[lo:hi] for n, v in kw.items()}
+        l = float(eng.train_step(coords[lo:hi], enc.B.contiguous(), gt[lo:hi], spec, count=B, **k))
+        return l, eng.grads.clone()
+
+    l_all, g_all = step(0, B)
+    cuts = [0, 16000, 32000, B]
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        assert eng.launch_dims(hi - lo)[0] <= nb
+    parts = [step(lo, hi) for lo, hi in zip(cuts[:-1], cuts[1:])]
+    l_sum, g_sum = sum(p[0] for p in parts), sum(p[1] for p in parts)
+    assert abs(l_sum - l_all) <= 5e-6 * abs(l_all)
+    assert rel_l2(g_sum, g_all) < 5e-6
+    assert torch.equal(step(0, B)[1], g_all)  # run-to-run determinism
+
+
 @pytest.mark.parametrize("model", ["Fourier", "Gabor", "KGabor"])
 def test_single_scale_trainer_mfn_vs_oracle(dev, model):
     """train.py's registry (train.py:63-68) also builds the filter networks for the single-scale loop:
