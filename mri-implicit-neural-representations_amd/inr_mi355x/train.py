@@ -269,13 +269,18 @@ def main():
     ap.add_argument("--config", type=str, required=True)
     ap.add_argument("--data_samples", type=str, default="")
     ap.add_argument("--output_path", type=str, default=".")
-    ap.add_argument("--synthetic", type=str, default="15,640,368", help="C,H,W of the synthetic k-space")
+    ap.add_argument("--synthetic", type=str, default=None,
+                    help="C,H,W: fit a synthetic k-space of that shape instead of the scan the config names")
     ap.add_argument("--max_steps", type=int, default=None)
     opts = ap.parse_args()
     config = set_default_configs(get_config(opts.config))
-    C, H, W = (int(v) for v in opts.synthetic.split(","))
-    image, coords, shape = make_kspace(C, H, W, normalization=config.get("normalization", "coil"),
-                                       image_space=bool(config.get("transform", False)))
+    if opts.synthetic:
+        C, H, W = (int(v) for v in opts.synthetic.split(","))
+        image, coords, shape = make_kspace(C, H, W, normalization=config.get("normalization", "coil"),
+                                           image_space=bool(config.get("transform", False)))
+    else:  # train.py:271-287: config['data_root'/'data'/'set'/'sample'/'slice'] (or 'custom_file_or_path')
+        from .datasets import from_config, trainer_inputs
+        image, coords, shape = trainer_inputs(from_config(config, "cuda"))
     tr = INRTrainer(config, image, coords, shape, "cuda")
     t0 = time.time()
     tr.fit(opts.max_steps, log_every=config.get("log_iter", 20))

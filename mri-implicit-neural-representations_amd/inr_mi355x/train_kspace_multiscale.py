@@ -185,8 +185,8 @@ class MultiscaleTrainer:
 
 
 def main():
-    """CLI with the reference's flags (train_kspace_multiscale.py:50-52): --config, --output_path; the fastMRI
-    loader is replaced by the synthetic k-space (--synthetic C,H,W)."""
+    """CLI with the reference's flags (train_kspace_multiscale.py:50-52): --config, --output_path; the scan
+    comes from datasets.py, or a synthetic k-space with --synthetic C,H,W."""
     import argparse
     import json
     import os
@@ -198,14 +198,19 @@ def main():
     ap.add_argument("--config", type=str, required=True)
     ap.add_argument("--data_samples", type=str, default="")
     ap.add_argument("--output_path", type=str, default=".")
-    ap.add_argument("--synthetic", type=str, default="15,640,368")
+    ap.add_argument("--synthetic", type=str, default=None,
+                    help="C,H,W: fit a synthetic k-space of that shape instead of the scan the config names")
     ap.add_argument("--max_steps", type=int, default=None)
     opts = ap.parse_args()
     config = set_default_configs(get_config(opts.config))
     if config["model"] not in ("BoundedFourier",):
         config["model"] = "MultiscaleKFourier"  # train_kspace_multiscale.py:93-98: anything else is the unbounded net
-    C, H, W = (int(v) for v in opts.synthetic.split(","))
-    image, coords, shape = make_kspace(C, H, W, normalization=config.get("normalization", "max"))
+    if opts.synthetic:
+        C, H, W = (int(v) for v in opts.synthetic.split(","))
+        image, coords, shape = make_kspace(C, H, W, normalization=config.get("normalization", "max"))
+    else:  # train_kspace_multiscale.py:57-72: the scan named by config['data_root'/'data'/'set'/'sample'/'slice']
+        from .datasets import from_config, trainer_inputs
+        image, coords, shape = trainer_inputs(from_config(config, "cuda"))
     dist = torch.sqrt(coords[:, 1] ** 2 + coords[:, 2] ** 2)
     tr = MultiscaleTrainer(config, image, coords, dist, None, shape, "cuda")
     t0 = time.time()

@@ -428,6 +428,35 @@ def test_cli_runs_the_shipped_configs(dev, module, cfg, extra, tmp_path):
     assert set(ck) == {"net", "enc", "opt"}
 
 
+@pytest.mark.parametrize("module,cfg", [("inr_mi355x.train", "config_siren_kspace.yaml"),
+                                        ("inr_mi355x.train_kspace_multiscale", "config_fourier_multiscale.yaml")])
+def test_cli_ingests_a_scan_file(dev, module, cfg, tmp_path):
+    """Without --synthetic the CLIs read the scan the config names (train.py:271-287): data_root/<data>_multicoil_<set>/,
+    entry ``sample``, slice ``slice`` -- here a two-file directory of .npz scans with an ISMRMRD header."""
+    import subprocess
+    import sys
+    import yaml
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = tmp_path / "brain_multicoil_train"
+    d.mkdir()
+    rng = np.random.default_rng(0)
+    hdr = ("<ismrmrdHeader xmlns='http://www.ismrm.org/ISMRMRD'><encoding><reconSpace><matrixSize><x>48</x><y>40</y>"
+           "<z>1</z></matrixSize></reconSpace></encoding></ismrmrdHeader>").encode()
+    for name in ("file_brain_0.npz", "file_brain_1.npz"):
+        ks = (rng.standard_normal((2, 3, 64, 44)) + 1j * rng.standard_normal((2, 3, 64, 44))).astype(np.complex64)
+        np.savez(d / name, kspace=ks, ismrmrd_header=np.frombuffer(hdr, np.uint8))
+    config = yaml.safe_load(open(os.path.join(root, "configs", cfg)))
+    config.update(data="brain", data_root=str(tmp_path), set="train", sample=1, slice=1, batch_size=1000)
+    cpath = tmp_path / "cfg.yaml"
+    yaml.safe_dump(config, open(cpath, "w"))
+    env = dict(os.environ, PYTHONPATH=os.path.join(root, "mri-implicit-neural-representations_amd"))
+    out = subprocess.run([sys.executable, "-m", module, "--config", str(cpath), "--output_path", str(tmp_path),
+                          "--max_steps", "3"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res["steps"] == 3 and np.isfinite(res["psnr"])
+
+
 def test_full_baseline_size_properties(dev):
     """BASELINE config 2 at its real size (640x368x15 = 3 532 800 coordinates, SIREN 5x256, batch 25 000), through
     properties that need no oracle run: (i) gradient additivity -- the fused step on a batch equals the sum of the
