@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define INR_ABI_VERSION 1
+#define INR_ABI_VERSION 2
 
 /* error codes */
 #define INR_OK 0
@@ -142,6 +142,7 @@ typedef struct inr_sizes {
   int64_t save_bytes_per_tile; /* activation stash per tile (tier 1: n_tiles of them) */
   int64_t max_blocks;      /* upper bound on the persistent grid (slab count) */
   int64_t slab_floats;     /* floats per gradient slab (= P + 4 loss words, padded) */
+  int64_t step_save_by_tile; /* inr_train_step_multi's `save`: 1 = n_tiles slots, 0 = n_blocks slots */
 } inr_sizes;
 
 int inr_abi_version(void);
@@ -219,12 +220,15 @@ int inr_train_step(const inr_plan* plan, const inr_loss_desc* loss, const float*
 /* Multi-head networks (MultiscaleKFourier.forward returns a list, mfn.py:255-267): `out` / `dout` are
  * [n_heads][B][out_features]; `dist` [B] = dist_to_center (nerp_datasets.py:385), read by the
  * consistency term; `save` is always required (it also carries the encoder features between stages;
- * pass n_blocks slots and by_block = 1 for a no_grad sweep, n_tiles slots and 0 before inr_backward_multi). */
+ * pass n_blocks slots and by_block = 1 for a no_grad sweep, n_tiles slots and 0 before inr_backward_multi).
+ * inr_backward_multi CONSUMES the stash: plans with inr_sizes.step_save_by_tile overwrite stashed factors with
+ * the gradient operands of their batch-level weight-gradient GEMM, so one forward serves one backward.
+ * inr_train_step_multi takes n_tiles slots when step_save_by_tile is set, n_blocks slots otherwise. */
 int inr_forward_multi(const inr_plan* plan, const float* params, const float* packed, const float* coords,
                       const float* enc_B, const float* dist, int64_t B, float* out, float* save,
                       int32_t by_block, void* stream);
 int inr_backward_multi(const inr_plan* plan, const float* params, const float* packed, const float* coords,
-                       const float* enc_B, const float* dist, int64_t B, const float* dout, const float* save,
+                       const float* enc_B, const float* dist, int64_t B, const float* dout, float* save,
                        float* slabs, float* grads, void* stream);
 /* MultiscaleBoundedFourier(boundaries=pairs_model) (train_kspace_multiscale.py:85,95): one (lo,hi) per hidden
  * Linear; must be called before the plan is used (dist may be NULL for the other kinds above). */

@@ -181,8 +181,8 @@ static int create_mfn_plan(const inr_net_desc* d, inr_plan** out) {
   }
   nd.slab_loss_off = goff;
   nd.slab_floats = round_up(goff + 4, 64);
-  // stash: [f | l cos u | h] per stage, encoder features, |x|^2 [TL], and (512-wide kernel) a copy of g_h [NB*32][TL]
-  nd.save_floats_per_tile = 3 * nd.mfn_stages * NB * 32 * TL + nd.L[0].Kblk * 32 * TL + TL + (NB == 16 ? NB * 32 * TL : 0);
+  // stash: [f | l cos u | h] per stage, encoder features, |x|^2 [TL]
+  nd.save_floats_per_tile = 3 * nd.mfn_stages * NB * 32 * TL + nd.L[0].Kblk * 32 * TL + TL;
   p->packed_floats = pk;
   *out = p;
   return INR_OK;
@@ -365,6 +365,10 @@ int inr_plan_destroy(inr_plan* plan) {
   return INR_OK;
 }
 
+// the 512-wide filter-network kernel leaves the hidden-width weight gradients to a batch-level GEMM that reads every
+// tile's stash, so its fused step needs n_tiles stash slots instead of n_blocks
+static bool step_save_by_tile(const inr_plan* plan) { return plan->nd.mfn_n != 0 && plan->nd.NB == 16; }
+
 int inr_plan_sizes(const inr_plan* plan, inr_sizes* out) {
   if (plan == nullptr || out == nullptr) return fail(INR_ERR_INVALID, "inr_plan_sizes: null argument");
   out->n_params = plan->nd.P;
@@ -373,6 +377,7 @@ int inr_plan_sizes(const inr_plan* plan, inr_sizes* out) {
   out->save_bytes_per_tile = (int64_t)plan->nd.save_floats_per_tile * 4;
   out->max_blocks = kMaxBlocks;
   out->slab_floats = plan->nd.slab_floats;
+  out->step_save_by_tile = step_save_by_tile(plan) ? 1 : 0;
   return INR_OK;
 }
 
@@ -663,7 +668,7 @@ int inr_forward_multi(const inr_plan* plan, const float* params, const float* pa
 }
 
 int inr_backward_multi(const inr_plan* plan, const float* params, const float* packed, const float* coords,
-                       const float* enc_B, const float* dist, int64_t B, const float* dout, const float* save,
+                       const float* enc_B, const float* dist, int64_t B, const float* dout, float* save,
                        float* slabs, float* grads, void* stream) {
   if (plan == nullptr || params == nullptr || packed == nullptr || coords == nullptr || enc_B == nullptr ||
       dout == nullptr || save == nullptr || slabs == nullptr || grads == nullptr)
@@ -681,7 +686,7 @@ int inr_backward_multi(const inr_plan* plan, const float* params, const float* p
   a.encB = enc_B;
   a.dout = dout;
   a.dist = dist;
-  a.save = const_cast<float*>(save);
+  a.save = save;
   a.slabs = slabs;
   a.B = B;
   a.n_tiles = (int)nt;
@@ -724,7 +729,7 @@ int inr_train_step_multi(const inr_plan* plan, const inr_loss_desc* loss, const 
   a.slabs = slabs;
   a.B = B;
   a.n_tiles = (int)nt;
-  a.save_by_block = 1;
+  a.save_by_block = step_save_by_tile(plan) ? 0 : 1;
   LossDesc ld;
   to_loss_desc(loss, &ld);
   int rc = launch(plan, ld, a, 2, (int)nb, (hipStream_t)stream);

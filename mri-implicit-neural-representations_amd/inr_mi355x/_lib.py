@@ -36,9 +36,13 @@ class LossDesc(C.Structure):
                 ("cons_inv", C.c_float * 4)]
 
 
+ABI_VERSION = 2  # INR_ABI_VERSION of include/inr_abi.h
+
+
 class Sizes(C.Structure):
     _fields_ = [("n_params", C.c_int64), ("packed_floats", C.c_int64), ("tile_rows", C.c_int64),
-                ("save_bytes_per_tile", C.c_int64), ("max_blocks", C.c_int64), ("slab_floats", C.c_int64)]
+                ("save_bytes_per_tile", C.c_int64), ("max_blocks", C.c_int64), ("slab_floats", C.c_int64),
+                ("step_save_by_tile", C.c_int64)]
 
 
 # every symbol include/inr_abi.h declares: (name, restype, argtypes)
@@ -86,8 +90,8 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the export is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.inr_abi_version() != 1:
-        raise RuntimeError(f"libinr_mi355x.so ABI version {lib.inr_abi_version()} != 1")
+    if lib.inr_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"libinr_mi355x.so ABI version {lib.inr_abi_version()} != {ABI_VERSION}")
     _lib = lib
     return lib
 

@@ -70,6 +70,7 @@ class MLPEngine:
         self.save_floats_per_tile = int(sz.save_bytes_per_tile) // 4
         self.max_blocks = int(sz.max_blocks)
         self.slab_floats = int(sz.slab_floats)
+        self.step_save_by_tile = bool(sz.step_save_by_tile)
         self.in_features, self.out_features = in_features, out_features
         self.input_mode = input_mode
         self.always_save = kind == L.KIND_WIRE2D or precision == L.PRECISION_BF16  # its orth terms travel through the save buffer even when not training
@@ -297,12 +298,13 @@ class MFNEngine(MLPEngine):
                    dist: Optional[torch.Tensor] = None, scale: float = 1.0,
                    cons: Optional[ConsistencySpec] = None):
         B = coords.shape[0]
-        _, nb = self.launch_dims(B)
+        nt, nb = self.launch_dims(B)
         ld = self.multi_loss_desc(spec, B if count is None else count, hdr_A, scale, cons)
         L.check(self.lib.inr_train_step_multi(self.plan, C.byref(ld), _ptr(self.params, "params"),
                                               _ptr(self.packed, "packed"), _ptr(coords, "coords"),
                                               _ptr(enc_B, "enc_B"), _ptr(gt, "gt"), _ptr(dist, "dist"),
-                                              _ptr(mask, "mask", torch.uint8), B, _ptr(self._ws_save(nb), "save"),
+                                              _ptr(mask, "mask", torch.uint8), B,
+                                              _ptr(self._ws_save(nt if self.step_save_by_tile else nb), "save"),
                                               _ptr(self._ws_slabs(nb), "slabs"), _ptr(self.grads, "grads"),
                                               _ptr(self._loss, "loss"), self._stream()))
         return self._loss[0]

@@ -23,7 +23,7 @@ def test_abi_header_symbols_exported():
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.inr_abi_version() == 1
+    assert lib.inr_abi_version() == 2
 
 
 def test_plan_validation_and_sizes():
