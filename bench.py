@@ -204,8 +204,8 @@ def main():
         eng = tr.engine
         x, gt = tr.coords[:batch], tr.image[:batch]
         ld = eng.loss_desc(tr.loss, batch)
-        _, nb = eng.launch_dims(batch)
-        save, slabs = eng._ws_save(nb), eng._ws_slabs(nb)
+        slots, n_slabs = eng.workspace(batch)
+        save, slabs = eng._ws_save(slots), eng._ws_slabs(n_slabs)
 
         def fused_only():
             L.check(eng.lib.inr_train_step(eng.plan, C.byref(ld), eng.params.data_ptr(), eng.packed.data_ptr(),

@@ -155,6 +155,11 @@ int inr_plan_destroy(inr_plan* plan);
 int inr_plan_sizes(const inr_plan* plan, inr_sizes* out);
 /* number of tiles / persistent blocks / workspace bytes for a batch of B rows */
 int inr_plan_launch_dims(const inr_plan* plan, int64_t B, int64_t* n_tiles, int64_t* n_blocks);
+/* buffers of a training step on B rows: `save` slots (of save_bytes_per_tile) that inr_train_step /
+ * inr_train_step_multi need -- n_tiles for plans whose weight gradients come from the batch-level GEMM
+ * (inr_sizes.step_save_by_tile), n_blocks otherwise -- and the number of slabs (of slab_floats) behind `slabs` for
+ * the step and backward entry points: n_blocks, plus one per K-chunk of that GEMM. */
+int inr_plan_workspace(const inr_plan* plan, int64_t B, int64_t* step_save_slots, int64_t* n_slabs);
 
 /* Re-orders flat params into the MFMA A-fragment image the kernels stream (no reference
  * counterpart: it is what `model.to(device)` + ATen's GEMM packing do implicitly). */
@@ -177,9 +182,10 @@ int inr_forward(const inr_plan* plan, const float* params, const float* packed, 
 
 /* Replaces loss.backward() through the model (train.py:189): given d(loss)/d(out) [B,out_features]
  * and the forward's `save`, writes d(loss)/d(params) into grads [P].  `slabs` is workspace of
- * n_blocks * slab_floats floats. */
+ * n_slabs * slab_floats floats (inr_plan_workspace).  The stash is CONSUMED: plans with
+ * inr_sizes.step_save_by_tile overwrite act'(z_l) with dZ_l, the operand of their weight-gradient GEMM. */
 int inr_backward(const inr_plan* plan, const float* params, const float* packed, const float* x,
-                 const float* enc_B, int64_t B, const float* dout, const float* save, float* slabs,
+                 const float* enc_B, int64_t B, const float* dout, float* save, float* slabs,
                  float* grads, void* stream);
 
 /* Replaces the loss modules + their autograd (train.py:178-182; metrics/losses.py): writes

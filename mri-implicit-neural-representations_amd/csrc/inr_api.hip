@@ -9,7 +9,10 @@
 #include <new>
 
 #include "../../include/inr_abi.h"
+#include <string>
+
 #include "inr_aux.h"
+#include "inr_dw_gemm.h"
 
 namespace {
 
@@ -365,9 +368,55 @@ int inr_plan_destroy(inr_plan* plan) {
   return INR_OK;
 }
 
-// the 512-wide filter-network kernel leaves the hidden-width weight gradients to a batch-level GEMM that reads every
-// tile's stash, so its fused step needs n_tiles stash slots instead of n_blocks
-static bool step_save_by_tile(const inr_plan* plan) { return plan->nd.mfn_n != 0 && plan->nd.NB == 16; }
+// Plans whose hidden-width weight gradients come from inr_dw_gemm.hip instead of in-kernel dW passes: the plain MLP
+// kernels (SIREN / FFN / WIRE, fp32, one wave per coordinate group).  Their fused step stashes per TILE and a second
+// set of slabs (one per K-chunk of the GEMM) follows the fused kernel's n_blocks slabs.
+static bool dw_gemm_plan(const inr_plan* plan) {
+  const NetDesc& nd = plan->nd;
+  if (nd.mfn_n != 0 || nd.bf16 || nd.hact == ACT_GABOR2D || nd.NB != 8) return false;  // 256-row tensors fill the GEMM's tiles
+  return nd.D > 2 || nd.input == IN_GAUSS;  // at least one hidden-width layer with a stashed input
+}
+
+// the 512-wide filter-network kernel does the same with its own GEMM (inr_mfn_wide_impl.h) into the fused slabs
+static bool step_save_by_tile(const inr_plan* plan) {
+  return (plan->nd.mfn_n != 0 && plan->nd.NB == 16) || dw_gemm_plan(plan);
+}
+
+// items, chunking and the flat-gradient range [lo, hi) of the layers the GEMM covers
+static void dw_gemm_setup(const inr_plan* plan, int64_t nt, inr::DwGemmArgs* g, inr::SlabSplit* split) {
+  const NetDesc& nd = plan->nd;
+  memset(g, 0, sizeof(*g));
+  const int TL = 32 * nd.NW, HSZ = nd.NB * 32 * TL, D = nd.D;
+  const int NS = nd.hact == ACT_GABOR ? 3 : 2;
+  g->TL = TL;
+  g->save_floats_per_tile = nd.save_floats_per_tile;
+  g->slab_floats = nd.slab_floats;
+  g->n_tiles = (int)nt;
+  int k = 0;
+  if (nd.input == IN_GAUSS) {
+    inr::DwGemmItem& it = g->it[k++];
+    it.g_off = 1 * HSZ;
+    it.h_off = NS * (D - 1) * HSZ + 4 * TL;
+    it.gw_off = nd.L[0].gw_off, it.gb_off = nd.L[0].gb_off;
+    it.Mblk = nd.NB, it.Kblk = nd.L[0].Kblk, it.K = nd.L[0].K;
+  }
+  for (int l = 1; l <= D - 2; ++l) {
+    inr::DwGemmItem& it = g->it[k++];
+    it.g_off = (NS * l + 1) * HSZ;
+    it.h_off = NS * (l - 1) * HSZ;
+    it.gw_off = nd.L[l].gw_off, it.gb_off = nd.L[l].gb_off;
+    it.Mblk = nd.NB, it.Kblk = nd.L[l].Kblk, it.K = nd.L[l].K;
+  }
+  g->n_items = k;
+  // about one workgroup per CU: the accumulators then stay in registers over as many tiles as possible
+  const int bpc = inr::dw_gemm_units(*g);
+  const int target = std::max(1, 256 / std::max(1, bpc));
+  g->tiles_per_chunk = (int)((nt + target - 1) / target);
+  g->n_chunks = (int)((nt + g->tiles_per_chunk - 1) / g->tiles_per_chunk);
+  split->lo = nd.L[nd.input == IN_GAUSS ? 0 : 1].w_off;
+  split->hi = nd.L[D - 1].w_off;
+  split->n2 = g->n_chunks;
+}
 
 int inr_plan_sizes(const inr_plan* plan, inr_sizes* out) {
   if (plan == nullptr || out == nullptr) return fail(INR_ERR_INVALID, "inr_plan_sizes: null argument");
@@ -378,6 +427,23 @@ int inr_plan_sizes(const inr_plan* plan, inr_sizes* out) {
   out->max_blocks = kMaxBlocks;
   out->slab_floats = plan->nd.slab_floats;
   out->step_save_by_tile = step_save_by_tile(plan) ? 1 : 0;
+  return INR_OK;
+}
+
+int inr_plan_workspace(const inr_plan* plan, int64_t B, int64_t* step_save_slots, int64_t* n_slabs) {
+  if (plan == nullptr || step_save_slots == nullptr || n_slabs == nullptr)
+    return fail(INR_ERR_INVALID, "inr_plan_workspace: null argument");
+  int64_t nt, nb;
+  int rc = inr_plan_launch_dims(plan, B, &nt, &nb);
+  if (rc != INR_OK) return rc;
+  *step_save_slots = step_save_by_tile(plan) ? nt : nb;
+  *n_slabs = nb;
+  if (dw_gemm_plan(plan)) {
+    inr::DwGemmArgs g;
+    inr::SlabSplit split;
+    dw_gemm_setup(plan, nt, &g, &split);
+    *n_slabs = nb + g.n_chunks;
+  }
   return INR_OK;
 }
 
@@ -487,8 +553,26 @@ int inr_forward(const inr_plan* plan, const float* params, const float* packed, 
   return launch(plan, ld, a, 0, (int)nb, (hipStream_t)stream);
 }
 
+// dW GEMM (plans that use it) + deterministic slab reduction into flat gradients
+static int finish_gradients(const inr_plan* plan, const inr::MlpArgs& a, int64_t nt, int64_t nb, float* grads,
+                            float* loss_out, const float* params, const float* packed, hipStream_t st,
+                            const char* who) {
+  inr::SlabSplit split{0, 0, 0};
+  if (a.dw_gemm) {
+    inr::DwGemmArgs g;
+    dw_gemm_setup(plan, nt, &g, &split);
+    g.save = a.save;
+    g.slabs = a.slabs + (size_t)nb * plan->nd.slab_floats;
+    hipError_t e = inr::launch_dw_gemm(g, st);
+    if (e != hipSuccess) return hip_fail(e, (std::string(who) + ": weight-gradient GEMM").c_str());
+  }
+  hipError_t e = inr::launch_reduce_slabs(plan->nd, a.slabs, (int)nb, grads, loss_out, params, packed, st, split);
+  if (e != hipSuccess) return hip_fail(e, (std::string(who) + ": slab reduction").c_str());
+  return INR_OK;
+}
+
 int inr_backward(const inr_plan* plan, const float* params, const float* packed, const float* x,
-                 const float* enc_B, int64_t B, const float* dout, const float* save, float* slabs,
+                 const float* enc_B, int64_t B, const float* dout, float* save, float* slabs,
                  float* grads, void* stream) {
   if (plan == nullptr || params == nullptr || packed == nullptr || x == nullptr || dout == nullptr ||
       save == nullptr || slabs == nullptr || grads == nullptr)
@@ -505,19 +589,17 @@ int inr_backward(const inr_plan* plan, const float* params, const float* packed,
   a.x = x;
   a.encB = enc_B;
   a.dout = dout;
-  a.save = const_cast<float*>(save);
+  a.save = save;
   a.slabs = slabs;
   a.B = B;
   a.n_tiles = (int)nt;
   a.save_by_block = 0;
+  a.dw_gemm = dw_gemm_plan(plan) ? 1 : 0;
   LossDesc ld;
   memset(&ld, 0, sizeof(ld));
   int rc = launch(plan, ld, a, 1, (int)nb, (hipStream_t)stream);
   if (rc != INR_OK) return rc;
-  hipError_t e = inr::launch_reduce_slabs(plan->nd, slabs, (int)nb, grads, nullptr, params, packed,
-                                          (hipStream_t)stream);
-  if (e != hipSuccess) return hip_fail(e, "inr_backward: slab reduction");
-  return INR_OK;
+  return finish_gradients(plan, a, nt, nb, grads, nullptr, params, packed, (hipStream_t)stream, "inr_backward");
 }
 
 static void to_loss_desc(const inr_loss_desc* l, LossDesc* o) {
@@ -610,16 +692,14 @@ int inr_train_step(const inr_plan* plan, const inr_loss_desc* loss, const float*
   a.slabs = slabs;
   a.B = B;
   a.n_tiles = (int)nt;
-  a.save_by_block = 1;
+  a.dw_gemm = dw_gemm_plan(plan) ? 1 : 0;
+  a.save_by_block = a.dw_gemm ? 0 : 1;
   LossDesc ld;
   to_loss_desc(loss, &ld);
   int rc = launch(plan, ld, a, 2, (int)nb, (hipStream_t)stream);
   if (rc != INR_OK) return rc;
   if (grads == nullptr) return INR_OK;  // profiling: leave the per-block slabs unreduced
-  hipError_t e = inr::launch_reduce_slabs(plan->nd, slabs, (int)nb, grads, loss_out, params, packed,
-                                          (hipStream_t)stream);
-  if (e != hipSuccess) return hip_fail(e, "inr_train_step: slab reduction");
-  return INR_OK;
+  return finish_gradients(plan, a, nt, nb, grads, loss_out, params, packed, (hipStream_t)stream, "inr_train_step");
 }
 
 int inr_plan_set_bounds(inr_plan* plan, const float* lo, const float* hi, int32_t n) {

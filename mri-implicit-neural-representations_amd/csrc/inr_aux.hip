@@ -61,15 +61,36 @@ __device__ __forceinline__ bool locate(const NetDesc& nd, int i, int& l, Virtual
   return false;
 }
 
+// Sum of the per-slab loss words by one whole workgroup (the extra last one of the reduction grids): lane t adds
+// slabs t, t + 256, ..., then a fixed LDS tree -- reproducible, and 196 dependent cache misses shorter than the
+// single-thread loop it replaces (which was the critical path of the whole reduction kernel).
+__device__ __forceinline__ void loss_words_sum(const float* __restrict__ slabs, int n, size_t stride, int off,
+                                               float* __restrict__ loss_out) {
+  __shared__ float red[256];
+  const int t = threadIdx.x;
+  float s = 0.f;
+  for (int b = t; b < n; b += 256) s += slabs[(size_t)b * stride + off];
+  red[t] = s;
+  __syncthreads();
+  for (int w = 128; w >= 1; w >>= 1) {
+    if (t < w) red[t] += red[t + w];
+    __syncthreads();
+  }
+  if (t == 0) loss_out[0] = red[0];
+}
+
 // ---------------------------------------------------------------------------------------------
 // grads[i] = sum over blocks (in block order: deterministic) of the slab entries that flat
 // element i owns; the loss word is summed by thread 0.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void reduce_slabs_kernel(const NetDesc nd, const float* __restrict__ slabs,
-                                                           int n_blocks, float* __restrict__ grads,
-                                                           float* __restrict__ loss_out) {
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const NetDesc nd, const float* __restrict__ slabs_all,
+                                                           int n_blocks_all, float* __restrict__ grads,
+                                                           float* __restrict__ loss_out, SlabSplit split) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   const int sf = nd.slab_floats;
+  const bool second = split.n2 > 0 && i >= split.lo && i < split.hi;
+  const float* __restrict__ slabs = second ? slabs_all + (size_t)n_blocks_all * sf : slabs_all;
+  const int n_blocks = second ? split.n2 : n_blocks_all;
   if (i < nd.P) {
     int l;
     VirtualPos vp;
@@ -110,24 +131,24 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const NetDesc nd, con
     }
     grads[i] = s;
   }
-  if (loss_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
-    float lsum = 0.f;
-    for (int b = 0; b < n_blocks; ++b) lsum += slabs[(size_t)b * sf + nd.slab_loss_off];
-    loss_out[0] = lsum;
-  }
+  if (loss_out != nullptr && blockIdx.x == gridDim.x - 1) loss_words_sum(slabs_all, n_blocks_all, (size_t)sf, nd.slab_loss_off, loss_out);
 }
 
 // Fast path when a slab has the flat-parameter layout (every layer LT_REAL).  A workgroup owns 256
 // consecutive gradient entries (64 lanes x 16 B); its four waves each sum a contiguous quarter of
 // the slabs (8 independent 16-byte loads in flight per lane) and the quarters are combined through
 // LDS in wave order -- a fixed summation tree, so results are bitwise reproducible.
-__global__ __launch_bounds__(256) void reduce_slabs_real_kernel(const float* __restrict__ slabs, int n_blocks,
+__global__ __launch_bounds__(256) void reduce_slabs_real_kernel(const float* __restrict__ slabs_all, int n_blocks_all,
                                                                 int slab_floats, int P, int loss_off,
                                                                 float* __restrict__ grads,
-                                                                float* __restrict__ loss_out) {
+                                                                float* __restrict__ loss_out, SlabSplit split) {
   __shared__ f32x4 part[4][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int i4 = (blockIdx.x * 64 + lane) * 4;
+  // split.lo / split.hi are multiples of 4 (checked by the launcher): a lane's four entries share a slab set
+  const bool second = split.n2 > 0 && i4 >= split.lo && i4 < split.hi;
+  const float* __restrict__ slabs = second ? slabs_all + (size_t)n_blocks_all * slab_floats : slabs_all;
+  const int n_blocks = second ? split.n2 : n_blocks_all;
   const int per = (n_blocks + 3) / 4;
   const int b0 = w * per, b1 = (b0 + per < n_blocks) ? b0 + per : n_blocks;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
@@ -148,11 +169,7 @@ __global__ __launch_bounds__(256) void reduce_slabs_real_kernel(const float* __r
     const f32x4 t = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
     for (int j = 0; j < 4 && i4 + j < P; ++j) grads[i4 + j] = t[j];
   }
-  if (loss_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
-    float lsum = 0.f;
-    for (int b = 0; b < n_blocks; ++b) lsum += slabs[(size_t)b * slab_floats + loss_off];
-    loss_out[0] = lsum;
-  }
+  if (loss_out != nullptr && blockIdx.x == gridDim.x - 1) loss_words_sum(slabs_all, n_blocks_all, (size_t)slab_floats, loss_off, loss_out);
 }
 
 // GaborLayer centres (mfn.py:116-131).  The fused kernel leaves, per filter and row j,
@@ -234,11 +251,7 @@ __global__ __launch_bounds__(256) void reduce_slabs_bf16_kernel(const float* __r
     const f32x4 t = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
     for (int j = 0; j < 4 && i4 + j < P; ++j) grads[i4 + j] = t[j];
   }
-  if (loss_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
-    float lsum = 0.f;
-    for (int b = 0; b < n_blocks; ++b) lsum += slabs[(size_t)b * slab_floats + loss_off];
-    loss_out[0] = lsum;
-  }
+  if (loss_out != nullptr && blockIdx.x == gridDim.x - 1) loss_words_sum(slabs, n_blocks, (size_t)slab_floats, loss_off, loss_out);
 }
 
 // same for zero-padded widths (slab rows are whole 32-row blocks, so element offsets differ from flat offsets)
@@ -258,38 +271,35 @@ __global__ __launch_bounds__(256) void reduce_slabs_bf16_any_kernel(const NetDes
     }
     grads[i] = s;
   }
-  if (loss_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
-    float lsum = 0.f;
-    for (int b = 0; b < n_blocks; ++b) lsum += slabs[(size_t)b * sf + nd.slab_loss_off];
-    loss_out[0] = lsum;
-  }
+  if (loss_out != nullptr && blockIdx.x == gridDim.x - 1) loss_words_sum(slabs, n_blocks, (size_t)sf, nd.slab_loss_off, loss_out);
 }
 
 hipError_t launch_reduce_slabs(const NetDesc& nd, const float* slabs, int n_blocks, float* grads, float* loss_out,
-                               const float* params, const float* packed, hipStream_t st) {
+                               const float* params, const float* packed, hipStream_t st, SlabSplit split) {
+  if (split.n2 > 0 && (nd.bf16 || nd.gabor)) return hipErrorInvalidValue;
   if (nd.bf16) {
     bool same = true;  // slab element offsets == flat offsets (hidden width = whole row blocks, e.g. 256)
     for (int l = 0; l < nd.ND; ++l) same = same && nd.L[l].gw_off == nd.L[l].w_off && nd.L[l].gb_off == nd.L[l].b_off;
     if (same) {
       const int grid = (nd.P + 255) / 256;
-      hipLaunchKernelGGL(reduce_slabs_bf16_kernel, dim3(grid), dim3(256), 0, st, slabs, n_blocks, nd.slab_floats, nd.P,
+      hipLaunchKernelGGL(reduce_slabs_bf16_kernel, dim3(grid + 1), dim3(256), 0, st, slabs, n_blocks, nd.slab_floats, nd.P,
                          nd.slab_loss_off, grads, loss_out);
     } else {
       const int grid = (nd.P + 255) / 256;
-      hipLaunchKernelGGL(reduce_slabs_bf16_any_kernel, dim3(grid), dim3(256), 0, st, nd, slabs, n_blocks, grads,
+      hipLaunchKernelGGL(reduce_slabs_bf16_any_kernel, dim3(grid + 1), dim3(256), 0, st, nd, slabs, n_blocks, grads,
                          loss_out);
     }
     return hipGetLastError();
   }
   bool all_real = true;  // ... and slab layout == flat layout (not the case for MFN: L[] order != flat order)
   for (int l = 0; l < nd.ND; ++l) all_real = all_real && nd.L[l].ltype == LT_REAL && nd.L[l].gw_off == nd.L[l].w_off;
-  if (all_real) {  // slab offsets == flat offsets; slab_floats % 64 == 0 keeps every slab 16-byte aligned
+  if (all_real && ((split.lo | split.hi) & 3) == 0) {  // slab offsets == flat offsets; slab_floats % 64 == 0 keeps every slab 16-byte aligned
     const int grid = (nd.P + 255) / 256;
-    hipLaunchKernelGGL(reduce_slabs_real_kernel, dim3(grid), dim3(256), 0, st, slabs, n_blocks, nd.slab_floats, nd.P,
-                       nd.slab_loss_off, grads, loss_out);
+    hipLaunchKernelGGL(reduce_slabs_real_kernel, dim3(grid + 1), dim3(256), 0, st, slabs, n_blocks, nd.slab_floats, nd.P,
+                       nd.slab_loss_off, grads, loss_out, split);
   } else {
     const int grid = (nd.P + 255) / 256;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(grid), dim3(256), 0, st, nd, slabs, n_blocks, grads, loss_out);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(grid + 1), dim3(256), 0, st, nd, slabs, n_blocks, grads, loss_out, split);
   }
   if (nd.gabor)
     hipLaunchKernelGGL(gabor_finish_kernel, dim3(nd.L[nd.mu0].M, nd.mfn_n + 1), dim3(64), 0, st, nd, slabs, n_blocks,

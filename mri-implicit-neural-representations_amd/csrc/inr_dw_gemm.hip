@@ -1,0 +1,188 @@
+// inr_dw_gemm.hip -- batch-level weight gradients: dW_l = dZ_l^T h_{l-1} over ALL coordinates of a step, as a
+// split-K fp32 MFMA GEMM that reads both operands from the per-tile stash the fused kernel leaves behind.
+//
+// Why not inside the fused kernel (as inr_mlp_impl.h can, and did): there a workgroup owns a slab of every dW and adds
+// its tile's contribution to it.  For one tile per wave the slab is written once (196 x 1.57 MB at the graded
+// shape, then read again by the reduction), the dW passes occupy the 196 busy CUs for a third of the kernel, and
+// three barriers per layer fence them.  Here every CU works, a workgroup keeps a 256 x 256 block of dW in
+// registers across a whole chunk of tiles (K = 512 coordinates and more), and a quarter as many slabs exist.
+//
+// Operand layout (written by the fused kernels): tile t, tensor at offset `off` (floats) inside the tile's stash,
+// row r (a feature), coordinate c of the tile:  save[t * save_floats_per_tile + off + r * TL + c].
+// A workgroup stages K-steps of 32 coordinates (512 rows x 128 B, whole cache lines) through two LDS buffers; each of
+// its four waves accumulates a 128 x 128 block: 4 x 4 MFMA blocks (v_mfma_f32_32x32x2_f32), 8 ds_read_b128 per 64 MFMAs.
+// dW rows follow the C layout of the MFMA: register r of lane (li, half) is row (r&3) + 8(r>>2) + 4 half, column li.
+#include <hip/hip_runtime.h>
+
+#include "inr_dw_gemm.h"
+
+namespace inr {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int DWG_LD = 36;                    // LDS row pitch (floats): 16-byte reads of 8 consecutive rows hit 32 distinct banks
+constexpr int DWG_STAGE = 2 * 256 * DWG_LD;   // floats per stage: G tile [256][32] + H tile [256][32]
+
+template <bool BIAS>
+__device__ __forceinline__ void dwg_mma(f32x16 (&acc)[4][4], float (&bsum)[4], const f32x4 (&A)[4],
+                                        const f32x4 (&B)[4]) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (BIAS) bsum[i] += A[i][e];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[i][e], B[j][e], acc[i][j], 0, 0, 0);
+    }
+}
+
+// one K-step (32 coordinates) of a workgroup's operands: 512 rows x 128 B, thread t fetches 16-byte segment t & 7 of
+// rows (t >> 3) + 32 k -- whole cache lines per 8 lanes
+__device__ __forceinline__ void dwg_fetch(f32x4 (&v)[16], const float* __restrict__ sv, const int (&roff)[16],
+                                          int kstep) {
+#pragma unroll
+  for (int k = 0; k < 16; ++k) v[k] = *reinterpret_cast<const f32x4*>(sv + roff[k] + 32 * kstep);
+}
+
+__device__ __forceinline__ void dwg_stash(float* buf, const f32x4 (&v)[16], int t) {
+  float* p = buf + (t >> 3) * DWG_LD + (t & 7) * 4;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) *reinterpret_cast<f32x4*>(p + k * 32 * DWG_LD) = v[k];
+}
+
+// Workgroup = a 256 x 256 block of one item's dW over one chunk of tiles; waves 2 x 2, 128 x 128 each.
+template <int TL, bool BIAS>
+__device__ __forceinline__ void dwg_body(const DwGemmArgs& a, const DwGemmItem& it, int kc, int mb0, int nb0,
+                                         float* lds) {
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int half = lane >> 5, li = lane & 31;
+  const int wm = w >> 1, wn = w & 1;
+  f32x16 acc[4][4];
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // global row of each of this thread's 16 fetches (rows past a tensor's extent: row 0, never stored)
+  int roff[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int r = (t >> 3) + 32 * k;  // 0..255: G rows, 256..511: H rows
+    const bool isg = r < 256;
+    const int blk = isg ? mb0 + (r >> 5) : nb0 + ((r - 256) >> 5);
+    const int row = (blk < (isg ? it.Mblk : it.Kblk)) ? blk * 32 + (r & 31) : 0;
+    roff[k] = (isg ? it.g_off : it.h_off) + row * TL + (t & 7) * 4;
+  }
+  constexpr int KS = TL / 32;  // K-steps per tile
+  const int t0 = kc * a.tiles_per_chunk;
+  const int t1 = (t0 + a.tiles_per_chunk < a.n_tiles) ? t0 + a.tiles_per_chunk : a.n_tiles;
+  const int n_steps = (t1 - t0) * KS;
+  const float* As = lds + (wm * 128 + li) * DWG_LD + 4 * half;
+  const float* Bs = lds + (256 + wn * 128 + li) * DWG_LD + 4 * half;
+  f32x4 v[16];
+  dwg_fetch(v, a.save + (size_t)t0 * a.save_floats_per_tile, roff, 0);
+  dwg_stash(lds, v, t);
+  __syncthreads();
+#pragma unroll 1
+  for (int s = 0; s < n_steps; ++s) {
+    const int sn = s + 1;
+    if (sn < n_steps)
+      dwg_fetch(v, a.save + (size_t)(t0 + sn / KS) * a.save_floats_per_tile, roff, sn % KS);
+    const float* Ab = As + (s & 1) * DWG_STAGE;
+    const float* Bb = Bs + (s & 1) * DWG_STAGE;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 A[4], B[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) A[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * DWG_LD + 8 * q);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) B[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * DWG_LD + 8 * q);
+      dwg_mma<BIAS>(acc, bsum, A, B);
+    }
+    if (sn < n_steps) dwg_stash(lds + (sn & 1) * DWG_STAGE, v, t);
+    __syncthreads();
+  }
+  float* slab = a.slabs + (size_t)kc * a.slab_floats;
+  const int mb = mb0 + 4 * wm, nb = nb0 + 4 * wn;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (mb + i >= it.Mblk) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int colj = 32 * (nb + j) + li;
+      if (colj < it.K) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = 32 * (mb + i) + (r & 3) + 8 * (r >> 2) + 4 * half;
+          slab[it.gw_off + (size_t)row * it.K + colj] = acc[i][j][r];
+        }
+      }
+    }
+    if (BIAS && wn == 0) {
+      const float tot = bsum[i] + __shfl_xor(bsum[i], 32);
+      if (half == 0) slab[it.gb_off + 32 * (mb + i) + li] = tot;
+    }
+  }
+}
+
+template <int TL>
+__global__ __launch_bounds__(256) void dw_gemm_kernel(const DwGemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int kc = blockIdx.x / a.blocks_per_chunk;
+  const int unit = blockIdx.x - kc * a.blocks_per_chunk;
+  int k = 0;
+  while (k + 1 < a.n_items && unit >= a.it[k + 1].unit0) ++k;
+  const DwGemmItem& it = a.it[k];
+  const int u = unit - it.unit0;
+  const int mi = u / it.nt, ni = u % it.nt;
+  if (ni == 0)
+    dwg_body<TL, true>(a, it, kc, 8 * mi, 0, lds);
+  else
+    dwg_body<TL, false>(a, it, kc, 8 * mi, 8 * ni, lds);
+}
+
+template <int TL>
+static hipError_t launch_tl(const DwGemmArgs& a, dim3 grid, hipStream_t st) {
+  constexpr size_t lds_bytes = (size_t)2 * DWG_STAGE * sizeof(float);  // 147 KB: two stages
+  auto k = dw_gemm_kernel<TL>;
+  static thread_local bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k, grid, dim3(256), lds_bytes, st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_dw_gemm(DwGemmArgs& a, hipStream_t st) {
+  if (a.n_items <= 0) return hipSuccess;
+  if (a.n_items > INR_DWG_MAX_ITEMS || a.n_chunks <= 0 || a.tiles_per_chunk <= 0) return hipErrorInvalidValue;
+  a.blocks_per_chunk = dw_gemm_units(a);
+  a.units = a.blocks_per_chunk;
+  const dim3 grid((unsigned)(a.n_chunks * a.blocks_per_chunk));
+  if (a.TL == 64) return launch_tl<64>(a, grid, st);
+  if (a.TL == 128) return launch_tl<128>(a, grid, st);
+  if (a.TL == 32) return launch_tl<32>(a, grid, st);
+  return hipErrorInvalidValue;
+}
+
+// 256 x 256 workgroup tiles of all items; also fills mt / nt / unit0
+int dw_gemm_units(DwGemmArgs& a) {
+  int units = 0;
+  for (int k = 0; k < a.n_items; ++k) {
+    DwGemmItem& it = a.it[k];
+    it.mt = (it.Mblk + 7) / 8;
+    it.nt = (it.Kblk + 7) / 8;
+    it.unit0 = units;
+    units += it.mt * it.nt;
+  }
+  return units;
+}
+
+}  // namespace inr

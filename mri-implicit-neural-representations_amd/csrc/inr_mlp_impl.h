@@ -789,6 +789,7 @@ __global__ __launch_bounds__(NW * 64) void inr_mlp_kernel(const NetDesc nd, cons
   float* slab = (MODE != MODE_FWD) ? a.slabs + (size_t)blockIdx.x * nd.slab_floats : nullptr;
   float loss_acc = 0.f;
   bool first = true;
+  const bool dwg = !G2D && a.dw_gemm != 0;  // hidden-width dW by the batch-level GEMM (inr_dw_gemm.hip)
   const LayerDesc& LL = nd.L[D - 1];
   // hidden rows == NB*32 except for WIRE's 181 complex features (362 rows padded to 384); the plan
   // only pairs NB == 12 with that width (inr_api.hip)
@@ -952,16 +953,20 @@ __global__ __launch_bounds__(NW * 64) void inr_mlp_kernel(const NetDesc nd, cons
         bwd_dx<NB, TL, PAIR, true>(gacc, R, a.packed + Ll.pb_off, Ll.Mpad8, sv + (size_t)(NS * l + 1) * HSZ, wcol,
                                    lane);
         INR_STAMP(14 + 4 * l);
-        __syncthreads();
-        INR_STAMP(15 + 4 * l);
-        {
-          BSrcStash<TL> bs{sv + (size_t)(NS * (l - 1)) * HSZ};
-          for (int n = w; n < Ll.Kblk; n += NW)
-            dw_pass<NB, TL, HFULL, BSrcStash<TL>>(lds, RS, bs, n, slab + Ll.gw_off, slab + Ll.gb_off, Ll.M, Ll.K,
-                                                  first, n == 0, lane);
+        if (dwg) {  // dZ_l (this wave's columns) over the act' slot it was formed from: operand of the batch GEMM
+          image_copy<NB, TL, true>(R, sv + (size_t)(NS * l + 1) * HSZ, wcol, lane);
+        } else {
+          __syncthreads();
+          INR_STAMP(15 + 4 * l);
+          {
+            BSrcStash<TL> bs{sv + (size_t)(NS * (l - 1)) * HSZ};
+            for (int n = w; n < Ll.Kblk; n += NW)
+              dw_pass<NB, TL, HFULL, BSrcStash<TL>>(lds, RS, bs, n, slab + Ll.gw_off, slab + Ll.gb_off, Ll.M, Ll.K,
+                                                    first, n == 0, lane);
+          }
+          INR_STAMP(16 + 4 * l);
+          __syncthreads();
         }
-        INR_STAMP(16 + 4 * l);
-        __syncthreads();
         if (G2D) {  // second Linear of the layer: dZ_orth = J_orth dH_l, dH_{l-1} += V_l^T dZ_orth, dV_l
           const LayerDesc& Ol = nd.L[nd.orth0 + l];
           image_copy<NB, TL, false>(R, sv_g, wcol, lane);
@@ -985,14 +990,17 @@ __global__ __launch_bounds__(NW * 64) void inr_mlp_kernel(const NetDesc nd, cons
       // ---- first layer: dW_0 against the stashed encoder features / the input matrix
       {
         const LayerDesc& L0 = nd.L[0];
-        __syncthreads();  // every wave's dZ_0 is in LDS
-        INR_STAMP(40);
-        if (INMODE == IN_GAUSS) {
+        if (INMODE == IN_GAUSS && dwg) {
+          image_copy<NB, TL, true>(R, sv + (size_t)1 * HSZ, wcol, lane);  // dZ_0 -> stash
+        } else if (INMODE == IN_GAUSS) {
+          __syncthreads();  // every wave's dZ_0 is in LDS
+          INR_STAMP(40);
           BSrcStash<TL> bs{sv_enc};
           for (int n = w; n < L0.Kblk; n += NW)
             dw_pass<NB, TL, HFULL, BSrcStash<TL>>(lds, RS, bs, n, slab + L0.gw_off, slab + L0.gb_off, L0.M, L0.K, first,
                                                  n == 0, lane);
         } else {
+          __syncthreads();  // every wave's dZ_0 is in LDS
           BSrcX bs{a.x, row0, a.B, L0.K};
           for (int n = w; n < L0.Kblk; n += NW)
             dw_pass<NB, TL, HFULL, BSrcX>(lds, RS, bs, n, slab + L0.gw_off, slab + L0.gb_off, L0.M, L0.K, first,

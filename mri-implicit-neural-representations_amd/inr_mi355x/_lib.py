@@ -54,6 +54,7 @@ SYMBOLS = {
     "inr_plan_destroy": (C.c_int, [_P]),
     "inr_plan_sizes": (C.c_int, [_P, C.POINTER(Sizes)]),
     "inr_plan_launch_dims": (C.c_int, [_P, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "inr_plan_workspace": (C.c_int, [_P, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "inr_pack_params": (C.c_int, [_P, _P, _P, _P]),
     "inr_encode_gauss": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P]),
     "inr_encode_logf": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P]),

@@ -110,6 +110,12 @@ class MLPEngine:
         L.check(self.lib.inr_plan_launch_dims(self.plan, B, C.byref(nt), C.byref(nb)))
         return int(nt.value), int(nb.value)
 
+    def workspace(self, B: int):
+        """(stash slots a fused step needs, slabs behind ``slabs``) for a batch of B rows."""
+        ss, ns = C.c_int64(), C.c_int64()
+        L.check(self.lib.inr_plan_workspace(self.plan, B, C.byref(ss), C.byref(ns)))
+        return int(ss.value), int(ns.value)
+
     def _stream(self) -> int:
         return torch.cuda.current_stream(self.params.device).cuda_stream
 
@@ -143,8 +149,8 @@ class MLPEngine:
     def backward(self, x: torch.Tensor, enc_B: Optional[torch.Tensor], dout: torch.Tensor) -> torch.Tensor:
         """d(loss)/d(params) for the most recent forward(save=True) on the same x."""
         B = x.shape[0]
-        nt, nb = self.launch_dims(B)
-        slabs = self._ws_slabs(nb)
+        nt, _ = self.launch_dims(B)
+        slabs = self._ws_slabs(self.workspace(B)[1])
         L.check(self.lib.inr_backward(self.plan, _ptr(self.params, "params"), _ptr(self.packed, "packed"),
                                       _ptr(x, "x"), _ptr(enc_B, "enc_B"), B, _ptr(dout, "dout"),
                                       _ptr(self._ws_save(nt), "save"), _ptr(slabs, "slabs"),
@@ -182,12 +188,12 @@ class MLPEngine:
         """Fused encode -> forward -> loss -> backward (stages of train.py:163-189).  Leaves the
         un-reduced-across-ranks gradient in self.grads and returns the loss scalar (device)."""
         B = x.shape[0]
-        _, nb = self.launch_dims(B)
+        slots, n_slabs = self.workspace(B)
         ld = self.loss_desc(spec, B if count is None else count, hdr_A)
         L.check(self.lib.inr_train_step(self.plan, C.byref(ld), _ptr(self.params, "params"),
                                         _ptr(self.packed, "packed"), _ptr(x, "x"), _ptr(enc_B, "enc_B"),
                                         _ptr(gt, "gt"), _ptr(mask, "mask", torch.uint8), B,
-                                        _ptr(self._ws_save(nb), "save"), _ptr(self._ws_slabs(nb), "slabs"),
+                                        _ptr(self._ws_save(slots), "save"), _ptr(self._ws_slabs(n_slabs), "slabs"),
                                         _ptr(self.grads, "grads"), _ptr(self._loss, "loss"), self._stream()))
         return self._loss[0]
 
@@ -298,13 +304,14 @@ class MFNEngine(MLPEngine):
                    dist: Optional[torch.Tensor] = None, scale: float = 1.0,
                    cons: Optional[ConsistencySpec] = None):
         B = coords.shape[0]
-        nt, nb = self.launch_dims(B)
+        _, nb = self.launch_dims(B)
+        slots, n_slabs = self.workspace(B)
         ld = self.multi_loss_desc(spec, B if count is None else count, hdr_A, scale, cons)
         L.check(self.lib.inr_train_step_multi(self.plan, C.byref(ld), _ptr(self.params, "params"),
                                               _ptr(self.packed, "packed"), _ptr(coords, "coords"),
                                               _ptr(enc_B, "enc_B"), _ptr(gt, "gt"), _ptr(dist, "dist"),
                                               _ptr(mask, "mask", torch.uint8), B,
-                                              _ptr(self._ws_save(nt if self.step_save_by_tile else nb), "save"),
-                                              _ptr(self._ws_slabs(nb), "slabs"), _ptr(self.grads, "grads"),
+                                              _ptr(self._ws_save(slots), "save"),
+                                              _ptr(self._ws_slabs(n_slabs), "slabs"), _ptr(self.grads, "grads"),
                                               _ptr(self._loss, "loss"), self._stream()))
         return self._loss[0]

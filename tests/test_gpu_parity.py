@@ -43,7 +43,7 @@ def dev():
 def test_library_is_the_hip_build():
     from inr_mi355x import _lib
     lib = _lib.load()
-    assert lib.inr_abi_version() == 1
+    assert lib.inr_abi_version() == _lib.ABI_VERSION
 
 
 def test_encoder_and_sincos_accuracy(dev):
