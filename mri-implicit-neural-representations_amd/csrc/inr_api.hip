@@ -368,54 +368,62 @@ int inr_plan_destroy(inr_plan* plan) {
   return INR_OK;
 }
 
-// Plans whose hidden-width weight gradients come from inr_dw_gemm.hip instead of in-kernel dW passes: the plain MLP
-// kernels (SIREN / FFN / WIRE, fp32, one wave per coordinate group).  Their fused step stashes per TILE and a second
-// set of slabs (one per K-chunk of the GEMM) follows the fused kernel's n_blocks slabs.
-static bool dw_gemm_plan(const inr_plan* plan) {
-  const NetDesc& nd = plan->nd;
-  if (nd.mfn_n != 0 || nd.bf16 || nd.hact == ACT_GABOR2D || nd.NB != 8) return false;  // 256-row tensors fill the GEMM's tiles
-  return nd.D > 2 || nd.input == IN_GAUSS;  // at least one hidden-width layer with a stashed input
-}
-
-// the 512-wide filter-network kernel does the same with its own GEMM (inr_mfn_wide_impl.h) into the fused slabs
-static bool step_save_by_tile(const inr_plan* plan) {
-  return (plan->nd.mfn_n != 0 && plan->nd.NB == 16) || dw_gemm_plan(plan);
-}
-
-// items, chunking and the flat-gradient range [lo, hi) of the layers the GEMM covers
-static void dw_gemm_setup(const inr_plan* plan, int64_t nt, inr::DwGemmArgs* g, inr::SlabSplit* split) {
+// items, chunking and the flat-gradient range [lo, hi) of the layers the batch-level dW GEMM covers; false: the plan
+// keeps its in-kernel dW passes
+static bool dw_gemm_setup(const inr_plan* plan, int64_t nt, inr::DwGemmArgs* g, inr::SlabSplit* split) {
   const NetDesc& nd = plan->nd;
   memset(g, 0, sizeof(*g));
+  split->lo = split->hi = split->n2 = 0;
+  const bool g2d = nd.hact == ACT_GABOR2D;
+  // the plain MLP kernels, fp32: 256-row tensors (one wave per coordinate group) and the two-waves-per-group shapes
+  if (nd.mfn_n != 0 || nd.bf16) return false;
+  if (!(nd.NB == 8 && !g2d) && nd.NB != 12 && nd.NB != 16) return false;
   const int TL = 32 * nd.NW, HSZ = nd.NB * 32 * TL, D = nd.D;
-  const int NS = nd.hact == ACT_GABOR ? 3 : 2;
+  const int NS = g2d ? 7 : (nd.hact == ACT_GABOR ? 3 : 2);
   g->TL = TL;
+  g->WB = nd.NB == 12 ? 3 : 4;
   g->save_floats_per_tile = nd.save_floats_per_tile;
   g->slab_floats = nd.slab_floats;
   g->n_tiles = (int)nt;
-  int k = 0;
-  if (nd.input == IN_GAUSS) {
+  int k = 0, covered = 0, lo = nd.P, hi = 0;
+  auto add = [&](const LayerDesc& L, int g_off, int h_off) {
     inr::DwGemmItem& it = g->it[k++];
-    it.g_off = 1 * HSZ;
-    it.h_off = NS * (D - 1) * HSZ + 4 * TL;
-    it.gw_off = nd.L[0].gw_off, it.gb_off = nd.L[0].gb_off;
-    it.Mblk = nd.NB, it.Kblk = nd.L[0].Kblk, it.K = nd.L[0].K;
-  }
+    it.g_off = g_off, it.h_off = h_off;
+    it.gw_off = L.gw_off, it.gb_off = L.gb_off;
+    it.Mblk = nd.NB, it.Kblk = L.Kblk, it.K = L.K;
+    covered += L.wn + L.bn;
+    lo = std::min(lo, std::min(L.w_off, L.b_off));
+    hi = std::max(hi, std::max(L.w_off + L.wn, L.b_off + L.bn));
+  };
+  if (2 * D > INR_DWG_MAX_ITEMS) return false;
+  if (nd.input == IN_GAUSS) add(nd.L[0], 1 * HSZ, NS * (D - 1) * HSZ + 4 * TL);  // dZ_0 x encoder features
   for (int l = 1; l <= D - 2; ++l) {
-    inr::DwGemmItem& it = g->it[k++];
-    it.g_off = (NS * l + 1) * HSZ;
-    it.h_off = NS * (l - 1) * HSZ;
-    it.gw_off = nd.L[l].gw_off, it.gb_off = nd.L[l].gb_off;
-    it.Mblk = nd.NB, it.Kblk = nd.L[l].Kblk, it.K = nd.L[l].K;
+    add(nd.L[l], (NS * l + 1) * HSZ, NS * (l - 1) * HSZ);                  // dZ_l x h_{l-1}
+    if (g2d) add(nd.L[nd.orth0 + l], (NS * l + 3) * HSZ, NS * (l - 1) * HSZ);  // WIRE2D: dZ_orth,l x h_{l-1}
   }
+  if (k == 0 || covered != hi - lo) return false;  // the covered layers must be one contiguous flat range
   g->n_items = k;
   // about one workgroup per CU: the accumulators then stay in registers over as many tiles as possible
   const int bpc = inr::dw_gemm_units(*g);
   const int target = std::max(1, 256 / std::max(1, bpc));
   g->tiles_per_chunk = (int)((nt + target - 1) / target);
   g->n_chunks = (int)((nt + g->tiles_per_chunk - 1) / g->tiles_per_chunk);
-  split->lo = nd.L[nd.input == IN_GAUSS ? 0 : 1].w_off;
-  split->hi = nd.L[D - 1].w_off;
+  split->lo = lo;
+  split->hi = hi;
   split->n2 = g->n_chunks;
+  return true;
+}
+
+static bool dw_gemm_plan(const inr_plan* plan) {
+  inr::DwGemmArgs g;
+  inr::SlabSplit split;
+  return dw_gemm_setup(plan, 1, &g, &split);
+}
+
+// fused steps of these plans stash per TILE (n_tiles slots): a batch-level GEMM reads the whole batch's stash.  The
+// 512-wide filter-network kernel has its own GEMM (inr_mfn_wide_impl.h) that writes into the fused kernel's slabs.
+static bool step_save_by_tile(const inr_plan* plan) {
+  return (plan->nd.mfn_n != 0 && plan->nd.NB == 16) || dw_gemm_plan(plan);
 }
 
 int inr_plan_sizes(const inr_plan* plan, inr_sizes* out) {

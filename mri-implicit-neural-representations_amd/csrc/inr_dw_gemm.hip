@@ -21,59 +21,69 @@ namespace inr {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int DWG_LD = 36;                    // LDS row pitch (floats): 16-byte reads of 8 consecutive rows hit 32 distinct banks
-constexpr int DWG_STAGE = 2 * 256 * DWG_LD;   // floats per stage: G tile [256][32] + H tile [256][32]
+constexpr int DWG_LD = 36;  // LDS row pitch (floats): 16-byte reads of 8 consecutive rows hit 32 distinct banks
+// WB: 32-row blocks per wave tile side (4: 128 x 128 per wave, 256 x 256 per workgroup; 3: 96 / 192 for the 384-row
+// WIRE shape).  A stage holds the G tile [64 WB][32] and the H tile [64 WB][32].
+template <int WB>
+constexpr int dwg_stage() { return 2 * 64 * WB * DWG_LD; }
 
-template <bool BIAS>
-__device__ __forceinline__ void dwg_mma(f32x16 (&acc)[4][4], float (&bsum)[4], const f32x4 (&A)[4],
-                                        const f32x4 (&B)[4]) {
+template <int WB, bool BIAS>
+__device__ __forceinline__ void dwg_mma(f32x16 (&acc)[WB][WB], float (&bsum)[WB], const f32x4 (&A)[WB],
+                                        const f32x4 (&B)[WB]) {
 #pragma unroll
   for (int e = 0; e < 4; ++e)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < WB; ++i) {
       if (BIAS) bsum[i] += A[i][e];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < WB; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[i][e], B[j][e], acc[i][j], 0, 0, 0);
     }
 }
 
-// one K-step (32 coordinates) of a workgroup's operands: 512 rows x 128 B, thread t fetches 16-byte segment t & 7 of
-// rows (t >> 3) + 32 k -- whole cache lines per 8 lanes
-__device__ __forceinline__ void dwg_fetch(f32x4 (&v)[16], const float* __restrict__ sv, const int (&roff)[16],
+// one K-step (32 coordinates) of a workgroup's operands: 128 WB rows x 128 B, thread t fetches 16-byte segment t & 7
+// of rows (t >> 3) + 32 k -- whole cache lines per 8 lanes
+template <int NF>
+__device__ __forceinline__ void dwg_fetch(f32x4 (&v)[NF], const float* __restrict__ sv, const int (&roff)[NF],
                                           int kstep) {
 #pragma unroll
-  for (int k = 0; k < 16; ++k) v[k] = *reinterpret_cast<const f32x4*>(sv + roff[k] + 32 * kstep);
+  for (int k = 0; k < NF; ++k) v[k] = *reinterpret_cast<const f32x4*>(sv + roff[k] + 32 * kstep);
 }
 
-__device__ __forceinline__ void dwg_stash(float* buf, const f32x4 (&v)[16], int t) {
+template <int NF>
+__device__ __forceinline__ void dwg_stash(float* buf, const f32x4 (&v)[NF], int t) {
   float* p = buf + (t >> 3) * DWG_LD + (t & 7) * 4;
 #pragma unroll
-  for (int k = 0; k < 16; ++k) *reinterpret_cast<f32x4*>(p + k * 32 * DWG_LD) = v[k];
+  for (int k = 0; k < NF; ++k) *reinterpret_cast<f32x4*>(p + k * 32 * DWG_LD) = v[k];
 }
 
-// Workgroup = a 256 x 256 block of one item's dW over one chunk of tiles; waves 2 x 2, 128 x 128 each.
-template <int TL, bool BIAS>
+// Workgroup = a (64 WB) x (64 WB) block of one item's dW over one chunk of tiles; waves 2 x 2, (32 WB)^2 each.
+template <int TL, int WB, bool BIAS>
 __device__ __forceinline__ void dwg_body(const DwGemmArgs& a, const DwGemmItem& it, int kc, int mb0, int nb0,
                                          float* lds) {
+  constexpr int NF = 4 * WB;         // 16-byte fetches per thread and stage
+  constexpr int TR = 64 * WB;        // rows of one operand tile
+  constexpr int DWG_STAGE = dwg_stage<WB>();
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int half = lane >> 5, li = lane & 31;
   const int wm = w >> 1, wn = w & 1;
-  f32x16 acc[4][4];
-  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+  f32x16 acc[WB][WB];
+  float bsum[WB];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < WB; ++i) {
+    bsum[i] = 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < WB; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  // global row of each of this thread's 16 fetches (rows past a tensor's extent: row 0, never stored)
-  int roff[16];
+  }
+  // global row of each of this thread's fetches (rows past a tensor's extent: row 0, never stored)
+  int roff[NF];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    const int r = (t >> 3) + 32 * k;  // 0..255: G rows, 256..511: H rows
-    const bool isg = r < 256;
-    const int blk = isg ? mb0 + (r >> 5) : nb0 + ((r - 256) >> 5);
+  for (int k = 0; k < NF; ++k) {
+    const int r = (t >> 3) + 32 * k;  // [0, TR): G rows, [TR, 2 TR): H rows
+    const bool isg = r < TR;
+    const int blk = isg ? mb0 + (r >> 5) : nb0 + ((r - TR) >> 5);
     const int row = (blk < (isg ? it.Mblk : it.Kblk)) ? blk * 32 + (r & 31) : 0;
     roff[k] = (isg ? it.g_off : it.h_off) + row * TL + (t & 7) * 4;
   }
@@ -81,9 +91,9 @@ __device__ __forceinline__ void dwg_body(const DwGemmArgs& a, const DwGemmItem& 
   const int t0 = kc * a.tiles_per_chunk;
   const int t1 = (t0 + a.tiles_per_chunk < a.n_tiles) ? t0 + a.tiles_per_chunk : a.n_tiles;
   const int n_steps = (t1 - t0) * KS;
-  const float* As = lds + (wm * 128 + li) * DWG_LD + 4 * half;
-  const float* Bs = lds + (256 + wn * 128 + li) * DWG_LD + 4 * half;
-  f32x4 v[16];
+  const float* As = lds + (wm * 32 * WB + li) * DWG_LD + 4 * half;
+  const float* Bs = lds + (TR + wn * 32 * WB + li) * DWG_LD + 4 * half;
+  f32x4 v[NF];
   dwg_fetch(v, a.save + (size_t)t0 * a.save_floats_per_tile, roff, 0);
   dwg_stash(lds, v, t);
   __syncthreads();
@@ -96,23 +106,23 @@ __device__ __forceinline__ void dwg_body(const DwGemmArgs& a, const DwGemmItem& 
     const float* Bb = Bs + (s & 1) * DWG_STAGE;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      f32x4 A[4], B[4];
+      f32x4 A[WB], B[WB];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) A[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * DWG_LD + 8 * q);
+      for (int i = 0; i < WB; ++i) A[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * DWG_LD + 8 * q);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) B[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * DWG_LD + 8 * q);
-      dwg_mma<BIAS>(acc, bsum, A, B);
+      for (int j = 0; j < WB; ++j) B[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * DWG_LD + 8 * q);
+      dwg_mma<WB, BIAS>(acc, bsum, A, B);
     }
     if (sn < n_steps) dwg_stash(lds + (sn & 1) * DWG_STAGE, v, t);
     __syncthreads();
   }
   float* slab = a.slabs + (size_t)kc * a.slab_floats;
-  const int mb = mb0 + 4 * wm, nb = nb0 + 4 * wn;
+  const int mb = mb0 + WB * wm, nb = nb0 + WB * wn;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < WB; ++i) {
     if (mb + i >= it.Mblk) continue;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < WB; ++j) {
       const int colj = 32 * (nb + j) + li;
       if (colj < it.K) {
 #pragma unroll
@@ -129,7 +139,7 @@ __device__ __forceinline__ void dwg_body(const DwGemmArgs& a, const DwGemmItem& 
   }
 }
 
-template <int TL>
+template <int TL, int WB>
 __global__ __launch_bounds__(256) void dw_gemm_kernel(const DwGemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int kc = blockIdx.x / a.blocks_per_chunk;
@@ -140,15 +150,15 @@ __global__ __launch_bounds__(256) void dw_gemm_kernel(const DwGemmArgs a) {
   const int u = unit - it.unit0;
   const int mi = u / it.nt, ni = u % it.nt;
   if (ni == 0)
-    dwg_body<TL, true>(a, it, kc, 8 * mi, 0, lds);
+    dwg_body<TL, WB, true>(a, it, kc, 2 * WB * mi, 0, lds);
   else
-    dwg_body<TL, false>(a, it, kc, 8 * mi, 8 * ni, lds);
+    dwg_body<TL, WB, false>(a, it, kc, 2 * WB * mi, 2 * WB * ni, lds);
 }
 
-template <int TL>
+template <int TL, int WB>
 static hipError_t launch_tl(const DwGemmArgs& a, dim3 grid, hipStream_t st) {
-  constexpr size_t lds_bytes = (size_t)2 * DWG_STAGE * sizeof(float);  // 147 KB: two stages
-  auto k = dw_gemm_kernel<TL>;
+  constexpr size_t lds_bytes = (size_t)2 * dwg_stage<WB>() * sizeof(float);  // two stages (WB = 4: 147 KB)
+  auto k = dw_gemm_kernel<TL, WB>;
   static thread_local bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -166,19 +176,19 @@ hipError_t launch_dw_gemm(DwGemmArgs& a, hipStream_t st) {
   a.blocks_per_chunk = dw_gemm_units(a);
   a.units = a.blocks_per_chunk;
   const dim3 grid((unsigned)(a.n_chunks * a.blocks_per_chunk));
-  if (a.TL == 64) return launch_tl<64>(a, grid, st);
-  if (a.TL == 128) return launch_tl<128>(a, grid, st);
-  if (a.TL == 32) return launch_tl<32>(a, grid, st);
+  if (a.TL == 128 && a.WB == 4) return launch_tl<128, 4>(a, grid, st);
+  if (a.TL == 64 && a.WB == 4) return launch_tl<64, 4>(a, grid, st);
+  if (a.TL == 64 && a.WB == 3) return launch_tl<64, 3>(a, grid, st);
   return hipErrorInvalidValue;
 }
 
-// 256 x 256 workgroup tiles of all items; also fills mt / nt / unit0
+// number of (64 WB)^2 workgroup tiles of all items; also fills mt / nt / unit0
 int dw_gemm_units(DwGemmArgs& a) {
   int units = 0;
   for (int k = 0; k < a.n_items; ++k) {
     DwGemmItem& it = a.it[k];
-    it.mt = (it.Mblk + 7) / 8;
-    it.nt = (it.Kblk + 7) / 8;
+    it.mt = (it.Mblk + 2 * a.WB - 1) / (2 * a.WB);
+    it.nt = (it.Kblk + 2 * a.WB - 1) / (2 * a.WB);
     it.unit0 = units;
     units += it.mt * it.nt;
   }

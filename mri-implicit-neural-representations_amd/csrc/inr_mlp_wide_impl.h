@@ -116,6 +116,7 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
   float* slab = (MODE != MODE_FWD) ? a.slabs + (size_t)blockIdx.x * nd.slab_floats : nullptr;
   float loss_acc = 0.f;
   bool first = true;
+  const bool dwg = a.dw_gemm != 0;  // hidden-width dW by the batch-level GEMM (inr_dw_gemm.hip)
   const LayerDesc& LL = nd.L[D - 1];
   const size_t aoff = (size_t)m0 * 256;
 
@@ -292,7 +293,9 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
 #pragma unroll
         for (int m = 0; m < MT; ++m) gacc[m] = zero16();
         bwd_dx<MT, TL, false, false, NB>(gacc, R, a.packed + Ll.pb_off + aoff, Ll.Mpad8, nullptr, wcol, lane);
-        {
+        if (dwg) {  // own rows of dZ_l over the act' slot they were formed from: operand of the batch GEMM
+          rows_copy<TL, RH, true>(R, sv + (size_t)(NS * l + 1) * HSZ, RH * hh, wcol, lane);
+        } else {
           BSrcStash<TL> bs{sv + (size_t)(NS * (l - 1)) * HSZ};
           for (int it = w; it < 2 * Ll.Kblk; it += NW) {  // (column block, row half) items over the four waves
             const int n = it >> 1, c = it & 1;
@@ -308,12 +311,16 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
           rows_times<TL, RH, true>(R, sv + (size_t)(NS * l + 3) * HSZ, sv + (size_t)(NS * l + 4) * HSZ, RH * hh, wcol, lane);
           __syncthreads();
           bwd_dx<MT, TL, false, false, NB>(gacc, R, a.packed + Ol.pb_off + aoff, Ol.Mpad8, nullptr, wcol, lane);
-          BSrcStash<TL> bs{sv + (size_t)(NS * (l - 1)) * HSZ};
-          for (int it = w; it < 2 * Ol.Kblk; it += NW) {
-            const int n = it >> 1, c = it & 1;
-            dw_pass<MT, TL, true, BSrcStash<TL>>(lds + c * MT * 32 * INR_LDS_LD, RS, bs, n,
-                                                 slab + Ol.gw_off + (size_t)c * RH * Ol.K, slab + Ol.gb_off + c * RH,
-                                                 Ol.M, Ol.K, first, n == 0, lane);
+          if (dwg) {
+            rows_copy<TL, RH, true>(R, sv + (size_t)(NS * l + 3) * HSZ, RH * hh, wcol, lane);  // dZ_orth (own rows)
+          } else {
+            BSrcStash<TL> bs{sv + (size_t)(NS * (l - 1)) * HSZ};
+            for (int it = w; it < 2 * Ol.Kblk; it += NW) {
+              const int n = it >> 1, c = it & 1;
+              dw_pass<MT, TL, true, BSrcStash<TL>>(lds + c * MT * 32 * INR_LDS_LD, RS, bs, n,
+                                                   slab + Ol.gw_off + (size_t)c * RH * Ol.K, slab + Ol.gb_off + c * RH,
+                                                   Ol.M, Ol.K, first, n == 0, lane);
+            }
           }
           __syncthreads();
         }
@@ -326,7 +333,9 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
       {
         const LayerDesc& L0 = nd.L[0];
         __syncthreads();  // dZ_0 complete
-        if (INMODE == IN_GAUSS) {
+        if (INMODE == IN_GAUSS && dwg) {
+          rows_copy<TL, RH, true>(R, sv + (size_t)1 * HSZ, RH * hh, wcol, lane);  // dZ_0 (own rows)
+        } else if (INMODE == IN_GAUSS) {
           BSrcStash<TL> bs{sv_enc};
           for (int it = w; it < 2 * L0.Kblk; it += NW) {
             const int n = it >> 1, c = it & 1;
