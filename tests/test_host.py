@@ -44,6 +44,23 @@ def test_plan_validation_and_sizes():
     assert (nt.value, nb.value) == (512, 256)
     assert lib.inr_plan_launch_dims(plan, 0, C.byref(nt), C.byref(nb)) < 0
     assert "B = 0" in L.last_error()
+    # workspace of a step: this plan's weight gradients come from the batch GEMM -> per-tile stash, chunk slabs
+    slots, slabs = C.c_int64(), C.c_int64()
+    assert sz.step_save_by_tile == 1
+    assert lib.inr_plan_workspace(plan, 25000, C.byref(slots), C.byref(slabs)) == 0
+    assert (slots.value, slabs.value) == (196, 196 + 49)  # 5 workgroup tiles per chunk -> 51 chunks of 4 tiles wanted -> 49
+    assert lib.inr_plan_workspace(plan, 65536, C.byref(slots), C.byref(slabs)) == 0
+    assert slots.value == 512 and 256 < slabs.value <= 256 + 52
+    assert lib.inr_plan_workspace(plan, 100, C.byref(slots), C.byref(slabs)) == 0
+    assert (slots.value, slabs.value) == (1, 2)
+    assert lib.inr_plan_workspace(plan, 0, C.byref(slots), C.byref(slabs)) < 0
+    lib.inr_plan_destroy(plan)
+    small = L.NetDesc(kind=L.KIND_SIREN, in_features=16, width=32, depth=4, out_features=2, last_act=L.ACT_TANH,
+                      input=L.INPUT_GAUSS, enc_size=8, w0=30.0)  # narrow nets keep their in-kernel dW passes
+    assert lib.inr_plan_create(C.byref(small), C.byref(plan)) == 0
+    assert lib.inr_plan_sizes(plan, C.byref(sz)) == 0 and sz.step_save_by_tile == 0
+    assert lib.inr_plan_workspace(plan, 65536, C.byref(slots), C.byref(slabs)) == 0
+    assert (slots.value, slabs.value) == (256, 256)
     lib.inr_plan_destroy(plan)
     for bad, frag in ((dict(width=513), "width"), (dict(width=0), "width"), (dict(depth=1), "depth"), (dict(out_features=9), "out_features"),
                       (dict(in_features=500), "2*enc_size"), (dict(kind=99), "kind")):
