@@ -87,6 +87,41 @@ def test_mlp_widths(dev, model, width):
     assert rel_l2(out2, q64[0]) <= max(10 * rel_l2(q32[0], q64[0]), 2e-5)
 
 
+@pytest.mark.parametrize("depth", [2, 3, 7])
+@pytest.mark.parametrize("model,width", [("SIREN", 256), ("FFN", 230), ("SIREN", 512)])
+def test_batch_dw_gemm_depths(dev, model, width, depth):
+    """The widths whose weight gradients come from the batch GEMM (inr_dw_gemm.hip), at depths that change its item
+    list: depth 2 = first layer only (fused gauss encoder) or nothing at all (materialised input: in-kernel passes),
+    3 = one hidden layer, 7 = five; four tiles = four K-chunks.  Fused step and forward/backward pair."""
+    import inr_mi355x as M
+    from inr_mi355x import _lib as L
+    net = dict(network_input_size=64, network_output_size=2, network_depth=depth, network_width=width)
+    enc_cfg = dict(embedding="gauss", scale=2, embedding_size=32, coordinates_size=3)
+    torch.manual_seed(depth)
+    enc = M.Positional_Encoder(enc_cfg, device=dev)
+    mdl = getattr(M, model)(net)
+    sd = {k: v.clone() for k, v in mdl.state_dict().items()}
+    mdl = mdl.to(dev)
+    B = 391
+    g = torch.Generator().manual_seed(depth)
+    coords = torch.rand(B, 3, generator=g) * 2 - 1
+    gt = torch.rand(B, 2, generator=g) * 0.5
+    r32 = _ref(model, sd, net, coords, enc.B.cpu(), gt, torch.float32)
+    r64 = _ref(model, sd, net, coords, enc.B.cpu(), gt, torch.float64)
+    eng = mdl.fused_engine(32)
+    assert eng.step_save_by_tile
+    out = eng.forward(coords.to(dev), enc.B.contiguous(), save=False).cpu()[None]
+    loss = eng.train_step(coords.to(dev), enc.B.contiguous(), gt.to(dev), M.LossSpec(L.LOSS_L2_HALF))
+    _check(out, loss, eng.grads.cpu(), r32, r64)
+    g_first = eng.grads.clone()
+    eng.train_step(coords.to(dev), enc.B.contiguous(), gt.to(dev), M.LossSpec(L.LOSS_L2_HALF))
+    assert torch.equal(eng.grads, g_first)  # chunk partials are summed in a fixed order
+    o1 = mdl(enc.embedding(coords.to(dev)))  # tier 1: materialised encoding, separate forward / backward kernels
+    (0.5 * torch.nn.functional.mse_loss(o1, gt.to(dev))).backward()
+    g1 = torch.cat([p.grad.reshape(-1) for p in mdl.parameters()]).cpu()
+    _check(o1.detach().cpu()[None], loss, g1, r32, r64)
+
+
 @pytest.mark.parametrize("width", [24, 64, 90, 128, 200])
 def test_wire_widths(dev, width):
     """network_width -> int(width/sqrt 2) complex features (networks.py:228): 16, 45, 63, 90, 141."""
