@@ -374,9 +374,39 @@ static bool dw_gemm_setup(const inr_plan* plan, int64_t nt, inr::DwGemmArgs* g, 
   const NetDesc& nd = plan->nd;
   memset(g, 0, sizeof(*g));
   split->lo = split->hi = split->n2 = 0;
+  split->mask = 0;
   const bool g2d = nd.hact == ACT_GABOR2D;
+  if (nd.bf16) return false;
+  if (nd.mfn_n != 0) {
+    // 512-wide filter networks (inr_mfn_wide_impl.h):  F_t: g_u_t (stash slot 3t+1) x encoder features, t < S;
+    // L_{i-1}: g_l_i (slot 3i) x h_{i-1} (slot 3(i-1)+2), 1 <= i < S.  Their flat ranges interleave with heads and
+    // Gabor centres, so the reduction learns the covered layers as a bit mask.
+    if (nd.NB != 16) return false;
+    const int S = nd.mfn_stages, n = nd.mfn_n, HSZ = 16 * 32 * 64;
+    if (2 * S - 1 > INR_DWG_MAX_ITEMS) return false;
+    g->TL = 64, g->WB = 4;
+    g->save_floats_per_tile = nd.save_floats_per_tile, g->slab_floats = nd.slab_floats, g->n_tiles = (int)nt;
+    int k = 0;
+    unsigned mask = 0;
+    for (int t = 0; t < 2 * S - 1; ++t) {
+      const int i = t - S + 1, l = t < S ? t : n + 1 + (i - 1);
+      const LayerDesc& L = nd.L[l];
+      inr::DwGemmItem& it = g->it[k++];
+      it.g_off = t < S ? (3 * t + 1) * HSZ : (3 * i) * HSZ;
+      it.h_off = t < S ? 3 * S * HSZ : (3 * (i - 1) + 2) * HSZ;
+      it.gw_off = L.gw_off, it.gb_off = L.gb_off, it.Mblk = 16, it.Kblk = L.Kblk, it.K = L.K;
+      mask |= 1u << l;
+    }
+    g->n_items = k;
+    const int bpc = inr::dw_gemm_units(*g);
+    const int target = std::max(1, 256 / std::max(1, bpc));
+    g->tiles_per_chunk = (int)((nt + target - 1) / target);
+    g->n_chunks = (int)((nt + g->tiles_per_chunk - 1) / g->tiles_per_chunk);
+    split->mask = mask;
+    split->n2 = g->n_chunks;
+    return true;
+  }
   // the plain MLP kernels, fp32: 256-row tensors (one wave per coordinate group) and the two-waves-per-group shapes
-  if (nd.mfn_n != 0 || nd.bf16) return false;
   if (!(nd.NB == 8 && !g2d) && nd.NB != 12 && nd.NB != 16) return false;
   const int TL = 32 * nd.NW, HSZ = nd.NB * 32 * TL, D = nd.D;
   const int NS = g2d ? 7 : (nd.hact == ACT_GABOR ? 3 : 2);
@@ -420,11 +450,8 @@ static bool dw_gemm_plan(const inr_plan* plan) {
   return dw_gemm_setup(plan, 1, &g, &split);
 }
 
-// fused steps of these plans stash per TILE (n_tiles slots): a batch-level GEMM reads the whole batch's stash.  The
-// 512-wide filter-network kernel has its own GEMM (inr_mfn_wide_impl.h) that writes into the fused kernel's slabs.
-static bool step_save_by_tile(const inr_plan* plan) {
-  return (plan->nd.mfn_n != 0 && plan->nd.NB == 16) || dw_gemm_plan(plan);
-}
+// fused steps of these plans stash per TILE (n_tiles slots): a batch-level GEMM reads the whole batch's stash
+static bool step_save_by_tile(const inr_plan* plan) { return dw_gemm_plan(plan); }
 
 int inr_plan_sizes(const inr_plan* plan, inr_sizes* out) {
   if (plan == nullptr || out == nullptr) return fail(INR_ERR_INVALID, "inr_plan_sizes: null argument");
@@ -565,7 +592,7 @@ int inr_forward(const inr_plan* plan, const float* params, const float* packed, 
 static int finish_gradients(const inr_plan* plan, const inr::MlpArgs& a, int64_t nt, int64_t nb, float* grads,
                             float* loss_out, const float* params, const float* packed, hipStream_t st,
                             const char* who) {
-  inr::SlabSplit split{0, 0, 0};
+  inr::SlabSplit split{0, 0, 0, 0};
   if (a.dw_gemm) {
     inr::DwGemmArgs g;
     dw_gemm_setup(plan, nt, &g, &split);
@@ -781,12 +808,10 @@ int inr_backward_multi(const inr_plan* plan, const float* params, const float* p
   a.save_by_block = 0;
   LossDesc ld;
   memset(&ld, 0, sizeof(ld));
+  a.dw_gemm = dw_gemm_plan(plan) ? 1 : 0;
   int rc = launch(plan, ld, a, 1, (int)nb, (hipStream_t)stream);
   if (rc != INR_OK) return rc;
-  hipError_t e = inr::launch_reduce_slabs(plan->nd, slabs, (int)nb, grads, nullptr, params, packed,
-                                          (hipStream_t)stream);
-  if (e != hipSuccess) return hip_fail(e, "inr_backward_multi: slab reduction");
-  return INR_OK;
+  return finish_gradients(plan, a, nt, nb, grads, nullptr, params, packed, (hipStream_t)stream, "inr_backward_multi");
 }
 
 int inr_train_step_multi(const inr_plan* plan, const inr_loss_desc* loss, const float* params, const float* packed,
@@ -817,16 +842,15 @@ int inr_train_step_multi(const inr_plan* plan, const inr_loss_desc* loss, const 
   a.slabs = slabs;
   a.B = B;
   a.n_tiles = (int)nt;
-  a.save_by_block = step_save_by_tile(plan) ? 0 : 1;
+  a.dw_gemm = dw_gemm_plan(plan) ? 1 : 0;
+  a.save_by_block = a.dw_gemm ? 0 : 1;
   LossDesc ld;
   to_loss_desc(loss, &ld);
   int rc = launch(plan, ld, a, 2, (int)nb, (hipStream_t)stream);
   if (rc != INR_OK) return rc;
   if (grads == nullptr) return INR_OK;
-  hipError_t e = inr::launch_reduce_slabs(plan->nd, slabs, (int)nb, grads, loss_out, params, packed,
-                                          (hipStream_t)stream);
-  if (e != hipSuccess) return hip_fail(e, "inr_train_step_multi: slab reduction");
-  return INR_OK;
+  return finish_gradients(plan, a, nt, nb, grads, loss_out, params, packed, (hipStream_t)stream,
+                          "inr_train_step_multi");
 }
 
 int inr_adam_step(const inr_plan* plan, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,

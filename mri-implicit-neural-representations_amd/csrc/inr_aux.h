@@ -17,14 +17,16 @@ struct AdamArgs {
 };
 
 
-// flat gradient entries [lo, hi) are summed over the n2 slabs that FOLLOW the n_blocks slabs of the fused kernel
-// (partial sums of the batch-level weight-gradient GEMM); n2 == 0: one slab set
+// entries of the layers in `mask` (bit l = L[l]) and the flat gradient entries [lo, hi) are summed over the n2 slabs
+// that FOLLOW the n_blocks slabs of the fused kernel (partial sums of the batch-level weight-gradient GEMM);
+// n2 == 0: one slab set
 struct SlabSplit {
   int lo, hi, n2;
+  unsigned mask;
 };
 hipError_t launch_reduce_slabs(const NetDesc& nd, const float* slabs, int n_blocks, float* grads, float* loss_out,
                                const float* params, const float* packed, hipStream_t st,
-                               SlabSplit split = SlabSplit{0, 0, 0});
+                               SlabSplit split = SlabSplit{0, 0, 0, 0});
 hipError_t launch_adam_pack(const NetDesc& nd, float* params, const float* grads, float* m1, float* m2,
                             float* packed, const AdamArgs& aa, hipStream_t st);
 hipError_t launch_encode_logf(const float* coords, const float* bands, long long B, int nb, float* out,

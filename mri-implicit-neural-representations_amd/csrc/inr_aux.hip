@@ -83,55 +83,49 @@ __device__ __forceinline__ void loss_words_sum(const float* __restrict__ slabs, 
 // grads[i] = sum over blocks (in block order: deterministic) of the slab entries that flat
 // element i owns; the loss word is summed by thread 0.
 // ---------------------------------------------------------------------------------------------
+// sum of n slab entries `stride` floats apart, 16 independent loads in flight, added in slab order
+__device__ __forceinline__ float slab_sum(const float* __restrict__ p, size_t stride, int n) {
+  float s = 0.f;
+  int b = 0;
+  for (; b + 16 <= n; b += 16) {
+    float v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = p[(size_t)(b + k) * stride];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += v[k];
+  }
+  for (; b < n; ++b) s += p[(size_t)b * stride];
+  return s;
+}
+
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const NetDesc nd, const float* __restrict__ slabs_all,
                                                            int n_blocks_all, float* __restrict__ grads,
                                                            float* __restrict__ loss_out, SlabSplit split) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  const int sf = nd.slab_floats;
-  const bool second = split.n2 > 0 && i >= split.lo && i < split.hi;
-  const float* __restrict__ slabs = second ? slabs_all + (size_t)n_blocks_all * sf : slabs_all;
-  const int n_blocks = second ? split.n2 : n_blocks_all;
+  const size_t sf = (size_t)nd.slab_floats;
   if (i < nd.P) {
     int l;
     VirtualPos vp;
     float s = 0.f;
     if (locate(nd, i, l, vp) && nd.L[l].live != 0) {  // dead layers: slab region never written -> 0
       const LayerDesc& L = nd.L[l];
+      const bool second = split.n2 > 0 && ((((split.mask >> l) & 1u) != 0) || (i >= split.lo && i < split.hi));
+      const float* __restrict__ slabs = second ? slabs_all + (size_t)n_blocks_all * sf : slabs_all;
+      const int n_blocks = second ? split.n2 : n_blocks_all;
       if (vp.n >= 1) {
         const size_t o0 = (size_t)L.gw_off + (size_t)vp.row[0] * L.K + vp.col[0];
-        if (vp.n == 1) {
-          int b = 0;
-          for (; b + 4 <= n_blocks; b += 4) {
-            const float v0 = slabs[(size_t)(b + 0) * sf + o0], v1 = slabs[(size_t)(b + 1) * sf + o0];
-            const float v2 = slabs[(size_t)(b + 2) * sf + o0], v3 = slabs[(size_t)(b + 3) * sf + o0];
-            s = (((s + v0) + v1) + v2) + v3;
-          }
-          for (; b < n_blocks; ++b) s += slabs[(size_t)b * sf + o0];
-          s *= vp.sign[0];
-        } else {
+        s = vp.sign[0] * slab_sum(slabs + o0, sf, n_blocks);
+        if (vp.n == 2) {
           const size_t o1 = (size_t)L.gw_off + (size_t)vp.row[1] * L.K + vp.col[1];
-          int b = 0;
-          for (; b + 4 <= n_blocks; b += 4) {  // 8 independent loads in flight; fixed summation order
-            float u[4], v[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              u[k] = slabs[(size_t)(b + k) * sf + o0];
-              v[k] = slabs[(size_t)(b + k) * sf + o1];
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) s += vp.sign[0] * u[k] + vp.sign[1] * v[k];
-          }
-          for (; b < n_blocks; ++b)
-            s += vp.sign[0] * slabs[(size_t)b * sf + o0] + vp.sign[1] * slabs[(size_t)b * sf + o1];
+          s += vp.sign[1] * slab_sum(slabs + o1, sf, n_blocks);
         }
       } else if (vp.bias_row >= 0) {
-        const size_t o0 = (size_t)L.gb_off + vp.bias_row;
-        for (int b = 0; b < n_blocks; ++b) s += slabs[(size_t)b * sf + o0];
+        s = slab_sum(slabs + (size_t)L.gb_off + vp.bias_row, sf, n_blocks);
       }
     }
     grads[i] = s;
   }
-  if (loss_out != nullptr && blockIdx.x == gridDim.x - 1) loss_words_sum(slabs_all, n_blocks_all, (size_t)sf, nd.slab_loss_off, loss_out);
+  if (loss_out != nullptr && blockIdx.x == gridDim.x - 1) loss_words_sum(slabs_all, n_blocks_all, sf, nd.slab_loss_off, loss_out);
 }
 
 // Fast path when a slab has the flat-parameter layout (every layer LT_REAL).  A workgroup owns 256
@@ -276,7 +270,7 @@ __global__ __launch_bounds__(256) void reduce_slabs_bf16_any_kernel(const NetDes
 
 hipError_t launch_reduce_slabs(const NetDesc& nd, const float* slabs, int n_blocks, float* grads, float* loss_out,
                                const float* params, const float* packed, hipStream_t st, SlabSplit split) {
-  if (split.n2 > 0 && (nd.bf16 || nd.gabor)) return hipErrorInvalidValue;
+  if (split.n2 > 0 && nd.bf16) return hipErrorInvalidValue;
   if (nd.bf16) {
     bool same = true;  // slab element offsets == flat offsets (hidden width = whole row blocks, e.g. 256)
     for (int l = 0; l < nd.ND; ++l) same = same && nd.L[l].gw_off == nd.L[l].w_off && nd.L[l].gb_off == nd.L[l].b_off;
@@ -293,7 +287,7 @@ hipError_t launch_reduce_slabs(const NetDesc& nd, const float* slabs, int n_bloc
   }
   bool all_real = true;  // ... and slab layout == flat layout (not the case for MFN: L[] order != flat order)
   for (int l = 0; l < nd.ND; ++l) all_real = all_real && nd.L[l].ltype == LT_REAL && nd.L[l].gw_off == nd.L[l].w_off;
-  if (all_real && ((split.lo | split.hi) & 3) == 0) {  // slab offsets == flat offsets; slab_floats % 64 == 0 keeps every slab 16-byte aligned
+  if (all_real && ((split.lo | split.hi) & 3) == 0 && split.mask == 0) {  // slab offsets == flat offsets; slab_floats % 64 == 0 keeps every slab 16-byte aligned
     const int grid = (nd.P + 255) / 256;
     hipLaunchKernelGGL(reduce_slabs_real_kernel, dim3(grid + 1), dim3(256), 0, st, slabs, n_blocks, nd.slab_floats, nd.P,
                        nd.slab_loss_off, grads, loss_out, split);

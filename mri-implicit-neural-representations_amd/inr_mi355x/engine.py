@@ -269,7 +269,8 @@ class MFNEngine(MLPEngine):
         L.check(self.lib.inr_backward_multi(self.plan, _ptr(self.params, "params"), _ptr(self.packed, "packed"),
                                             _ptr(coords, "coords"), _ptr(enc_B, "enc_B"), _ptr(dist, "dist"), B,
                                             _ptr(dout, "dout"),
-                                            _ptr(self._ws_save(nt), "save"), _ptr(self._ws_slabs(nb), "slabs"),
+                                            _ptr(self._ws_save(nt), "save"),
+                                            _ptr(self._ws_slabs(self.workspace(B)[1]), "slabs"),
                                             _ptr(self.grads, "grads"), self._stream()))
         return self.grads
 
