@@ -789,7 +789,11 @@ __global__ __launch_bounds__(NW * 64) void inr_mlp_kernel(const NetDesc nd, cons
   float* slab = (MODE != MODE_FWD) ? a.slabs + (size_t)blockIdx.x * nd.slab_floats : nullptr;
   float loss_acc = 0.f;
   bool first = true;
+#ifdef INR_DWG_STATIC  // 256-row builds: hidden-width dW ALWAYS comes from the batch-level GEMM (launch_mlp checks)
+  constexpr bool dwg = !G2D;
+#else
   const bool dwg = !G2D && a.dw_gemm != 0;  // hidden-width dW by the batch-level GEMM (inr_dw_gemm.hip)
+#endif
   const LayerDesc& LL = nd.L[D - 1];
   // hidden rows == NB*32 except for WIRE's 181 complex features (362 rows padded to 384); the plan
   // only pairs NB == 12 with that width (inr_api.hip)
@@ -1047,6 +1051,10 @@ inline hipError_t launch_mlp(const NetDesc& nd, const LossDesc& ld, const MlpArg
   auto k = inr_mlp_kernel<NB, NW, INMODE, HACT, MODE>;
   static thread_local bool attr_set = false;
   if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
+#ifdef INR_DWG_STATIC  // the kernel has no in-kernel dW passes for layers the GEMM can take: the caller must run it
+  if (MODE != MODE_FWD && HACT != ACT_GABOR2D && !a.dw_gemm && (nd.D > 2 || INMODE == IN_GAUSS))
+    return hipErrorInvalidValue;
+#endif
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        160 * 1024);
