@@ -4,7 +4,7 @@
 
 namespace inr {
 
-#define INR_DWG_MAX_ITEMS 16
+#define INR_DWG_MAX_ITEMS 32
 
 struct DwGemmItem {
   int g_off, h_off;    // floats from the start of a tile's stash to dZ_l [Mblk*32][TL] and h_{l-1} [Kblk*32][TL]

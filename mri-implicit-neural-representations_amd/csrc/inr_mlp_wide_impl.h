@@ -116,7 +116,6 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
   float* slab = (MODE != MODE_FWD) ? a.slabs + (size_t)blockIdx.x * nd.slab_floats : nullptr;
   float loss_acc = 0.f;
   bool first = true;
-  const bool dwg = a.dw_gemm != 0;  // hidden-width dW by the batch-level GEMM (inr_dw_gemm.hip)
   const LayerDesc& LL = nd.L[D - 1];
   const size_t aoff = (size_t)m0 * 256;
 
@@ -293,35 +292,16 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
 #pragma unroll
         for (int m = 0; m < MT; ++m) gacc[m] = zero16();
         bwd_dx<MT, TL, false, false, NB>(gacc, R, a.packed + Ll.pb_off + aoff, Ll.Mpad8, nullptr, wcol, lane);
-        if (dwg) {  // own rows of dZ_l over the act' slot they were formed from: operand of the batch GEMM
-          rows_copy<TL, RH, true>(R, sv + (size_t)(NS * l + 1) * HSZ, RH * hh, wcol, lane);
-        } else {
-          BSrcStash<TL> bs{sv + (size_t)(NS * (l - 1)) * HSZ};
-          for (int it = w; it < 2 * Ll.Kblk; it += NW) {  // (column block, row half) items over the four waves
-            const int n = it >> 1, c = it & 1;
-            dw_pass<MT, TL, true, BSrcStash<TL>>(lds + c * MT * 32 * INR_LDS_LD, RS, bs, n,
-                                                 slab + Ll.gw_off + (size_t)c * RH * Ll.K, slab + Ll.gb_off + c * RH,
-                                                 Ll.M, Ll.K, first, n == 0, lane);
-          }
-        }
-        __syncthreads();  // dZ_l has been read by every dW pass and dX
+        // dW_l is left to the batch GEMM (inr_dw_gemm.hip): own rows of dZ_l over the act' slot they were formed from
+        rows_copy<TL, RH, true>(R, sv + (size_t)(NS * l + 1) * HSZ, RH * hh, wcol, lane);
+        __syncthreads();  // dZ_l has been read by every wave's dX
         if (G2D) {  // second Linear of the layer: dZ_orth = J_orth dH_l, dH_{l-1} += V_l^T dZ_orth, dV_l
           const LayerDesc& Ol = nd.L[nd.orth0 + l];
           rows_copy<TL, RH, false>(R, sv_g, RH * hh, wcol, lane);
           rows_times<TL, RH, true>(R, sv + (size_t)(NS * l + 3) * HSZ, sv + (size_t)(NS * l + 4) * HSZ, RH * hh, wcol, lane);
           __syncthreads();
           bwd_dx<MT, TL, false, false, NB>(gacc, R, a.packed + Ol.pb_off + aoff, Ol.Mpad8, nullptr, wcol, lane);
-          if (dwg) {
-            rows_copy<TL, RH, true>(R, sv + (size_t)(NS * l + 3) * HSZ, RH * hh, wcol, lane);  // dZ_orth (own rows)
-          } else {
-            BSrcStash<TL> bs{sv + (size_t)(NS * (l - 1)) * HSZ};
-            for (int it = w; it < 2 * Ol.Kblk; it += NW) {
-              const int n = it >> 1, c = it & 1;
-              dw_pass<MT, TL, true, BSrcStash<TL>>(lds + c * MT * 32 * INR_LDS_LD, RS, bs, n,
-                                                   slab + Ol.gw_off + (size_t)c * RH * Ol.K, slab + Ol.gb_off + c * RH,
-                                                   Ol.M, Ol.K, first, n == 0, lane);
-            }
-          }
+          rows_copy<TL, RH, true>(R, sv + (size_t)(NS * l + 3) * HSZ, RH * hh, wcol, lane);  // dZ_orth (own rows)
           __syncthreads();
         }
         if (l == 1)
@@ -333,16 +313,8 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
       {
         const LayerDesc& L0 = nd.L[0];
         __syncthreads();  // dZ_0 complete
-        if (INMODE == IN_GAUSS && dwg) {
-          rows_copy<TL, RH, true>(R, sv + (size_t)1 * HSZ, RH * hh, wcol, lane);  // dZ_0 (own rows)
-        } else if (INMODE == IN_GAUSS) {
-          BSrcStash<TL> bs{sv_enc};
-          for (int it = w; it < 2 * L0.Kblk; it += NW) {
-            const int n = it >> 1, c = it & 1;
-            dw_pass<MT, TL, true, BSrcStash<TL>>(lds + c * MT * 32 * INR_LDS_LD, RS, bs, n,
-                                                 slab + L0.gw_off + (size_t)c * RH * L0.K, slab + L0.gb_off + c * RH,
-                                                 L0.M, L0.K, first, n == 0, lane);
-          }
+        if (INMODE == IN_GAUSS) {
+          rows_copy<TL, RH, true>(R, sv + (size_t)1 * HSZ, RH * hh, wcol, lane);  // dZ_0 (own rows), for the GEMM
         } else {
           BSrcX bs{a.x, row0, a.B, L0.K};
           for (int it = w; it < 2 * L0.Kblk; it += NW) {
@@ -392,6 +364,8 @@ inline hipError_t launch_mlp_wide(const NetDesc& nd, const LossDesc& ld, const M
   auto k = inr_mlp_wide_kernel<NB, INMODE, HACT, MODE>;
   static thread_local bool attr_set = false;
   if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
+  // backward has no dW passes for the hidden-width layers: the caller runs the batch GEMM on the stash
+  if (MODE != MODE_FWD && !a.dw_gemm && (nd.D > 2 || INMODE == IN_GAUSS)) return hipErrorInvalidValue;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        160 * 1024);
