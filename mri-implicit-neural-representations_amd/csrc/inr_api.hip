@@ -729,6 +729,9 @@ int inr_train_step(const inr_plan* plan, const inr_loss_desc* loss, const float*
   a.n_tiles = (int)nt;
   a.dw_gemm = dw_gemm_plan(plan) ? 1 : 0;
   a.save_by_block = a.dw_gemm ? 0 : 1;
+#ifdef INR_STAMPS
+  a.dbg = g_stamp_buf;
+#endif
   LossDesc ld;
   to_loss_desc(loss, &ld);
   int rc = launch(plan, ld, a, 2, (int)nb, (hipStream_t)stream);

@@ -79,13 +79,15 @@ __device__ __forceinline__ void wire_epilogue(const f32x16 (&acc)[MT], const flo
 // own rows of the image <-> global scratch [rows][TL] (WIRE2D: a layer's output gradient is needed twice)
 template <int TL, int RH, bool TO_GLOBAL>
 __device__ __forceinline__ void rows_copy(float* R, float* __restrict__ G, int r0, int wcol, int lane) {
-  const int half = lane >> 5, col = lane & 31;
+  // 16 bytes per lane: eight lanes cover the 32 coordinates of a row, a wave eight rows per instruction pair
+  const int seg = lane & 7, rr = lane >> 3;
+  float* g = G + (wcol & ~31) + 4 * seg;
 #pragma unroll 8
-  for (int r = r0 + half; r < r0 + RH; r += 2) {
+  for (int r = r0 + rr; r < r0 + RH; r += 8) {
     if (TO_GLOBAL)
-      G[r * TL + wcol] = R[swz(r, col)];
+      *reinterpret_cast<f32x4*>(g + r * TL) = *reinterpret_cast<const f32x4*>(R + swz(r, 4 * seg));
     else
-      R[swz(r, col)] = G[r * TL + wcol];
+      *reinterpret_cast<f32x4*>(R + swz(r, 4 * seg)) = *reinterpret_cast<const f32x4*>(g + r * TL);
   }
 }
 

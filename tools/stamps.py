@@ -29,9 +29,14 @@ for _ in range(3):
 torch.cuda.synchronize()
 d = dbg.cpu().view(nb, NWV, 64).double()
 names = {0: "start", 1: "fwd L0", 2: "fwd L1", 3: "fwd L2", 4: "fwd L3", 10: "fwd last+loss", 11: "sync", 12: "dW last",
-         13: "dX last+store", 26: "dX L3", 27: "sync", 28: "dW L3", 29: "sync+store", 22: "dX L2", 23: "sync", 24: "dW L2",
-         25: "sync+store", 18: "dX L1", 19: "sync", 20: "dW L1", 21: "sync+store", 40: "dz0+sync", 41: "dW L0", 42: "sync"}
-order = [0, 1, 2, 3, 4, 10, 11, 12, 13, 26, 27, 28, 29, 22, 23, 24, 25, 18, 19, 20, 21, 40, 41, 42]
+         13: "dX last+store", 26: "dX L3", 29: "dZ3 -> stash", 22: "dX L2", 25: "dZ2 -> stash", 18: "dX L1",
+         21: "dZ1 -> stash", 41: "dZ0 -> stash", 42: "sync"}
+# (the 256-row builds leave dW of the hidden-width layers to inr_dw_gemm.hip: no dW phases in the kernel)
+order = [0, 1, 2, 3, 4, 10, 11, 12, 13, 26, 29, 22, 25, 18, 21, 41, 42]
+if PREC != "f32":
+    names.update({27: "sync", 28: "dW L3", 29: "sync+store", 23: "sync", 24: "dW L2", 25: "sync+store", 19: "sync",
+                  20: "dW L1", 21: "sync+store", 40: "dz0+sync", 41: "dW L0"})
+    order = [0, 1, 2, 3, 4, 10, 11, 12, 13, 26, 27, 28, 29, 22, 23, 24, 25, 18, 19, 20, 21, 40, 41, 42]
 tot = (d[:, :, 42] - d[:, :, 0])
 print(f"B={B} blocks={nb} total cycles/wave: mean {tot.mean():.0f} min {tot.min():.0f} max {tot.max():.0f}")
 prev = order[0]
