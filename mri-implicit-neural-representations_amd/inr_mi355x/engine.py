@@ -116,6 +116,12 @@ class MLPEngine:
         L.check(self.lib.inr_plan_workspace(self.plan, B, C.byref(ss), C.byref(ns)))
         return int(ss.value), int(ns.value)
 
+    def _take_stash(self, B: int) -> None:
+        if getattr(self, "_stash_rows", None) != B:
+            raise RuntimeError("backward needs the stash of a forward(save=True) on the same batch, and a backward "
+                               "consumes it: run the forward again")
+        self._stash_rows = None
+
     def _stream(self) -> int:
         return torch.cuda.current_stream(self.params.device).cuda_stream
 
@@ -144,11 +150,14 @@ class MLPEngine:
         L.check(self.lib.inr_forward(self.plan, _ptr(self.params, "params"), _ptr(self.packed, "packed"),
                                      _ptr(x, "x"), _ptr(enc_B, "enc_B"), B, _ptr(out, "out"),
                                      _ptr(sv, "save"), self._stream()))
+        self._stash_rows = B if sv is not None else None
         return out
 
     def backward(self, x: torch.Tensor, enc_B: Optional[torch.Tensor], dout: torch.Tensor) -> torch.Tensor:
-        """d(loss)/d(params) for the most recent forward(save=True) on the same x."""
+        """d(loss)/d(params) for the most recent forward(save=True) on the same x.  Consumes the stash (the
+        weight-gradient GEMM's operands overwrite the stashed activation derivatives): one backward per forward."""
         B = x.shape[0]
+        self._take_stash(B)
         nt, _ = self.launch_dims(B)
         slabs = self._ws_slabs(self.workspace(B)[1])
         L.check(self.lib.inr_backward(self.plan, _ptr(self.params, "params"), _ptr(self.packed, "packed"),
@@ -188,6 +197,7 @@ class MLPEngine:
         """Fused encode -> forward -> loss -> backward (stages of train.py:163-189).  Leaves the
         un-reduced-across-ranks gradient in self.grads and returns the loss scalar (device)."""
         B = x.shape[0]
+        self._stash_rows = None  # the fused step writes (and consumes) the same stash buffer
         slots, n_slabs = self.workspace(B)
         ld = self.loss_desc(spec, B if count is None else count, hdr_A)
         L.check(self.lib.inr_train_step(self.plan, C.byref(ld), _ptr(self.params, "params"),
@@ -260,11 +270,13 @@ class MFNEngine(MLPEngine):
         L.check(self.lib.inr_forward_multi(self.plan, _ptr(self.params, "params"), _ptr(self.packed, "packed"),
                                            _ptr(coords, "coords"), _ptr(enc_B, "enc_B"), _ptr(dist, "dist"), B,
                                            _ptr(out, "out"), _ptr(sv, "save"), 0 if save else 1, self._stream()))
+        self._stash_rows = B if save else None
         return out
 
     def backward(self, coords: torch.Tensor, enc_B: torch.Tensor, dout: torch.Tensor,
                  dist: Optional[torch.Tensor] = None) -> torch.Tensor:
         B = coords.shape[0]
+        self._take_stash(B)
         nt, nb = self.launch_dims(B)
         L.check(self.lib.inr_backward_multi(self.plan, _ptr(self.params, "params"), _ptr(self.packed, "packed"),
                                             _ptr(coords, "coords"), _ptr(enc_B, "enc_B"), _ptr(dist, "dist"), B,
@@ -305,6 +317,7 @@ class MFNEngine(MLPEngine):
                    dist: Optional[torch.Tensor] = None, scale: float = 1.0,
                    cons: Optional[ConsistencySpec] = None):
         B = coords.shape[0]
+        self._stash_rows = None
         _, nb = self.launch_dims(B)
         slots, n_slabs = self.workspace(B)
         ld = self.multi_loss_desc(spec, B if count is None else count, hdr_A, scale, cons)

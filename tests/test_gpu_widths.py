@@ -120,6 +120,16 @@ def test_batch_dw_gemm_depths(dev, model, width, depth):
     (0.5 * torch.nn.functional.mse_loss(o1, gt.to(dev))).backward()
     g1 = torch.cat([p.grad.reshape(-1) for p in mdl.parameters()]).cpu()
     _check(o1.detach().cpu()[None], loss, g1, r32, r64)
+    # the backward consumed the stash (dZ over act'): a second one without a forward must refuse, not return garbage
+    e1 = mdl._engine()
+    x1 = enc.embedding(coords.to(dev))
+    e1.forward(x1, None, save=True)
+    dout = torch.ones(B, 2, device=dev)
+    ga = e1.backward(x1, None, dout).clone()
+    with pytest.raises(RuntimeError, match="consumes"):
+        e1.backward(x1, None, dout)
+    e1.forward(x1, None, save=True)
+    assert torch.equal(e1.backward(x1, None, dout), ga)
 
 
 @pytest.mark.parametrize("width", [24, 64, 90, 128, 200])
