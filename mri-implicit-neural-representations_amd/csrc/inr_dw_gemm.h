@@ -19,7 +19,6 @@ struct DwGemmArgs {
   long long save_floats_per_tile;
   int slab_floats;
   int n_tiles, n_chunks, tiles_per_chunk;
-  int strided;         // 1: chunk kc = tiles kc, kc + n_chunks, ... (tiles_per_chunk unused)
   int TL;              // coordinates per tile: 64 or 128
   int WB;              // 32-row blocks per wave-tile side: 4 (workgroup tile 256 x 256) or 3 (192 x 192)
   int n_items;

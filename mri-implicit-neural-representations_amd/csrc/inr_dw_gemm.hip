@@ -88,12 +88,10 @@ __device__ __forceinline__ void dwg_body(const DwGemmArgs& a, const DwGemmItem& 
     roff[k] = (isg ? it.g_off : it.h_off) + row * TL + (t & 7) * 4;
   }
   constexpr int KS = TL / 32;  // K-steps per tile
-  // chunk kc: tiles [kc tpc, (kc + 1) tpc) -- or, strided, kc, kc + n_chunks, ... (the tiles workgroup kc of a
-  // persistent fused kernel walked)
-  const int t0 = a.strided ? kc : kc * a.tiles_per_chunk;
-  const int tstep = a.strided ? a.n_chunks : 1;
-  int n_mine = a.strided ? (a.n_tiles - kc + a.n_chunks - 1) / a.n_chunks : a.n_tiles - t0;
-  if (!a.strided && n_mine > a.tiles_per_chunk) n_mine = a.tiles_per_chunk;
+  // chunk kc = tiles [kc tpc, (kc + 1) tpc)
+  const int t0 = kc * a.tiles_per_chunk;
+  int n_mine = a.n_tiles - t0;
+  if (n_mine > a.tiles_per_chunk) n_mine = a.tiles_per_chunk;
   const int n_steps = (n_mine > 0 ? n_mine : 0) * KS;
   const float* As = lds + (wm * 32 * WB + li) * DWG_LD + 4 * half;
   const float* Bs = lds + (TR + wn * 32 * WB + li) * DWG_LD + 4 * half;
@@ -107,7 +105,7 @@ __device__ __forceinline__ void dwg_body(const DwGemmArgs& a, const DwGemmItem& 
   for (int s = 0; s < n_steps; ++s) {
     const int sn = s + 1;
     if (sn < n_steps)
-      dwg_fetch(v, a.save + (size_t)(t0 + (sn / KS) * tstep) * a.save_floats_per_tile, roff, sn % KS);
+      dwg_fetch(v, a.save + (size_t)(t0 + sn / KS) * a.save_floats_per_tile, roff, sn % KS);
     const float* Ab = As + (s & 1) * DWG_STAGE;
     const float* Bb = Bs + (s & 1) * DWG_STAGE;
 #pragma unroll
@@ -178,8 +176,7 @@ static hipError_t launch_tl(const DwGemmArgs& a, dim3 grid, hipStream_t st) {
 
 hipError_t launch_dw_gemm(DwGemmArgs& a, hipStream_t st) {
   if (a.n_items <= 0) return hipSuccess;
-  if (a.n_items > INR_DWG_MAX_ITEMS || a.n_chunks <= 0 || (!a.strided && a.tiles_per_chunk <= 0))
-    return hipErrorInvalidValue;
+  if (a.n_items > INR_DWG_MAX_ITEMS || a.n_chunks <= 0 || a.tiles_per_chunk <= 0) return hipErrorInvalidValue;
   a.blocks_per_chunk = dw_gemm_units(a);
   a.units = a.blocks_per_chunk;
   const dim3 grid((unsigned)(a.n_chunks * a.blocks_per_chunk));
