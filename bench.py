@@ -208,13 +208,12 @@ def main():
         eng = tr.engine
         x, gt = tr.coords[:batch], tr.image[:batch]
         ld = eng.loss_desc(tr.loss, batch)
-        slots, n_slabs = eng.workspace(batch)
-        save, slabs = eng._ws_save(slots), eng._ws_slabs(n_slabs)
+        ws = eng._ws(*eng.workspace(batch))
 
         def fused_only():
             L.check(eng.lib.inr_train_step(eng.plan, C.byref(ld), eng.params.data_ptr(), eng.packed.data_ptr(),
                                            x.data_ptr(), tr.enc_B.data_ptr(), gt.data_ptr(), None, batch,
-                                           save.data_ptr(), slabs.data_ptr(), None, eng._loss.data_ptr(), st))
+                                           C.byref(ws), None, eng._loss.data_ptr(), st))
 
         for _ in range(5):
             fused_only()

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define INR_ABI_VERSION 2
+#define INR_ABI_VERSION 3
 
 /* error codes */
 #define INR_OK 0
@@ -80,7 +80,8 @@ enum inr_act {
 /* how the first layer's input is produced */
 enum inr_input {
   INR_INPUT_X = 0,     /* x [B, in_features] already in memory (what model.forward receives,
-                          train.py:163-169: coords = encoder.embedding(coords); model(coords)) */
+                          train.py:163-169: coords = encoder.embedding(coords); model(coords)); every kind,
+                          the filter networks of models/mfn.py included (mfn.py:34-43,85-94,255-267) */
   INR_INPUT_GAUSS = 1  /* fused Positional_Encoder 'gauss' (networks.py:30-33): coords [B,3] and
                           enc_B [E,3]; in_features must equal 2E; [B,2E] is never materialised */
 };
@@ -134,6 +135,17 @@ typedef struct inr_loss_desc {
 
 typedef struct inr_plan inr_plan;
 
+/* Caller-owned scratch of one call, with its extents so that a short buffer is INR_ERR_INVALID and never an
+ * out-of-bounds GPU write.  `save` = the activation stash (slots of inr_sizes.save_bytes_per_tile), `slabs` = the
+ * gradient slabs (of inr_sizes.slab_floats floats); how many of each a batch of B rows needs:
+ * inr_plan_launch_dims / inr_plan_workspace.  Extents are in floats. */
+typedef struct inr_workspace {
+  float* save;
+  int64_t save_floats;
+  float* slabs;
+  int64_t slab_floats;
+} inr_workspace;
+
 /* sizes (in bytes unless stated) a caller needs to allocate buffers for a plan */
 typedef struct inr_sizes {
   int64_t n_params;        /* P: floats in flat params / grads / Adam moments */
@@ -175,17 +187,17 @@ int inr_encode_logf(const float* coords, const float* bands, int64_t B, int32_t 
                     void* stream);
 
 /* Replaces model.forward (networks.py:121-124 / 67-69).  `x` is [B,in_features] (INR_INPUT_X) or
- * coords [B,3] (INR_INPUT_GAUSS, with enc_B [E,3]).  out [B,out_features].  `save` (may be NULL
- * for a no_grad forward, train.py:203-220) receives n_tiles * save_bytes_per_tile bytes. */
+ * coords [B,3] (INR_INPUT_GAUSS, with enc_B [E,3]).  out [B,out_features].  `ws` may be NULL (or ws->save NULL)
+ * for a no_grad forward (train.py:203-220); otherwise ws->save receives n_tiles stash slots. */
 int inr_forward(const inr_plan* plan, const float* params, const float* packed, const float* x,
-                const float* enc_B, int64_t B, float* out, float* save, void* stream);
+                const float* enc_B, int64_t B, float* out, const inr_workspace* ws, void* stream);
 
 /* Replaces loss.backward() through the model (train.py:189): given d(loss)/d(out) [B,out_features]
- * and the forward's `save`, writes d(loss)/d(params) into grads [P].  `slabs` is workspace of
- * n_slabs * slab_floats floats (inr_plan_workspace).  The stash is CONSUMED: plans with
- * inr_sizes.step_save_by_tile overwrite act'(z_l) with dZ_l, the operand of their weight-gradient GEMM. */
+ * and the forward's stash (ws->save, n_tiles slots), writes d(loss)/d(params) into grads [P].  ws->slabs holds
+ * n_slabs slabs (inr_plan_workspace).  The stash is CONSUMED: plans with inr_sizes.step_save_by_tile overwrite
+ * act'(z_l) with dZ_l, the operand of their weight-gradient GEMM. */
 int inr_backward(const inr_plan* plan, const float* params, const float* packed, const float* x,
-                 const float* enc_B, int64_t B, const float* dout, float* save, float* slabs,
+                 const float* enc_B, int64_t B, const float* dout, const inr_workspace* ws,
                  float* grads, void* stream);
 
 /* Replaces the loss modules + their autograd (train.py:178-182; metrics/losses.py): writes
@@ -220,28 +232,30 @@ int inr_tv_grad(const float* out, int64_t R, int64_t R_own, int64_t W, int64_t H
  * NULL to launch the fused kernel alone and leave the slabs unreduced (used to time it). */
 int inr_train_step(const inr_plan* plan, const inr_loss_desc* loss, const float* params,
                    const float* packed, const float* x, const float* enc_B, const float* gt,
-                   const uint8_t* mask, int64_t B, float* save, float* slabs, float* grads,
+                   const uint8_t* mask, int64_t B, const inr_workspace* ws, float* grads,
                    float* loss_out, void* stream);
 
 /* Multi-head networks (MultiscaleKFourier.forward returns a list, mfn.py:255-267): `out` / `dout` are
- * [n_heads][B][out_features]; `dist` [B] = dist_to_center (nerp_datasets.py:385), read by the
- * consistency term; `save` is always required (it also carries the encoder features between stages;
+ * [n_heads][B][out_features]; `coords` is coords [B,3] with enc_B [E,3] (INR_INPUT_GAUSS plans) or the encoded
+ * x [B,in_features] with enc_B NULL (INR_INPUT_X plans: what the reference's forward receives, mfn.py:34-43);
+ * `dist` [B] = dist_to_center (nerp_datasets.py:385), read by the consistency term and the bounded linears;
+ * ws->save is always required (it also carries the input features between stages;
  * pass n_blocks slots and by_block = 1 for a no_grad sweep, n_tiles slots and 0 before inr_backward_multi).
  * inr_backward_multi CONSUMES the stash: plans with inr_sizes.step_save_by_tile overwrite stashed factors with
  * the gradient operands of their batch-level weight-gradient GEMM, so one forward serves one backward.
  * inr_train_step_multi takes n_tiles slots when step_save_by_tile is set, n_blocks slots otherwise. */
 int inr_forward_multi(const inr_plan* plan, const float* params, const float* packed, const float* coords,
-                      const float* enc_B, const float* dist, int64_t B, float* out, float* save,
+                      const float* enc_B, const float* dist, int64_t B, float* out, const inr_workspace* ws,
                       int32_t by_block, void* stream);
 int inr_backward_multi(const inr_plan* plan, const float* params, const float* packed, const float* coords,
-                       const float* enc_B, const float* dist, int64_t B, const float* dout, float* save,
-                       float* slabs, float* grads, void* stream);
+                       const float* enc_B, const float* dist, int64_t B, const float* dout,
+                       const inr_workspace* ws, float* grads, void* stream);
 /* MultiscaleBoundedFourier(boundaries=pairs_model) (train_kspace_multiscale.py:85,95): one (lo,hi) per hidden
  * Linear; must be called before the plan is used (dist may be NULL for the other kinds above). */
 int inr_plan_set_bounds(inr_plan* plan, const float* lo, const float* hi, int32_t n);
 int inr_train_step_multi(const inr_plan* plan, const inr_loss_desc* loss, const float* params,
                          const float* packed, const float* coords, const float* enc_B, const float* gt,
-                         const float* dist, const uint8_t* mask, int64_t B, float* save, float* slabs,
+                         const float* dist, const uint8_t* mask, int64_t B, const inr_workspace* ws,
                          float* grads, float* loss_out, void* stream);
 int inr_plan_heads(const inr_plan* plan, int32_t* n_heads);
 

@@ -42,7 +42,8 @@ inline int pick_nb(int need, std::initializer_list<int> built) {
 constexpr int kMaxBlocks = 256;  // one persistent workgroup per CU (MI355X: 256 CUs)
 
 #ifdef INR_STAMPS
-long long* g_stamp_buf = nullptr;  // diagnostic build only (make dbg): phase stamps of the fused kernel
+long long* g_stamp_buf = nullptr;  // diagnostic build only (make dbg): phase stamps of the fused kernels
+long long g_stamp_cap = 0;         // entries behind it: INR_STAMP drops a stamp whose index is not below this
 #endif
 
 }  // namespace
@@ -64,9 +65,23 @@ static int create_mfn_plan(const inr_net_desc* d, inr_plan** out) {
   const int NB = W < 1 ? -1 : pick_nb((W + 31) / 32, {1, 4, 8, 16});
   if (NB < 0)
     return fail(INR_ERR_UNSUPPORTED, "inr_plan_create: MFN width %d (kernels are built for widths 1..512)", W);
-  if (d->input != INR_INPUT_GAUSS || d->enc_size < 8 || (d->enc_size % 8) != 0 || d->in_features != 2 * d->enc_size)
-    return fail(INR_ERR_UNSUPPORTED, "inr_plan_create: MFN kernels need the fused gauss encoder (in_features == 2*enc_size, "
-                "enc_size %% 8 == 0)");
+  // The filters read their input features from a [2E'][TL] image in the stash, k-step s -> rows s (lane half 0)
+  // and E' + s (half 1).  INR_INPUT_GAUSS: the fused encoder writes it, E' = enc_size.  INR_INPUT_X: the kernel
+  // transposes the tile's rows of x [B,in_features] into it, E' = half of in_features rounded up to 16 (rows past
+  // in_features are zero and carry zero weights).
+  int Ehalf;
+  if (d->input == INR_INPUT_GAUSS) {
+    if (d->enc_size < 8 || (d->enc_size % 8) != 0 || d->in_features != 2 * d->enc_size)
+      return fail(INR_ERR_UNSUPPORTED, "inr_plan_create: fused gauss encoder needs in_features == 2*enc_size, "
+                  "enc_size %% 8 == 0");
+    Ehalf = d->enc_size;
+  } else if (d->input == INR_INPUT_X) {
+    if (d->in_features < 1 || d->in_features > 4096)
+      return fail(INR_ERR_INVALID, "inr_plan_create: in_features %d", d->in_features);
+    Ehalf = round_up(d->in_features, 16) / 2;
+  } else {
+    return fail(INR_ERR_INVALID, "inr_plan_create: input mode %d", d->input);
+  }
   if (d->out_features < 1 || d->out_features > 4)
     return fail(INR_ERR_UNSUPPORTED, "inr_plan_create: out_features %d outside [1,4]", d->out_features);
   inr_plan* p = new (std::nothrow) inr_plan();
@@ -78,8 +93,8 @@ static int create_mfn_plan(const inr_net_desc* d, inr_plan** out) {
   nd.NW = NB == 16 ? 2 : 4;
   nd.hact = ACT_SIN;
   nd.last_act = ACT_ID;
-  nd.input = IN_GAUSS;
-  nd.E = d->enc_size;
+  nd.input = d->input == INR_INPUT_GAUSS ? IN_GAUSS : IN_X;
+  nd.E = Ehalf;
   nd.out_f = d->out_features;
   nd.mfn_n = n;
   if (d->kind == INR_KIND_MSBOUNDED) {
@@ -113,7 +128,7 @@ static int create_mfn_plan(const inr_net_desc* d, inr_plan** out) {
   auto fill = [&](LayerDesc& L, int K, int M, bool filter, bool head) {
     L.K = K;
     L.M = M;
-    L.Kpad8 = filter ? round_up(K, 8) : NB * 32;
+    L.Kpad8 = filter ? 2 * Ehalf : NB * 32;  // == round_up(K, 8) for the gauss encoder
     L.Kblk = filter ? (K + 31) / 32 : NB;  // hidden images always span all NB blocks (zero padding)
     L.Mblk = head ? (M + 31) / 32 : NB;
     L.Mpad8 = head ? round_up(M, 8) : NB * 32;
@@ -185,7 +200,7 @@ static int create_mfn_plan(const inr_net_desc* d, inr_plan** out) {
   nd.slab_loss_off = goff;
   nd.slab_floats = round_up(goff + 4, 64);
   // stash: [f | l cos u | h] per stage, encoder features, |x|^2 [TL]
-  nd.save_floats_per_tile = 3 * nd.mfn_stages * NB * 32 * TL + nd.L[0].Kblk * 32 * TL + TL;
+  nd.save_floats_per_tile = 3 * nd.mfn_stages * NB * 32 * TL + nd.L[0].Kblk * 32 * TL + TL;  // Kblk*32 >= 2 E'
   p->packed_floats = pk;
   *out = p;
   return INR_OK;
@@ -453,6 +468,23 @@ static bool dw_gemm_plan(const inr_plan* plan) {
 // fused steps of these plans stash per TILE (n_tiles slots): a batch-level GEMM reads the whole batch's stash
 static bool step_save_by_tile(const inr_plan* plan) { return dw_gemm_plan(plan); }
 
+// a call's scratch against what the plan needs: `save_slots` stash slots (0: none), `n_slabs` slabs (0: none)
+static int check_ws(const inr_plan* plan, const inr_workspace* ws, int64_t save_slots, int64_t n_slabs,
+                    const char* who) {
+  if (ws == nullptr) return fail(INR_ERR_INVALID, "%s: null workspace", who);
+  const int64_t need_save = save_slots * (int64_t)plan->nd.save_floats_per_tile;
+  const int64_t need_slabs = n_slabs * (int64_t)plan->nd.slab_floats;
+  if (save_slots > 0 && (ws->save == nullptr || ws->save_floats < need_save))
+    return fail(INR_ERR_INVALID, "%s: stash of %lld floats, the call needs %lld (%lld slots of %d; see "
+                "inr_plan_workspace)", who, (long long)(ws->save == nullptr ? 0 : ws->save_floats),
+                (long long)need_save, (long long)save_slots, plan->nd.save_floats_per_tile);
+  if (n_slabs > 0 && (ws->slabs == nullptr || ws->slab_floats < need_slabs))
+    return fail(INR_ERR_INVALID, "%s: %lld slab floats, the call needs %lld (%lld slabs of %d; see "
+                "inr_plan_workspace)", who, (long long)(ws->slabs == nullptr ? 0 : ws->slab_floats),
+                (long long)need_slabs, (long long)n_slabs, plan->nd.slab_floats);
+  return INR_OK;
+}
+
 int inr_plan_sizes(const inr_plan* plan, inr_sizes* out) {
   if (plan == nullptr || out == nullptr) return fail(INR_ERR_INVALID, "inr_plan_sizes: null argument");
   out->n_params = plan->nd.P;
@@ -561,17 +593,22 @@ int inr_encode_gauss(const float* coords, const float* enc_B, int64_t B, int32_t
 }
 
 int inr_forward(const inr_plan* plan, const float* params, const float* packed, const float* x,
-                const float* enc_B, int64_t B, float* out, float* save, void* stream) {
+                const float* enc_B, int64_t B, float* out, const inr_workspace* ws, void* stream) {
   if (plan == nullptr || params == nullptr || packed == nullptr || x == nullptr || out == nullptr)
     return fail(INR_ERR_INVALID, "inr_forward: null argument");
   if (plan->nd.mfn_n > 0) return fail(INR_ERR_INVALID, "inr_forward: multiplicative-filter plans use inr_forward_multi");
   if (plan->nd.input == IN_GAUSS && enc_B == nullptr) return fail(INR_ERR_INVALID, "inr_forward: enc_B is null");
+  float* save = ws != nullptr ? ws->save : nullptr;
   if ((plan->nd.hact == ACT_GABOR2D || plan->nd.bf16) && save == nullptr)
     return fail(INR_ERR_INVALID, "inr_forward: WIRE2D and bf16 plans need a save buffer (n_tiles * "
                 "save_floats_per_tile floats)");
   if (B <= 0) return fail(INR_ERR_INVALID, "inr_forward: B = %lld", (long long)B);
   int64_t nt, nb;
   inr_plan_launch_dims(plan, B, &nt, &nb);
+  if (save != nullptr) {
+    const int rc = check_ws(plan, ws, nt, 0, "inr_forward");
+    if (rc != INR_OK) return rc;
+  }
   inr::MlpArgs a;
   memset(&a, 0, sizeof(a));
   a.params = params;
@@ -607,16 +644,21 @@ static int finish_gradients(const inr_plan* plan, const inr::MlpArgs& a, int64_t
 }
 
 int inr_backward(const inr_plan* plan, const float* params, const float* packed, const float* x,
-                 const float* enc_B, int64_t B, const float* dout, float* save, float* slabs,
+                 const float* enc_B, int64_t B, const float* dout, const inr_workspace* ws,
                  float* grads, void* stream) {
   if (plan == nullptr || params == nullptr || packed == nullptr || x == nullptr || dout == nullptr ||
-      save == nullptr || slabs == nullptr || grads == nullptr)
+      ws == nullptr || grads == nullptr)
     return fail(INR_ERR_INVALID, "inr_backward: null argument");
   if (plan->nd.mfn_n > 0) return fail(INR_ERR_INVALID, "inr_backward: multiplicative-filter plans use inr_backward_multi");
   if (plan->nd.input == IN_GAUSS && enc_B == nullptr) return fail(INR_ERR_INVALID, "inr_backward: enc_B is null");
   if (B <= 0) return fail(INR_ERR_INVALID, "inr_backward: B = %lld", (long long)B);
-  int64_t nt, nb;
+  int64_t nt, nb, slots, n_slabs;
   inr_plan_launch_dims(plan, B, &nt, &nb);
+  inr_plan_workspace(plan, B, &slots, &n_slabs);
+  {
+    const int rc = check_ws(plan, ws, nt, n_slabs, "inr_backward");
+    if (rc != INR_OK) return rc;
+  }
   inr::MlpArgs a;
   memset(&a, 0, sizeof(a));
   a.params = params;
@@ -624,8 +666,8 @@ int inr_backward(const inr_plan* plan, const float* params, const float* packed,
   a.x = x;
   a.encB = enc_B;
   a.dout = dout;
-  a.save = save;
-  a.slabs = slabs;
+  a.save = ws->save;
+  a.slabs = ws->slabs;
   a.B = B;
   a.n_tiles = (int)nt;
   a.save_by_block = 0;
@@ -701,9 +743,9 @@ int inr_tv_grad(const float* out, int64_t R, int64_t R_own, int64_t W, int64_t H
 
 int inr_train_step(const inr_plan* plan, const inr_loss_desc* loss, const float* params, const float* packed,
                    const float* x, const float* enc_B, const float* gt, const uint8_t* mask, int64_t B,
-                   float* save, float* slabs, float* grads, float* loss_out, void* stream) {
+                   const inr_workspace* ws, float* grads, float* loss_out, void* stream) {
   if (plan == nullptr || loss == nullptr || params == nullptr || packed == nullptr || x == nullptr ||
-      gt == nullptr || save == nullptr || slabs == nullptr || loss_out == nullptr)
+      gt == nullptr || ws == nullptr || loss_out == nullptr)
     return fail(INR_ERR_INVALID, "inr_train_step: null argument");
   if (plan->nd.mfn_n > 0)
     return fail(INR_ERR_INVALID, "inr_train_step: multiplicative-filter plans use inr_train_step_multi");
@@ -713,8 +755,13 @@ int inr_train_step(const inr_plan* plan, const inr_loss_desc* loss, const float*
   if (loss->kind >= INR_LOSS_LOGSPACE && plan->nd.out_f != 2)
     return fail(INR_ERR_INVALID, "inr_train_step: complex-row losses need out_features == 2");
   if (B <= 0) return fail(INR_ERR_INVALID, "inr_train_step: B = %lld", (long long)B);
-  int64_t nt, nb;
+  int64_t nt, nb, slots, n_slabs;
   inr_plan_launch_dims(plan, B, &nt, &nb);
+  inr_plan_workspace(plan, B, &slots, &n_slabs);
+  {
+    const int rc = check_ws(plan, ws, slots, n_slabs, "inr_train_step");
+    if (rc != INR_OK) return rc;
+  }
   inr::MlpArgs a;
   memset(&a, 0, sizeof(a));
   a.params = params;
@@ -723,14 +770,15 @@ int inr_train_step(const inr_plan* plan, const inr_loss_desc* loss, const float*
   a.encB = enc_B;
   a.gt = gt;
   a.mask = mask;
-  a.save = save;
-  a.slabs = slabs;
+  a.save = ws->save;
+  a.slabs = ws->slabs;
   a.B = B;
   a.n_tiles = (int)nt;
   a.dw_gemm = dw_gemm_plan(plan) ? 1 : 0;
   a.save_by_block = a.dw_gemm ? 0 : 1;
 #ifdef INR_STAMPS
   a.dbg = g_stamp_buf;
+  a.dbg_cap = g_stamp_cap;
 #endif
   LossDesc ld;
   to_loss_desc(loss, &ld);
@@ -758,16 +806,21 @@ int inr_plan_heads(const inr_plan* plan, int32_t* n_heads) {
 }
 
 int inr_forward_multi(const inr_plan* plan, const float* params, const float* packed, const float* coords,
-                      const float* enc_B, const float* dist, int64_t B, float* out, float* save, int32_t by_block,
-                      void* stream) {
-  if (plan == nullptr || params == nullptr || packed == nullptr || coords == nullptr || enc_B == nullptr ||
-      out == nullptr || save == nullptr)
+                      const float* enc_B, const float* dist, int64_t B, float* out, const inr_workspace* ws,
+                      int32_t by_block, void* stream) {
+  if (plan == nullptr || params == nullptr || packed == nullptr || coords == nullptr || out == nullptr ||
+      ws == nullptr)
     return fail(INR_ERR_INVALID, "inr_forward_multi: null argument");
+  if (plan->nd.input == IN_GAUSS && enc_B == nullptr) return fail(INR_ERR_INVALID, "inr_forward_multi: enc_B is null");
   if (plan->nd.bounded && dist == nullptr) return fail(INR_ERR_INVALID, "inr_forward_multi: bounded model needs dist");
   if (plan->nd.mfn_n == 0) return fail(INR_ERR_INVALID, "inr_forward_multi: not a multiplicative-filter plan");
   if (B <= 0) return fail(INR_ERR_INVALID, "inr_forward_multi: B = %lld", (long long)B);
   int64_t nt, nb;
   inr_plan_launch_dims(plan, B, &nt, &nb);
+  {
+    const int rc = check_ws(plan, ws, by_block ? nb : nt, 0, "inr_forward_multi");
+    if (rc != INR_OK) return rc;
+  }
   inr::MlpArgs a;
   memset(&a, 0, sizeof(a));
   a.params = params;
@@ -776,7 +829,7 @@ int inr_forward_multi(const inr_plan* plan, const float* params, const float* pa
   a.encB = enc_B;
   a.out = out;
   a.dist = dist;
-  a.save = save;
+  a.save = ws->save;
   a.B = B;
   a.n_tiles = (int)nt;
   a.save_by_block = by_block ? 1 : 0;
@@ -786,16 +839,22 @@ int inr_forward_multi(const inr_plan* plan, const float* params, const float* pa
 }
 
 int inr_backward_multi(const inr_plan* plan, const float* params, const float* packed, const float* coords,
-                       const float* enc_B, const float* dist, int64_t B, const float* dout, float* save,
-                       float* slabs, float* grads, void* stream) {
-  if (plan == nullptr || params == nullptr || packed == nullptr || coords == nullptr || enc_B == nullptr ||
-      dout == nullptr || save == nullptr || slabs == nullptr || grads == nullptr)
+                       const float* enc_B, const float* dist, int64_t B, const float* dout,
+                       const inr_workspace* ws, float* grads, void* stream) {
+  if (plan == nullptr || params == nullptr || packed == nullptr || coords == nullptr || dout == nullptr ||
+      ws == nullptr || grads == nullptr)
     return fail(INR_ERR_INVALID, "inr_backward_multi: null argument");
+  if (plan->nd.input == IN_GAUSS && enc_B == nullptr) return fail(INR_ERR_INVALID, "inr_backward_multi: enc_B is null");
   if (plan->nd.bounded && dist == nullptr) return fail(INR_ERR_INVALID, "inr_backward_multi: bounded model needs dist");
   if (plan->nd.mfn_n == 0) return fail(INR_ERR_INVALID, "inr_backward_multi: not a multiplicative-filter plan");
   if (B <= 0) return fail(INR_ERR_INVALID, "inr_backward_multi: B = %lld", (long long)B);
-  int64_t nt, nb;
+  int64_t nt, nb, slots, n_slabs;
   inr_plan_launch_dims(plan, B, &nt, &nb);
+  inr_plan_workspace(plan, B, &slots, &n_slabs);
+  {
+    const int rc = check_ws(plan, ws, nt, n_slabs, "inr_backward_multi");
+    if (rc != INR_OK) return rc;
+  }
   inr::MlpArgs a;
   memset(&a, 0, sizeof(a));
   a.params = params;
@@ -804,8 +863,8 @@ int inr_backward_multi(const inr_plan* plan, const float* params, const float* p
   a.encB = enc_B;
   a.dout = dout;
   a.dist = dist;
-  a.save = save;
-  a.slabs = slabs;
+  a.save = ws->save;
+  a.slabs = ws->slabs;
   a.B = B;
   a.n_tiles = (int)nt;
   a.save_by_block = 0;
@@ -819,19 +878,25 @@ int inr_backward_multi(const inr_plan* plan, const float* params, const float* p
 
 int inr_train_step_multi(const inr_plan* plan, const inr_loss_desc* loss, const float* params, const float* packed,
                          const float* coords, const float* enc_B, const float* gt, const float* dist,
-                         const uint8_t* mask, int64_t B, float* save, float* slabs, float* grads, float* loss_out,
+                         const uint8_t* mask, int64_t B, const inr_workspace* ws, float* grads, float* loss_out,
                          void* stream) {
   if (plan == nullptr || loss == nullptr || params == nullptr || packed == nullptr || coords == nullptr ||
-      enc_B == nullptr || gt == nullptr || save == nullptr || slabs == nullptr || loss_out == nullptr)
+      gt == nullptr || ws == nullptr || loss_out == nullptr)
     return fail(INR_ERR_INVALID, "inr_train_step_multi: null argument");
+  if (plan->nd.input == IN_GAUSS && enc_B == nullptr) return fail(INR_ERR_INVALID, "inr_train_step_multi: enc_B is null");
   if (plan->nd.mfn_n == 0) return fail(INR_ERR_INVALID, "inr_train_step_multi: not a multiplicative-filter plan");
   if (loss->kind < INR_LOSS_L2_HALF || loss->kind > INR_LOSS_MSLE_HALF)
     return fail(INR_ERR_INVALID, "inr_train_step_multi: loss kind %d", loss->kind);
   if ((loss->cons_w != 0.f || plan->nd.bounded) && dist == nullptr)
     return fail(INR_ERR_INVALID, "inr_train_step_multi: the consistency term / bounded linears need dist");
   if (B <= 0) return fail(INR_ERR_INVALID, "inr_train_step_multi: B = %lld", (long long)B);
-  int64_t nt, nb;
+  int64_t nt, nb, slots, n_slabs;
   inr_plan_launch_dims(plan, B, &nt, &nb);
+  inr_plan_workspace(plan, B, &slots, &n_slabs);
+  {
+    const int rc = check_ws(plan, ws, slots, n_slabs, "inr_train_step_multi");
+    if (rc != INR_OK) return rc;
+  }
   inr::MlpArgs a;
   memset(&a, 0, sizeof(a));
   a.params = params;
@@ -841,12 +906,16 @@ int inr_train_step_multi(const inr_plan* plan, const inr_loss_desc* loss, const 
   a.gt = gt;
   a.dist = dist;
   a.mask = mask;
-  a.save = save;
-  a.slabs = slabs;
+  a.save = ws->save;
+  a.slabs = ws->slabs;
   a.B = B;
   a.n_tiles = (int)nt;
   a.dw_gemm = dw_gemm_plan(plan) ? 1 : 0;
   a.save_by_block = a.dw_gemm ? 0 : 1;
+#ifdef INR_STAMPS
+  a.dbg = g_stamp_buf;
+  a.dbg_cap = g_stamp_cap;
+#endif
   LossDesc ld;
   to_loss_desc(loss, &ld);
   int rc = launch(plan, ld, a, 2, (int)nb, (hipStream_t)stream);
@@ -883,8 +952,10 @@ int inr_adam_step(const inr_plan* plan, float* params, const float* grads, float
 }
 
 #ifdef INR_STAMPS
-int inr_debug_set_stamp_buffer(long long* buf) {
+// entries = 64 per WAVE of the grid (kernels index (blockIdx.x * waves_per_workgroup + wave) * 64 + stamp)
+int inr_debug_set_stamp_buffer(long long* buf, long long entries) {
   g_stamp_buf = buf;
+  g_stamp_cap = buf != nullptr ? entries : 0;
   return INR_OK;
 }
 #endif

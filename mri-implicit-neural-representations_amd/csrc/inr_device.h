@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "inr_launch.h"
 
 #define INR_MAX_LAYERS 32
 #define INR_MAX_HEADS 4

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include "inr_dw_gemm.h"
+#include "inr_launch.h"
 
 namespace inr {
 
@@ -163,12 +164,9 @@ template <int TL, int WB>
 static hipError_t launch_tl(const DwGemmArgs& a, dim3 grid, hipStream_t st) {
   constexpr size_t lds_bytes = (size_t)2 * dwg_stage<WB>() * sizeof(float);  // two stages (WB = 4: 147 KB)
   auto k = dw_gemm_kernel<TL, WB>;
-  static thread_local bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       160 * 1024);
+  {
+    hipError_t e = allow_full_lds<dw_gemm_kernel<TL, WB>>();
     if (e != hipSuccess) return e;
-    attr_set = true;
   }
   hipLaunchKernelGGL(k, grid, dim3(256), lds_bytes, st, a);
   return hipGetLastError();

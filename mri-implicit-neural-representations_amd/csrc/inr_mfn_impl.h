@@ -58,6 +58,29 @@ __device__ __forceinline__ void gemm_enc_stash(f32x16 (&acc)[NB], const float* _
   }
 }
 
+// INR_INPUT_X (the reference's call contract, mfn.py:34-43: forward receives the ENCODED x [B,in]): this
+// coordinate's row of x goes into the feature image of the stash, from where every stage reads it exactly as it
+// reads the fused encoder's output.  Lane (coordinate, half) writes rows [half E', half E' + E') -- the rows its
+// own filter GEMMs read back -- and zeros past in_features (those k-steps carry zero weights).
+template <int TL>
+__device__ __forceinline__ void x_rows_to_stash(const float* __restrict__ x, long long crow, bool valid, int K, int E,
+                                                float* __restrict__ sv_enc, int wcol, int lane) {
+  const int k0 = (lane >> 5) ? E : 0;
+  const float* xr = x + (size_t)(valid ? crow : 0) * K;
+  float* dst = sv_enc + (size_t)k0 * TL + wcol;
+  if ((K & 3) == 0) {  // rows of x are 16-byte aligned: four features per load
+#pragma unroll 4
+    for (int j = 0; j < E; j += 4) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (valid && k0 + j < K) v = *reinterpret_cast<const f32x4*>(xr + k0 + j);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dst[(j + e) * TL] = v[e];
+    }
+  } else {
+    for (int j = 0; j < E; ++j) dst[j * TL] = (valid && k0 + j < K) ? xr[k0 + j] : 0.f;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // stage epilogue for row blocks [m0, m0+MT): u = accU + c (bias image), f = sin u, fc = cos u;
 //   GABOR (GaborLayer.forward, mfn.py:116-131): D = |x|^2 + |mu_j|^2 - 2 q (q = accQ = mu_j . x),
@@ -311,8 +334,11 @@ __global__ __launch_bounds__(NW * 64) void inr_mfn_kernel(const NetDesc nd, cons
   float* HGall = lds + NW * RS;
   float* HG = HGall + w * HS;
   float* encB_lds = HGall + NW * HS;
-  for (int i = tid; i < 3 * nd.E; i += NW * 64) encB_lds[i] = a.encB[i];
-  __syncthreads();
+  const bool xin = nd.input == IN_X;  // x [B,in] in memory instead of the fused gauss encoder
+  if (!xin) {
+    for (int i = tid; i < 3 * nd.E; i += NW * 64) encB_lds[i] = a.encB[i];
+    __syncthreads();
+  }
   const int n = nd.mfn_n, S = nd.mfn_stages, NH = nd.n_heads;
   const LayerDesc* Fl = nd.L;           // filters 0..n
   const LayerDesc* Ll = nd.L + n + 1;   // linears 0..n-1
@@ -340,18 +366,19 @@ __global__ __launch_bounds__(NW * 64) void inr_mfn_kernel(const NetDesc nd, cons
     if (MODE != MODE_BWD) {
       {
         float x0 = 0.f, x1 = 0.f, x2c = 0.f;
-        if (valid) {
+        if (valid && !xin) {
           x0 = a.x[3 * crow + 0];
           x1 = a.x[3 * crow + 1];
           x2c = a.x[3 * crow + 2];
         }
+        if (xin) x_rows_to_stash<TL>(a.x, crow, valid, Fl[0].K, nd.E, sv_enc, wcol, lane);
         const float two_pi = 6.283185307179586f;
 #pragma unroll
         for (int m0 = 0; m0 < NB; m0 += MT) {
           f32x16 accU[MT], accQ[GABOR ? MT : 1];
 #pragma unroll
           for (int m = 0; m < MT; ++m) accU[m] = zero16();
-          if (m0 == 0)  // generates the encoder features and leaves them in the stash for everything after
+          if (m0 == 0 && !xin)  // generates the encoder features and leaves them in the stash for everything after
             fwd_layer0_gauss<MT, TL, true, NB>(accU, a.packed + Fl[0].pf_off, encB_lds, nd.E, two_pi * x0, two_pi * x1,
                                                two_pi * x2c, sv_enc, wcol, lane);
           else
@@ -552,15 +579,12 @@ __global__ __launch_bounds__(NW * 64) void inr_mfn_kernel(const NetDesc nd, cons
 
 template <int NB, int NW, int MODE, bool GABOR>
 inline hipError_t launch_mfn(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int grid, hipStream_t st) {
-  const size_t lds_bytes = ((size_t)NW * (NB + 1) * 32 * INR_LDS_LD + 3 * (size_t)nd.E) * sizeof(float);
+  const size_t lds_bytes = ((size_t)NW * (NB + 1) * 32 * INR_LDS_LD + (nd.input == IN_GAUSS ? 3 * (size_t)nd.E : 0)) * sizeof(float);
   auto k = inr_mfn_kernel<NB, NW, MODE, GABOR>;
-  static thread_local bool attr_set = false;
   if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       160 * 1024);
+  {
+    hipError_t e = allow_full_lds<inr_mfn_kernel<NB, NW, MODE, GABOR>>();
     if (e != hipSuccess) return e;
-    attr_set = true;
   }
   hipLaunchKernelGGL(k, dim3(grid), dim3(NW * 64), lds_bytes, st, nd, ld, a);
   return hipGetLastError();

@@ -7,7 +7,7 @@ namespace inr {
 
 hipError_t INR_LAUNCH_NAME(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int mode, int grid,
                            hipStream_t st) {
-  if (nd.input != IN_GAUSS) return hipErrorInvalidValue;
+  if (nd.input != IN_GAUSS && nd.input != IN_X) return hipErrorInvalidValue;
   if (nd.gabor) {
     switch (mode) {
       case MODE_FWD: return launch_mfn<INR_NB, INR_NW, MODE_FWD, true>(nd, ld, a, grid, st);

@@ -17,7 +17,7 @@ static hipError_t dispatch(const NetDesc& nd, const LossDesc& ld, const MlpArgs&
 }
 
 hipError_t launch_mfn_nb16(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int mode, int grid, hipStream_t st) {
-  if (nd.input != IN_GAUSS || nd.NB != 16 || nd.NW != 2 || a.save == nullptr) return hipErrorInvalidValue;
+  if ((nd.input != IN_GAUSS && nd.input != IN_X) || nd.NB != 16 || nd.NW != 2 || a.save == nullptr) return hipErrorInvalidValue;
   return nd.gabor ? dispatch<true>(nd, ld, a, mode, grid, st) : dispatch<false>(nd, ld, a, mode, grid, st);
 }
 

@@ -25,6 +25,7 @@ struct MlpArgs {
   int save_by_block;   // 1: stash slot = blockIdx (fused); 0: slot = tile
   int dw_gemm;         // 1: leave dZ_l of the hidden-width layers in the stash for inr_dw_gemm.hip, skip their dW passes
   long long* dbg;      // diagnostic builds (-DINR_STAMPS) only: per-wave phase time stamps
+  long long dbg_cap;   // entries behind dbg (a stamp past it is dropped)
 };
 
 

@@ -587,13 +587,10 @@ template <int NB, int NW, int MODE>
 inline hipError_t launch_mlp_bf16(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int grid, hipStream_t st) {
   const size_t lds_bytes = ((size_t)NW * NB * 32 * INR_LDS_LD + 3 * (size_t)nd.E + 3 * NW * 32) * sizeof(float);
   auto k = inr_mlp_bf16_kernel<NB, NW, MODE>;
-  static thread_local bool attr_set = false;
   if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       160 * 1024);
+  {
+    hipError_t e = allow_full_lds<inr_mlp_bf16_kernel<NB, NW, MODE>>();
     if (e != hipSuccess) return e;
-    attr_set = true;
   }
   hipLaunchKernelGGL(k, dim3(grid), dim3(NW * 64), lds_bytes, st, nd, ld, a);
   return hipGetLastError();

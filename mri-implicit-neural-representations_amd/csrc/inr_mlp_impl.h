@@ -754,12 +754,13 @@ __device__ __forceinline__ void dw_pass(const float* Rall, int region_stride, BS
 // Diagnostic phase stamps (never compiled into the shipped library): s_memtime per wave at phase
 // boundaries, written to a buffer nothing else reads.
 #ifdef INR_STAMPS
-#define INR_STAMP(i)                                                                     \
-  do {                                                                                   \
-    __builtin_amdgcn_sched_barrier(0);                                                   \
-    if (a.dbg != nullptr && lane == 0)                                                   \
-      a.dbg[(blockIdx.x * NW + w) * 64 + (i)] = (long long)__builtin_amdgcn_s_memtime(); \
-    __builtin_amdgcn_sched_barrier(0);                                                   \
+#define INR_STAMP(i)                                                                               \
+  do {                                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+    const long long stamp_at_ = ((long long)blockIdx.x * NW + w) * 64 + (i);                       \
+    if (a.dbg != nullptr && lane == 0 && (i) < 64 && stamp_at_ < a.dbg_cap)                       \
+      a.dbg[stamp_at_] = (long long)__builtin_amdgcn_s_memtime();                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
   } while (0)
 #else
 #define INR_STAMP(i) \
@@ -1051,17 +1052,14 @@ template <int NB, int NW, int INMODE, int HACT, int MODE>
 inline hipError_t launch_mlp(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int grid, hipStream_t st) {
   const size_t lds_bytes = ((size_t)NW * NB * 32 * INR_LDS_LD + 3 * (size_t)nd.E) * sizeof(float);
   auto k = inr_mlp_kernel<NB, NW, INMODE, HACT, MODE>;
-  static thread_local bool attr_set = false;
   if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
 #ifdef INR_DWG_STATIC  // the kernel has no in-kernel dW passes for layers the GEMM can take: the caller must run it
   if (MODE != MODE_FWD && HACT != ACT_GABOR2D && !a.dw_gemm && (nd.D > 2 || INMODE == IN_GAUSS))
     return hipErrorInvalidValue;
 #endif
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       160 * 1024);
+  {
+    hipError_t e = allow_full_lds<inr_mlp_kernel<NB, NW, INMODE, HACT, MODE>>();
     if (e != hipSuccess) return e;
-    attr_set = true;
   }
   hipLaunchKernelGGL(k, dim3(grid), dim3(NW * 64), lds_bytes, st, nd, ld, a);
   return hipGetLastError();

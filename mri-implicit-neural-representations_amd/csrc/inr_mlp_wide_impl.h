@@ -364,15 +364,12 @@ template <int NB, int INMODE, int HACT, int MODE>
 inline hipError_t launch_mlp_wide(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int grid, hipStream_t st) {
   const size_t lds_bytes = ((size_t)2 * NB * 32 * INR_LDS_LD + (INMODE == IN_GAUSS ? 3 * (size_t)nd.E : 0)) * sizeof(float);
   auto k = inr_mlp_wide_kernel<NB, INMODE, HACT, MODE>;
-  static thread_local bool attr_set = false;
   if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
   // backward has no dW passes for the hidden-width layers: the caller runs the batch GEMM on the stash
   if (MODE != MODE_FWD && !a.dw_gemm && (nd.D > 2 || INMODE == IN_GAUSS)) return hipErrorInvalidValue;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       160 * 1024);
+  {
+    hipError_t e = allow_full_lds<inr_mlp_wide_kernel<NB, INMODE, HACT, MODE>>();
     if (e != hipSuccess) return e;
-    attr_set = true;
   }
   hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds_bytes, st, nd, ld, a);
   return hipGetLastError();

@@ -36,7 +36,12 @@ class LossDesc(C.Structure):
                 ("cons_inv", C.c_float * 4)]
 
 
-ABI_VERSION = 2  # INR_ABI_VERSION of include/inr_abi.h
+ABI_VERSION = 3  # INR_ABI_VERSION of include/inr_abi.h
+
+
+class Workspace(C.Structure):
+    """inr_workspace: a call's caller-owned scratch with its extents (floats)."""
+    _fields_ = [("save", C.c_void_p), ("save_floats", C.c_int64), ("slabs", C.c_void_p), ("slab_floats", C.c_int64)]
 
 
 class Sizes(C.Structure):
@@ -58,18 +63,19 @@ SYMBOLS = {
     "inr_pack_params": (C.c_int, [_P, _P, _P, _P]),
     "inr_encode_gauss": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P]),
     "inr_encode_logf": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P]),
-    "inr_forward": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, _P, _P, _P]),
-    "inr_backward": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, _P, _P, _P, _P, _P]),
+    "inr_forward": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, _P, C.POINTER(Workspace), _P]),
+    "inr_backward": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, _P, C.POINTER(Workspace), _P, _P]),
     "inr_loss_grad": (C.c_int, [C.POINTER(LossDesc), _P, _P, _P, _P, C.c_int64, _P, _P, _P]),
     "inr_loss_grad_multi": (C.c_int, [C.POINTER(LossDesc), _P, _P, _P, _P, C.c_int32, C.c_int64, _P, _P, _P]),
     "inr_tv_grad": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_float, _P, _P, _P]),
-    "inr_train_step": (C.c_int, [_P, C.POINTER(LossDesc), _P, _P, _P, _P, _P, _P, C.c_int64, _P, _P, _P, _P, _P]),
+    "inr_train_step": (C.c_int, [_P, C.POINTER(LossDesc), _P, _P, _P, _P, _P, _P, C.c_int64, C.POINTER(Workspace), _P,
+                                 _P, _P]),
     "inr_plan_heads": (C.c_int, [_P, C.POINTER(C.c_int32)]),
     "inr_plan_set_bounds": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int32]),
-    "inr_forward_multi": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, _P, _P, C.c_int32, _P]),
-    "inr_backward_multi": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, _P, _P, _P, _P, _P]),
-    "inr_train_step_multi": (C.c_int, [_P, C.POINTER(LossDesc), _P, _P, _P, _P, _P, _P, _P, C.c_int64, _P, _P, _P,
-                                       _P, _P]),
+    "inr_forward_multi": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, _P, C.POINTER(Workspace), C.c_int32, _P]),
+    "inr_backward_multi": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, _P, C.POINTER(Workspace), _P, _P]),
+    "inr_train_step_multi": (C.c_int, [_P, C.POINTER(LossDesc), _P, _P, _P, _P, _P, _P, _P, C.c_int64,
+                                       C.POINTER(Workspace), _P, _P, _P]),
     "inr_adam_step": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_double, C.c_double, C.c_double, C.c_double,
                                 C.c_double, C.c_double, C.c_double, C.c_int32, _P]),
 }

@@ -36,6 +36,13 @@ class LossSpec:
                         float(opts.get("hdr_ff_factor", 0.5)))
 
 
+def _shape(t: Optional[torch.Tensor], name: str, *shape) -> None:
+    """Raise unless ``t`` has exactly this shape (the kernels index by these extents: a short tensor would be an
+    out-of-bounds GPU read, a [B,512] tensor passed where [B,3] is expected garbage without an error)."""
+    if t is not None and tuple(t.shape) != tuple(shape):
+        raise RuntimeError(f"{name} has shape {tuple(t.shape)}, expected {tuple(shape)}")
+
+
 def _ptr(t: Optional[torch.Tensor], name: str, dtype=torch.float32) -> Optional[int]:
     if t is None:
         return None
@@ -137,33 +144,56 @@ class MLPEngine:
             self._slabs = torch.empty(need, device=self.params.device)
         return self._slabs
 
+    def _ws(self, save_slots: int, n_slabs: int):
+        """inr_workspace of a call: the buffers AND their extents, which the library checks against the plan."""
+        ws = L.Workspace()
+        if save_slots > 0:
+            sv = self._ws_save(save_slots)
+            ws.save, ws.save_floats = _ptr(sv, "save"), sv.numel()
+        if n_slabs > 0:
+            sl = self._ws_slabs(n_slabs)
+            ws.slabs, ws.slab_floats = _ptr(sl, "slabs"), sl.numel()
+        return ws
+
+    def _check_input(self, x: torch.Tensor, enc_B: Optional[torch.Tensor]) -> int:
+        B = int(x.shape[0])
+        if self.input_mode == L.INPUT_GAUSS:
+            _shape(x, "coords", B, 3)
+            if enc_B is None:
+                raise RuntimeError("enc_B is required: this engine fuses the gauss Positional_Encoder")
+            _shape(enc_B, "enc_B", self.in_features // 2, 3)
+        else:
+            _shape(x, "x", B, self.in_features)
+        return B
+
     # ---- kernels ------------------------------------------------------------------------------
     def pack(self) -> None:
         L.check(self.lib.inr_pack_params(self.plan, _ptr(self.params, "params"), _ptr(self.packed, "packed"),
                                          self._stream()))
 
     def forward(self, x: torch.Tensor, enc_B: Optional[torch.Tensor] = None, save: bool = False) -> torch.Tensor:
-        B = x.shape[0]
+        B = self._check_input(x, enc_B)
         nt, _ = self.launch_dims(B)
         out = torch.empty(B, self.out_features, device=x.device)
-        sv = self._ws_save(nt) if (save or self.always_save) else None
+        saving = save or self.always_save
+        ws = self._ws(nt if saving else 0, 0)
         L.check(self.lib.inr_forward(self.plan, _ptr(self.params, "params"), _ptr(self.packed, "packed"),
                                      _ptr(x, "x"), _ptr(enc_B, "enc_B"), B, _ptr(out, "out"),
-                                     _ptr(sv, "save"), self._stream()))
-        self._stash_rows = B if sv is not None else None
+                                     C.byref(ws), self._stream()))
+        self._stash_rows = B if saving else None
         return out
 
     def backward(self, x: torch.Tensor, enc_B: Optional[torch.Tensor], dout: torch.Tensor) -> torch.Tensor:
         """d(loss)/d(params) for the most recent forward(save=True) on the same x.  Consumes the stash (the
         weight-gradient GEMM's operands overwrite the stashed activation derivatives): one backward per forward."""
-        B = x.shape[0]
+        B = self._check_input(x, enc_B)
+        _shape(dout, "dout", B, self.out_features)
         self._take_stash(B)
         nt, _ = self.launch_dims(B)
-        slabs = self._ws_slabs(self.workspace(B)[1])
+        ws = self._ws(nt, self.workspace(B)[1])
         L.check(self.lib.inr_backward(self.plan, _ptr(self.params, "params"), _ptr(self.packed, "packed"),
                                       _ptr(x, "x"), _ptr(enc_B, "enc_B"), B, _ptr(dout, "dout"),
-                                      _ptr(self._ws_save(nt), "save"), _ptr(slabs, "slabs"),
-                                      _ptr(self.grads, "grads"), self._stream()))
+                                      C.byref(ws), _ptr(self.grads, "grads"), self._stream()))
         return self.grads
 
     def loss_desc(self, spec: LossSpec, count: int, hdr_A: float = 0.0) -> L.LossDesc:
@@ -174,6 +204,9 @@ class MLPEngine:
                   mask: Optional[torch.Tensor] = None, hdr_A: float = 0.0):
         """Tier-1 loss: returns (loss scalar tensor view, dout [B,2])."""
         B = out.shape[0]
+        _shape(out, "out", B, 2)
+        _shape(gt, "gt", B, 2)
+        _shape(mask, "mask", B)
         dout = torch.empty_like(out)
         ld = self.loss_desc(spec, count, hdr_A)
         L.check(self.lib.inr_loss_grad(C.byref(ld), _ptr(out, "out"), _ptr(gt, "gt"), None,
@@ -196,14 +229,15 @@ class MLPEngine:
                    count: Optional[int] = None, mask: Optional[torch.Tensor] = None, hdr_A: float = 0.0):
         """Fused encode -> forward -> loss -> backward (stages of train.py:163-189).  Leaves the
         un-reduced-across-ranks gradient in self.grads and returns the loss scalar (device)."""
-        B = x.shape[0]
+        B = self._check_input(x, enc_B)
+        _shape(gt, "gt", B, self.out_features)
+        _shape(mask, "mask", B)
         self._stash_rows = None  # the fused step writes (and consumes) the same stash buffer
-        slots, n_slabs = self.workspace(B)
+        ws = self._ws(*self.workspace(B))
         ld = self.loss_desc(spec, B if count is None else count, hdr_A)
         L.check(self.lib.inr_train_step(self.plan, C.byref(ld), _ptr(self.params, "params"),
                                         _ptr(self.packed, "packed"), _ptr(x, "x"), _ptr(enc_B, "enc_B"),
-                                        _ptr(gt, "gt"), _ptr(mask, "mask", torch.uint8), B,
-                                        _ptr(self._ws_save(slots), "save"), _ptr(self._ws_slabs(n_slabs), "slabs"),
+                                        _ptr(gt, "gt"), _ptr(mask, "mask", torch.uint8), B, C.byref(ws),
                                         _ptr(self.grads, "grads"), _ptr(self._loss, "loss"), self._stream()))
         return self._loss[0]
 
@@ -251,8 +285,12 @@ class MFNEngine(MLPEngine):
     MultiscaleKFourier).  Heads come back as one [n_heads, B, out] tensor."""
 
     def __init__(self, kind: int, in_features: int, width: int, depth: int, out_features: int, enc_size: int,
-                 bounds=None):
-        super().__init__(kind, in_features, width, depth, out_features, L.ACT_ID, L.INPUT_GAUSS, enc_size, 0.0)
+                 bounds=None, input_mode: int = L.INPUT_GAUSS):
+        """input_mode INPUT_GAUSS: called on raw coordinates [B,3] with the encoder matrix (the gauss encoder is
+        fused into the filters); INPUT_X: called on the encoded x [B,in_features] like the reference's forward
+        (mfn.py:34-43), enc_B is None."""
+        super().__init__(kind, in_features, width, depth, out_features, L.ACT_ID, input_mode,
+                         enc_size if input_mode == L.INPUT_GAUSS else 0, 0.0)
         nh = C.c_int32()
         L.check(self.lib.inr_plan_heads(self.plan, C.byref(nh)))
         self.n_heads = int(nh.value)
@@ -263,27 +301,29 @@ class MFNEngine(MLPEngine):
 
     def forward(self, coords: torch.Tensor, enc_B: torch.Tensor, save: bool = False,
                 dist: Optional[torch.Tensor] = None) -> torch.Tensor:
-        B = coords.shape[0]
+        B = self._check_input(coords, enc_B)
+        _shape(dist, "dist", B)
         nt, nb = self.launch_dims(B)
         out = torch.empty(self.n_heads, B, self.out_features, device=coords.device)
-        sv = self._ws_save(nt if save else nb)
+        ws = self._ws(nt if save else nb, 0)
         L.check(self.lib.inr_forward_multi(self.plan, _ptr(self.params, "params"), _ptr(self.packed, "packed"),
                                            _ptr(coords, "coords"), _ptr(enc_B, "enc_B"), _ptr(dist, "dist"), B,
-                                           _ptr(out, "out"), _ptr(sv, "save"), 0 if save else 1, self._stream()))
+                                           _ptr(out, "out"), C.byref(ws), 0 if save else 1, self._stream()))
         self._stash_rows = B if save else None
         return out
 
     def backward(self, coords: torch.Tensor, enc_B: torch.Tensor, dout: torch.Tensor,
                  dist: Optional[torch.Tensor] = None) -> torch.Tensor:
-        B = coords.shape[0]
+        B = self._check_input(coords, enc_B)
+        _shape(dist, "dist", B)
+        _shape(dout, "dout", self.n_heads, B, self.out_features)
         self._take_stash(B)
         nt, nb = self.launch_dims(B)
+        ws = self._ws(nt, self.workspace(B)[1])
         L.check(self.lib.inr_backward_multi(self.plan, _ptr(self.params, "params"), _ptr(self.packed, "packed"),
                                             _ptr(coords, "coords"), _ptr(enc_B, "enc_B"), _ptr(dist, "dist"), B,
-                                            _ptr(dout, "dout"),
-                                            _ptr(self._ws_save(nt), "save"),
-                                            _ptr(self._ws_slabs(self.workspace(B)[1]), "slabs"),
-                                            _ptr(self.grads, "grads"), self._stream()))
+                                            _ptr(dout, "dout"), C.byref(ws), _ptr(self.grads, "grads"),
+                                            self._stream()))
         return self.grads
 
     def multi_loss_desc(self, spec: LossSpec, count: int, hdr_A: float = 0.0, scale: float = 1.0,
@@ -305,6 +345,10 @@ class MFNEngine(MLPEngine):
         """Tier-1 multiscale loss (train_kspace_multiscale.py:176-195) on outs [n_heads,B,2]: returns (loss scalar
         view, douts [n_heads,B,2]).  Pointwise terms on rows with mask != 0, consistency on every row."""
         NH, B = outs.shape[0], outs.shape[1]
+        _shape(outs, "outs", NH, B, 2)
+        _shape(gt, "gt", B, 2)
+        _shape(mask, "mask", B)
+        _shape(dist, "dist", B)
         douts = torch.empty_like(outs)
         ld = self.multi_loss_desc(spec, count, 0.0, scale, cons)
         L.check(self.lib.inr_loss_grad_multi(C.byref(ld), _ptr(outs, "outs"), _ptr(gt, "gt"), _ptr(dist, "dist"),
@@ -316,16 +360,16 @@ class MFNEngine(MLPEngine):
                    count: Optional[int] = None, mask: Optional[torch.Tensor] = None, hdr_A: float = 0.0,
                    dist: Optional[torch.Tensor] = None, scale: float = 1.0,
                    cons: Optional[ConsistencySpec] = None):
-        B = coords.shape[0]
+        B = self._check_input(coords, enc_B)
+        _shape(gt, "gt", B, self.out_features)
+        _shape(mask, "mask", B)
+        _shape(dist, "dist", B)
         self._stash_rows = None
-        _, nb = self.launch_dims(B)
-        slots, n_slabs = self.workspace(B)
+        ws = self._ws(*self.workspace(B))
         ld = self.multi_loss_desc(spec, B if count is None else count, hdr_A, scale, cons)
         L.check(self.lib.inr_train_step_multi(self.plan, C.byref(ld), _ptr(self.params, "params"),
                                               _ptr(self.packed, "packed"), _ptr(coords, "coords"),
                                               _ptr(enc_B, "enc_B"), _ptr(gt, "gt"), _ptr(dist, "dist"),
-                                              _ptr(mask, "mask", torch.uint8), B,
-                                              _ptr(self._ws_save(slots), "save"),
-                                              _ptr(self._ws_slabs(n_slabs), "slabs"), _ptr(self.grads, "grads"),
-                                              _ptr(self._loss, "loss"), self._stream()))
+                                              _ptr(mask, "mask", torch.uint8), B, C.byref(ws),
+                                              _ptr(self.grads, "grads"), _ptr(self._loss, "loss"), self._stream()))
         return self._loss[0]

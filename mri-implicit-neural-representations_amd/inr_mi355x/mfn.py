@@ -3,12 +3,18 @@
 ``MultiscaleBoundedFourier`` (:288-355).  Same constructor signature, RNG
 order, state_dict keys / order (``linear.*``, ``output_linear(.k).*``, ``filters.k.linear.*``).
 
-The MI355X kernel fuses the gauss encoder into every filter (the encoded [B,2E] input is never
-materialised), so the model is called on RAW coordinates after ``bind_encoder(encoder)``:
+Two ways to call a model, both on the hand-written kernels:
 
-    enc = Positional_Encoder(config['encoder'], device)      # consumes the RNG first, like train.py:52
-    model = MultiscaleKFourier(config['net']).to(device).bind_encoder(enc)
-    outs = model(coords, dist_to_center)                      # list of 4 [B,2] tensors (heads 1,3,5,7)
+  * the reference's own contract (train.py:163-169, mfn.py:34-43,85-94,255-267): ``model(x)`` on the ENCODED
+    input ``x = encoder.embedding(coords)`` [B, network_input_size], any encoder ('gauss' | 'LogF' | 'none'):
+
+        enc = Positional_Encoder(config['encoder'], device)      # consumes the RNG first, like train.py:52
+        model = MultiscaleKFourier(config['net']).to(device)
+        outs = model(coords=enc.embedding(coords), dist_to_center=dist)   # list of 4 [B,2] tensors (heads 1,3,5,7)
+
+  * fused: after ``model.bind_encoder(enc)`` ('gauss' only) the model may also be called on RAW coordinates
+    [B,3]; the kernel then generates the features itself and the [B,2E] tensor is never materialised.  The
+    trainers use this form (``fused_engine``).
 """
 from __future__ import annotations
 
@@ -24,27 +30,31 @@ from .networks import _FlatModel, _Holder, _view
 
 class _MFNFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, module, coords, dist, *params):
-        eng = module._engine()
+    def forward(ctx, module, x, dist, *params):
+        mode = module._mode_of(x)
+        eng = module._engine(mode)
         eng.pack()
         need_grad = any(ctx.needs_input_grad[3:])
-        coords = coords.contiguous()
+        x = x.contiguous()
         dist = dist.reshape(-1).contiguous() if dist is not None else None
-        out = eng.forward(coords, module._enc_B, save=need_grad, dist=dist)
-        ctx.module = module
-        ctx.dist = dist
-        ctx.save_for_backward(coords)
+        enc_B = module._enc_B if mode == "gauss" else None
+        out = eng.forward(x, enc_B, save=need_grad, dist=dist)
+        ctx.module, ctx.dist, ctx.mode = module, dist, mode
+        ctx.save_for_backward(x)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        (coords,) = ctx.saved_tensors
+        (x,) = ctx.saved_tensors
         module = ctx.module
-        eng = module._engine()
-        flat_grad = eng.backward(coords, module._enc_B, dout.contiguous(), dist=ctx.dist)
+        eng = module._engine(ctx.mode)
+        enc_B = module._enc_B if ctx.mode == "gauss" else None
+        flat_grad = eng.backward(x, enc_B, dout.contiguous(), dist=ctx.dist)
         grads = []
         for (o, n, s, c), live in zip(module._layout, module._live):
-            grads.append(_view(flat_grad, o, n, s, c) if live else None)  # dead layers: grad None, like autograd
+            # clones: the engine's gradient buffer is reused by the next backward, and AccumulateGrad may adopt
+            # what it is handed as .grad; dead layers: grad None, like autograd
+            grads.append(_view(flat_grad, o, n, s, c).clone() if live else None)
         return (None, None, None, *grads)
 
 
@@ -76,6 +86,7 @@ class _MFNBase(_FlatModel):
     _multiscale = False
     _bounds = None
     _gabor = None  # (alpha, beta) of the GaborLayer gamma prior, or None for Fourier filters
+    _output_act = False  # mfn.py:40-41: torch.sin on the output (single-head classes only)
 
     def _build_mfn(self, params, filter_scale: float, weight_scale: float):
         n = params["network_depth"]
@@ -149,32 +160,61 @@ class _MFNBase(_FlatModel):
         self._live = live
 
     def bind_encoder(self, encoder) -> "_MFNBase":
+        """Optional: lets the model be called on raw coordinates [B,3] with the gauss encoder fused into the
+        filters (what the trainers do).  Without it the model takes the encoded input, like the reference's."""
         if encoder.embedding_type != "gauss":
-            raise NotImplementedError("the MFN kernels fuse the 'gauss' Positional_Encoder")
+            raise NotImplementedError("only the 'gauss' Positional_Encoder can be fused into the filters; call the "
+                                      "model on encoder.embedding(coords) instead")
+        if 2 * encoder.B.shape[0] != self._in:
+            raise RuntimeError(f"encoder gives {2 * encoder.B.shape[0]} features, network_input_size is {self._in}")
         self._enc_B = encoder.B.contiguous()
         self._eng = None
         return self
 
-    def _engine(self) -> MFNEngine:
+    def _mode_of(self, x: torch.Tensor) -> str:
+        """'x': the reference's contract, x = encoder.embedding(coords) [B, network_input_size];
+        'gauss': raw coordinates [B,3] with the bound encoder fused."""
+        if x.dim() != 2:
+            raise RuntimeError(f"model input must be [B, features], got {tuple(x.shape)}")
+        if x.shape[1] == self._in:
+            return "x"
+        if self._enc_B is not None and x.shape[1] == self._enc_B.shape[1]:
+            return "gauss"
+        raise RuntimeError(f"model input has {x.shape[1]} features: expected the encoded input [B,{self._in}] "
+                           "(encoder.embedding(coords), train.py:163-169)"
+                           + ("" if self._enc_B is None else f" or raw coordinates [B,{self._enc_B.shape[1]}]"))
+
+    def _engine(self, mode: Optional[str] = None) -> MFNEngine:
         if not self._flat.is_cuda:
             raise RuntimeError("inr_mi355x models run on an MI355X only: call .to('cuda') first (no CPU fallback)")
-        if self._enc_B is None:
-            raise RuntimeError("call bind_encoder(Positional_Encoder(...)) first: the gauss encoder is fused into the "
-                               "filters and the model is evaluated on raw coordinates")
+        if mode is None:
+            mode = "gauss" if self._enc_B is not None else "x"
+        if mode == "gauss" and self._enc_B is None:
+            raise RuntimeError("call bind_encoder(Positional_Encoder(...)) first to run on raw coordinates")
         if self._eng is None:
+            self._eng = {}
+        if mode not in self._eng:
             from . import _lib as L
             kind = L.KIND_MSBOUNDED if self._bounds is not None else (L.KIND_MSFOURIER if self._multiscale else L.KIND_FOURIER)
             if self._gabor is not None:
                 kind = self._kind
-            self._eng = MFNEngine(kind, self._in, self._W, self._n, self._out, self._enc_B.shape[0], self._bounds)
-            self._eng.bind(self._flat)
-        return self._eng
+            if mode == "gauss":
+                eng = MFNEngine(kind, self._in, self._W, self._n, self._out, self._enc_B.shape[0], self._bounds)
+            else:
+                eng = MFNEngine(kind, self._in, self._W, self._n, self._out, 0, self._bounds, input_mode=L.INPUT_X)
+            eng.bind(self._flat)
+            self._eng[mode] = eng
+        return self._eng[mode]
 
     def fused_engine(self, enc_size: int) -> MFNEngine:
-        return self._engine()
+        return self._engine("gauss")
 
-    def _heads(self, coords, dist=None):
-        return _MFNFunction.apply(self, coords, dist, *self._flat_params)
+    def _heads(self, x, dist=None):
+        return _MFNFunction.apply(self, x, dist, *self._flat_params)
+
+    def _single(self, x):
+        out = self._heads(x)[0]
+        return torch.sin(out) if self._output_act else out  # MFNBase.forward, mfn.py:40-41
 
 
 class FourierNet(_MFNBase):
@@ -182,12 +222,11 @@ class FourierNet(_MFNBase):
 
     def __init__(self, params, out_size=1.0, input_scale=2.0, weight_scale=1.0, bias=True, output_act=False):
         super().__init__()
-        if output_act:
-            raise NotImplementedError("output_act")
+        self._output_act = bool(output_act)
         self._build_mfn(params, input_scale / np.sqrt(params["network_depth"] + 1), weight_scale)
 
     def forward(self, x, dist_to_center=None):
-        return self._heads(x)[0]
+        return self._single(x)
 
 
 class GaborNet(_MFNBase):
@@ -196,8 +235,7 @@ class GaborNet(_MFNBase):
 
     def __init__(self, params, input_scale=2, weight_scale=1.0, alpha=6.0, beta=1.0, bias=True, output_act=False):
         super().__init__()
-        if output_act:
-            raise NotImplementedError("output_act")
+        self._output_act = bool(output_act)
         from . import _lib as L
         self._kind = L.KIND_KGABOR if isinstance(self, KGaborNet) else L.KIND_GABOR
         n = params["network_depth"]
@@ -205,7 +243,7 @@ class GaborNet(_MFNBase):
         self._build_mfn(params, input_scale / np.sqrt(n + 1), weight_scale)
 
     def forward(self, x, dist_to_center=None):
-        return self._heads(x)[0]
+        return self._single(x)
 
 
 class KGaborNet(GaborNet):
@@ -213,7 +251,7 @@ class KGaborNet(GaborNet):
     (with_dist_filtering stays False), so the arithmetic is GaborNet's."""
 
     def forward(self, x, dist_to_center=None):
-        return self._heads(x)[0]
+        return self._single(x)
 
 
 class MultiscaleKFourier(_MFNBase):
@@ -228,7 +266,7 @@ class MultiscaleKFourier(_MFNBase):
             raise NotImplementedError("output_layers other than [1,3,5,7]")
         self._build_mfn(params, weight_scale / np.sqrt(params["network_depth"] + 1), weight_scale)
 
-    def forward(self, coords, dist_to_center=None, **kw):
+    def forward(self, coords, dist_to_center=None, **kw):  # output_act is ignored here, as in mfn.py:255-267
         h = self._heads(coords)
         return [h[k] for k in range(h.shape[0])]
 

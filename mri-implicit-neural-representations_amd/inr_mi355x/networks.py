@@ -75,7 +75,9 @@ class _MLPFunction(torch.autograd.Function):
         module = ctx.module
         eng = module._engine()
         flat_grad = eng.backward(x, None, dout.contiguous())
-        grads = [_view(flat_grad, o, n, s, c) for (o, n, s, c) in module._layout]
+        # clones: the engine's gradient buffer is reused by the next backward, and AccumulateGrad may adopt what it
+        # is handed as .grad (a second backward without zero_grad must accumulate, not overwrite)
+        grads = [_view(flat_grad, o, n, s, c).clone() for (o, n, s, c) in module._layout]
         return (None, None, *grads)
 
 

@@ -108,10 +108,15 @@ class INRTrainer:
         self.model = MODELS[config["model"]](config["net"]).to(self.device)
         emb = config["encoder"]["embedding"]
         self.is_mfn = config["model"] in MFN_MODELS
-        if self.is_mfn:  # the gauss encoder is fused into every filter: the model runs on raw coordinates
+        if self.is_mfn and getattr(self.model, "_output_act", False):
+            raise NotImplementedError("output_act in the fused training step (no shipped config sets it)")
+        if self.is_mfn and emb == "gauss":  # fused into every filter: the model runs on raw coordinates
             self.model.bind_encoder(self.encoder)
-            self.engine = self.model._engine()
+            self.engine = self.model._engine("gauss")
             self.enc_B = self.encoder.B.contiguous()
+        elif self.is_mfn:  # 'LogF' / 'none': the filters read encoder.embedding(coords) from memory
+            self.engine = self.model._engine("x")
+            self.enc_B = None
         elif emb == "gauss":  # config["precision"]: "f32" (parity path, default) | "bf16" (throughput path)
             self.engine = self.model.fused_engine(config["encoder"]["embedding_size"],
                                                   **({"precision": config["precision"]} if "precision" in config else {}))
@@ -125,6 +130,10 @@ class INRTrainer:
         self.l2 = float(reg["strenght"]) if reg["type"] == "L2" else 0.0
         if reg["type"] not in ("none", "L1", "L2"):
             raise NotImplementedError(f"regularization {reg['type']!r}")
+        if (self.l1 or self.l2) and config["model"] in ("WIRE", "WIRE2D"):
+            # regularization.py:21-36 on complex64 tensors means sum |z| (L1) and |sum z^2| (L2, a complex square):
+            # the Adam kernel's per-component sign / 2p terms are the REAL-parameter forms
+            raise NotImplementedError("L1 / L2 regularization with complex-weight models (WIRE, WIRE2D)")
         # undersampled fit (models/utils.py:102-123): train on the zero-filled k-space with the loss on
         # sampled rows only; validation still compares with the full k-space (val_loader, utils.py:131-137)
         self.image_full = image.to(self.device).contiguous()
@@ -184,9 +193,19 @@ class INRTrainer:
             loss = self._tv_step(lo, count, A)
         else:
             slo, shi = shard_rows(lo, hi, self.rank, self.world)
-            m = self.mask[slo:shi] if self.mask is not None else None
-            loss = self._fused(slo, shi, count, m, A)
+            if shi == slo:  # a short last batch can leave a rank without rows: it contributes zeros to the sum
+                self.engine.grads.zero_()
+                loss = torch.zeros((), device=self.device)
+            else:
+                m = self.mask[slo:shi] if self.mask is not None else None
+                loss = self._fused(slo, shi, count, m, A)
         loss = allreduce_step_outputs(self.engine.grads, loss, self.world, self.pg, self.engine.gbuf)
+        # the loss the reference logs includes the penalty VALUE (train.py:185-192); its gradient is formed inside
+        # the Adam kernel.  Every rank holds the same parameters: added once, after the all-reduce.
+        if self.l1:
+            loss = loss + self.l1 * self.engine.params.abs().sum()
+        if self.l2:
+            loss = loss + self.l2 * (self.engine.params * self.engine.params).sum()
         lr = self.config["lr"] * lr_factor(epoch, self.config["max_epoch"])
         self.engine.adam_step(lr, self.config["beta1"], self.config["beta2"], 1e-8, self.config["weight_decay"],
                               self.l1, self.l2)

@@ -60,9 +60,14 @@ class MultiscaleTrainer:
             self.model = MultiscaleBoundedFourier(config["net"], boundaries=create_pairs(list(radii), 2))
         else:
             self.model = MultiscaleKFourier(config["net"])
-        self.model = self.model.to(self.device).bind_encoder(self.encoder)
-        self.engine = self.model._engine()
-        self.enc_B = self.encoder.B.contiguous()
+        self.model = self.model.to(self.device)
+        if config["encoder"]["embedding"] == "gauss":  # fused into every filter: the kernels take raw coordinates
+            self.model.bind_encoder(self.encoder)
+            self.engine = self.model._engine("gauss")
+            self.enc_B = self.encoder.B.contiguous()
+        else:  # 'LogF' / 'none': the filters read encoder.embedding(coords) from memory (train_kspace_multiscale.py:169)
+            self.engine = self.model._engine("x")
+            self.enc_B = None
         self.pairs = create_pairs(list(radii), 1)
         # undersampling / per-coil batches / TV as in the single-scale loop (models/utils.py:102-123;
         # train_kspace_multiscale.py:173-182)
@@ -91,6 +96,9 @@ class MultiscaleTrainer:
         if "pretrain" in config:
             self.load_checkpoint(torch.load(config["pretrain"], map_location=self.device))
 
+    def _inputs(self, lo: int, hi: int) -> torch.Tensor:
+        return self.coords[lo:hi] if self.enc_B is not None else self.encoder.embedding(self.coords[lo:hi]).contiguous()
+
     def _cons_spec(self, it: int, lo: int, hi: int) -> ConsistencySpec:
         if it not in self._cons:
             d = self.dist_cpu[lo:hi]
@@ -113,7 +121,7 @@ class MultiscaleTrainer:
             return torch.zeros((), device=self.device)
         ye = min(y1 + 1, H)
         slo, sown, shi = lo + y0 * W, lo + y1 * W, lo + ye * W
-        x, d = self.coords[slo:shi], self.dist[slo:shi]
+        x, d = self._inputs(slo, shi), self.dist[slo:shi]
         outs = self.engine.forward(x, self.enc_B, save=True, dist=d)
         m = torch.ones(shi - slo, dtype=torch.uint8, device=self.device) if self.mask is None else self.mask[slo:shi].clone()
         d_loss = d
@@ -134,9 +142,14 @@ class MultiscaleTrainer:
             loss = self._tv_step(it, lo, hi, count)
         else:
             slo, shi = shard_rows(lo, hi, self.rank, self.world)
-            loss = self.engine.train_step(self.coords[slo:shi], self.enc_B, self.image[slo:shi], self.loss,
-                                          count=count, mask=None if self.mask is None else self.mask[slo:shi],
-                                          dist=self.dist[slo:shi], scale=self.scale, cons=self._cons_spec(it, lo, hi))
+            if shi == slo:  # a short last batch can leave a rank without rows: it contributes zeros to the sum
+                self.engine.grads.zero_()
+                loss = torch.zeros((), device=self.device)
+            else:
+                loss = self.engine.train_step(self._inputs(slo, shi), self.enc_B, self.image[slo:shi], self.loss,
+                                              count=count, mask=None if self.mask is None else self.mask[slo:shi],
+                                              dist=self.dist[slo:shi], scale=self.scale,
+                                              cons=self._cons_spec(it, lo, hi))
         loss = allreduce_step_outputs(self.engine.grads, loss, self.world, self.pg, self.engine.gbuf)
         lr = self.config["lr"] * lr_factor(epoch, self.config["max_epoch"])
         self.engine.adam_step(lr, self.config["beta1"], self.config["beta2"], 1e-8, self.config["weight_decay"])
@@ -153,8 +166,9 @@ class MultiscaleTrainer:
         from .checkpoint import load_dict
 
         def rebind(enc):
-            self.enc_B = enc.B.contiguous()
-            self.model._enc_B = self.enc_B
+            if self.enc_B is not None:
+                self.enc_B = enc.B.contiguous()
+                self.model._enc_B = self.enc_B
 
         load_dict(self.model, self.encoder, self.engine, ckpt, rebind)
 
@@ -175,7 +189,7 @@ class MultiscaleTrainer:
         outs = []
         for lo in range(0, self.n, chunk):
             hi = min(lo + chunk, self.n)
-            outs.append(self.engine.forward(self.coords[lo:hi], self.enc_B, save=False, dist=self.dist[lo:hi])[-1])
+            outs.append(self.engine.forward(self._inputs(lo, hi), self.enc_B, save=False, dist=self.dist[lo:hi])[-1])
         return torch.cat(outs, 0)
 
     @torch.no_grad()

@@ -26,3 +26,18 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def record_parity(test: str, **values) -> None:
+    """Append the measured errors behind a parity criterion (e_gpu = HIP path vs float64 oracle, e_cpu = the oracle's
+    own fp32 evaluation vs float64, ...) to gpurun_out/parity_errors.jsonl, so the margins the criteria leave are
+    on record (profiles/r*_parity_errors.jsonl is a committed copy).  Never fails a test."""
+    import json
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "parity_errors.jsonl"), "a") as f:
+            f.write(json.dumps(dict(test=test, **{k: (float(v) if isinstance(v, (int, float)) else v)
+                                                  for k, v in values.items()})) + "\n")
+    except OSError:
+        pass

@@ -1,0 +1,352 @@
+"""The five BASELINE.json configs at (or near) their real sizes -- ``-m gpu``.
+
+Each workload is pinned to the oracle (the CPU restatement of the reference's loop, itself pinned to the reference by
+tests/golden) on as many rows as the oracle finishes in seconds, and exercised at its full batch size through
+size-independent properties (gradient additivity over a ragged split, run-to-run determinism, data-parallel shards
+summing to the single-rank step).  Measured error pairs are appended to gpurun_out/parity_errors.jsonl.
+
+  config 1  SIREN 4x256 image-space fit of a 320x320 slice, L2 (train.py:139-141,221-229: transform True)
+  config 3  WIRE 4x256 (181 complex) + HDRLoss_FF at batch 25 000
+  config 4  MultiscaleKFourier 8x512, LSL (LogSpaceLoss x0.5) + 0.1 ConsistencyLoss at batch 100 000
+  config 5  radial acc 4 + per-coil batches (640x368 = 235 520 rows) + TV, fp32 and the bf16 path
+  (config 2 lives in test_gpu_parity.py: test_full_size_trajectory_vs_oracle, test_full_baseline_size_properties)
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+pytestmark = pytest.mark.gpu
+
+import oracle as O  # noqa: E402  (checker only)
+from conftest import record_parity  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _real(t):
+    return torch.view_as_real(t) if t.is_complex() else t
+
+
+def rel_l2(a, b):
+    a, b = _real(a).double().flatten(), _real(b).double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _cfg(name):
+    return yaml.safe_load(open(os.path.join(ROOT, "configs", name)))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# config 5: radial-4 undersampling + per-coil batches + TV (SIREN 5x256, one coil = 640 x 368 = 235 520 coordinates)
+# ---------------------------------------------------------------------------------------------------------------
+C5 = (2, 640, 368)
+
+
+def _config5(precision=None):
+    cfg = _cfg("config_siren_radial_tv_bf16.yaml")
+    assert cfg["undersampling"] == "radial-4" and cfg["per_coil"] and cfg["use_tv"] and cfg["precision"] == "bf16"
+    cfg = dict(cfg)
+    cfg.pop("precision")
+    if precision:
+        cfg["precision"] = precision
+    return cfg
+
+
+@pytest.fixture(scope="module")
+def c5_data():
+    from inr_mi355x.synthetic import make_kspace
+    return make_kspace(*C5, seed=1234, normalization="coil")
+
+
+def test_config5_percoil_radial_tv_vs_oracle(dev, c5_data):
+    """fp32: two per-coil steps (forward on all 235 520 rows, loss on the ~59 k sampled ones, TV on the whole coil
+    grid, train.py:158-192 with per_coil + use_tv + radial-4) against the oracle's loop on the same mask."""
+    from inr_mi355x.train import INRTrainer
+    image, coords, shape = c5_data
+    cfg = _config5()
+    tr = INRTrainer(cfg, image, coords, shape, dev, seed=0, mask_seed=7)
+    H, W = shape[1], shape[2]
+    assert tr.use_tv and tr.per_coil and tr.bs == H * W == 235520 and tr.steps_per_epoch == C5[0]
+    mask = tr.mask_cpu
+    acc = mask.numel() / float(mask.sum())
+    assert 3.5 < acc < 4.5, acc  # radial-4 (measured acceleration ~3.95)
+    sd = {k: v.detach().cpu().clone() for k, v in tr.model.state_dict().items()}
+    want = O.train_single_scale(cfg, sd, tr.encoder.B.cpu(), coords, image * mask[:, None], 2, mask=mask, grid_hw=(H, W))
+    got = np.array([s[1] for s in tr.fit(2, log_every=1)])
+    record_parity("config5:fp32", got=list(map(float, got)), want=list(map(float, want)))
+    np.testing.assert_allclose(got, np.array(want), rtol=2e-5)
+    flat = torch.cat([sd[k].reshape(-1) for k in tr.model.state_dict().keys()])  # the oracle stepped sd in place
+    e = rel_l2(tr.engine.params.cpu(), flat)
+    record_parity("config5:fp32", what="params after 2 steps", e_gpu=e)
+    assert e < 1e-5
+
+
+def test_config5_bf16_tracks_fp32(dev, c5_data):
+    """The bf16-MFMA path on the same per-coil + mask + TV step (unfused forward / loss + TV / backward on the bf16
+    kernels): gradient and loss of the first step at the bf16 tolerances of tests/test_gpu_bf16.py, deterministic."""
+    from inr_mi355x.train import INRTrainer
+    image, coords, shape = c5_data
+    a = INRTrainer(_config5(), image, coords, shape, dev, seed=0, mask_seed=7)
+    b = INRTrainer(_config5("bf16"), image, coords, shape, dev, seed=0, mask_seed=7)
+    count = int(a.mask_cpu[:a.bs].sum())
+    la = float(a._tv_step(0, count, 0.0))
+    lb = float(b._tv_step(0, count, 0.0))
+    ga, gb = a.engine.grads.clone(), b.engine.grads.clone()
+    e = rel_l2(gb, ga)
+    record_parity("config5:bf16", what="grad vs fp32", e_gpu=e, loss_f32=la, loss_bf16=lb)
+    assert abs(lb - la) <= 3e-2 * abs(la) and e < 6e-2, (la, lb, e)
+    assert float(b._tv_step(0, count, 0.0)) == lb and torch.equal(b.engine.grads, gb)
+    # both keep fitting
+    l2a = [s[1] for s in a.fit(3, log_every=1)]
+    l2b = [s[1] for s in b.fit(3, log_every=1)]
+    np.testing.assert_allclose(np.array(l2b), np.array(l2a), rtol=5e-2)
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+@pytest.mark.parametrize("world", [2, 3])
+def test_config5_halo_shards_sum_to_single_rank(dev, c5_data, world, precision):
+    """Data parallel per-coil TV step: image rows split over ranks, one halo row recomputed per rank;
+    the ranks' partial gradients and losses must add up to the single-rank step."""
+    from inr_mi355x.train import INRTrainer
+    image, coords, shape = c5_data
+    cfg = _config5(None if precision == "f32" else "bf16")
+    one = INRTrainer(cfg, image, coords, shape, dev, seed=0, mask_seed=7)
+    count = int(one.mask_cpu[:one.bs].sum())
+    l1 = float(one._tv_step(0, count, 0.0))
+    g1 = one.engine.grads.clone()
+    lsum, gsum = 0.0, torch.zeros_like(g1)
+    for r in range(world):
+        tr = INRTrainer(cfg, image, coords, shape, dev, seed=0, mask_seed=7, rank=r, world=world)
+        lsum += float(tr._tv_step(0, count, 0.0))
+        gsum += tr.engine.grads
+    tol = 5e-6 if precision == "f32" else 2e-2  # bf16: tiles regroup rows, bf16 slab partials round differently
+    e = rel_l2(gsum, g1)
+    record_parity(f"config5:halo:{precision}:w{world}", e_gpu=e, loss_1=l1, loss_sum=lsum)
+    assert abs(lsum - l1) <= tol * abs(l1) and e < tol, (l1, lsum, e)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# config 3: WIRE 4x256 + HDR at batch 25 000
+# ---------------------------------------------------------------------------------------------------------------
+def test_config3_wire_hdr_batch_25000(dev):
+    """WIRE depth 4 / width 256 (181 complex features = 384 interleaved rows, two-waves-per-group kernel + batch dW
+    GEMM) with HDRLoss_FF at the BASELINE batch: 25 000 rows = 391 64-row tiles on 256 persistent workgroups and
+    multi-chunk dW.  (i) gradient / loss against the oracle in float64 (criterion of test_gpu_wire.py: as close to
+    float64 as the oracle's own fp32 evaluation, x4); (ii) additivity over a ragged split; (iii) determinism."""
+    import inr_mi355x as M
+    cfg = _cfg("config_wire_kspace.yaml")
+    assert cfg["model"] == "WIRE" and cfg["loss"] == "HDR" and cfg["batch_size"] == 25000
+    net, opts = cfg["net"], cfg["loss_opts"]
+    torch.manual_seed(0)
+    model = M.WIRE(net)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.to(dev)
+    B = 25000
+    g = torch.Generator().manual_seed(3)
+    coords = torch.rand(B, 3, generator=g) * 2 - 1
+    gt = torch.randn(B, 2, generator=g) * 0.2
+    f = torch.exp(-(coords[:, 1].double() ** 2 + coords[:, 2].double() ** 2) / (2 * float(opts["hdr_ff_sigma"]) ** 2))
+    A = float(torch.mean((1 - f) ** 2))
+    keys = O.trainable_keys("WIRE", sd)
+    kind = "HDR"
+
+    def ref(dtype):
+        cd = torch.complex128 if dtype == torch.float64 else torch.complex64
+        params = {}
+        for k, v in sd.items():
+            v = v.to(cd) if v.is_complex() else v.to(dtype)
+            params[k] = v.clone().requires_grad_(True) if k in keys else v
+        out = O.wire_forward(params, coords.to(dtype), net).contiguous()
+        if kind == "HDR":
+            loss = O.loss_hdr(out, gt.to(dtype), coords.to(dtype), opts)[0]  # separable form: O(B) memory
+        else:
+            loss = O.loss_l2_half(out, gt.to(dtype))
+        grads = torch.autograd.grad(loss, [params[k] for k in keys])
+        return loss.detach(), torch.cat([_real(x).reshape(-1) for x in grads])
+
+    eng = model._engine()
+    nt, nb = eng.launch_dims(B)
+    assert nt > nb  # persistent workgroups walk several tiles
+    cd, gd = coords.to(dev), gt.to(dev)
+    # HDR's log^2(|e|/den) is near-singular on the rows where the error happens to be tiny: at this batch the
+    # reference's OWN fp32 gradient is ~10 % away from its float64 value, so the HDR pair mostly shows that the HIP
+    # path is no worse; the L2 pair on the same network is the sharp one.
+    for kind in ("L2", "HDR"):
+        l32, g32 = ref(torch.float32)
+        l64, g64 = ref(torch.float64)
+        spec = M.LossSpec.from_config({"loss": kind, "loss_opts": opts})
+        loss = float(eng.train_step(cd, None, gd, spec, hdr_A=A))
+        grad = eng.grads.clone()
+        e_gpu, e_cpu = rel_l2(grad.cpu(), g64), rel_l2(g32, g64)
+        le_gpu, le_cpu = abs(loss - float(l64)) / abs(float(l64)), abs(float(l32) - float(l64)) / abs(float(l64))
+        record_parity(f"config3:wire_{kind}_25000", e_gpu=e_gpu, e_cpu=e_cpu, loss_e_gpu=le_gpu, loss_e_cpu=le_cpu)
+        assert e_gpu <= max(4 * e_cpu, 1e-5), (kind, e_gpu, e_cpu)
+        assert le_gpu <= max(4 * le_cpu, 1e-5), (kind, le_gpu, le_cpu)
+    eng.train_step(cd, None, gd, spec, hdr_A=A)  # (spec, loss, grad: the HDR pass)
+    assert torch.equal(eng.grads, grad)
+    cut = 11111
+    la = float(eng.train_step(cd[:cut], None, gd[:cut], spec, count=B, hdr_A=A))
+    ga = eng.grads.clone()
+    lb = float(eng.train_step(cd[cut:], None, gd[cut:], spec, count=B, hdr_A=A))
+    e_add = rel_l2(ga + eng.grads, grad)
+    record_parity("config3:wire_hdr_25000", what="additivity", e_gpu=e_add)
+    assert abs(la + lb - loss) <= 5e-6 * abs(loss) and e_add < 5e-6
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# config 4: MultiscaleKFourier 8x512, LSL + 0.1 consistency, batch 100 000
+# ---------------------------------------------------------------------------------------------------------------
+RADII = [0.0, 0.2, 0.45, 0.8, 5.0]
+
+
+def _ms_oracle_step(sd, enc_B, coords, gt, dist, net, eps, dtype):
+    """One loss of train_kspace_multiscale.py:176-190 with LSL: 0.1 ConsistencyLoss + sum_k 0.5 LogSpaceLoss."""
+    keys = O.trainable_keys("MultiscaleKFourier", sd)
+    params = {k: (v.to(dtype).clone().requires_grad_(True) if k in keys else v.to(dtype)) for k, v in sd.items()}
+    x = O.encode(coords.to(dtype), enc_B.to(dtype), "gauss")
+    outs = O.model_forward("MultiscaleKFourier", params, x, net)
+    pairs = O.create_pairs(RADII, 1)
+    loss = 0.1 * O.loss_consistency(outs, dist.to(dtype), pairs)
+    for o in outs:
+        loss = loss + 0.5 * O.loss_logspace(o, gt.to(dtype), dict(hdr_eps=eps))
+    grads = torch.autograd.grad(loss, [params[k] for k in keys])
+    return loss.detach(), torch.cat([g.reshape(-1) for g in grads])
+
+
+def test_config4_multiscale_lsl_consistency(dev):
+    """The shipped config_fourier_multiscale.yaml network and loss: (i) width 512 with LSL + 0.1 consistency against
+    the oracle at 2 000 rows; (ii) at the BASELINE batch of 100 000 rows (1 563 tiles on 256 workgroups, four dW
+    K-chunks): additivity over a ragged split with global counts, and determinism."""
+    import inr_mi355x as M
+    from inr_mi355x import _lib as L
+    from inr_mi355x.engine import ConsistencySpec
+    from inr_mi355x.mfn import MultiscaleKFourier
+    cfg = _cfg("config_fourier_multiscale.yaml")
+    assert cfg["loss"] == "LSL" and cfg["batch_size"] == 100000 and cfg["net"]["network_width"] == 512
+    net, eps = cfg["net"], float(cfg["loss_opts"]["hdr_eps"])
+    torch.manual_seed(0)
+    enc = M.Positional_Encoder(cfg["encoder"], device=dev)
+    model = MultiscaleKFourier(net)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.to(dev).bind_encoder(enc)
+    eng = model._engine("gauss")
+    spec = M.LossSpec(L.LOSS_LOGSPACE, eps=eps)
+    pairs = O.create_pairs(RADII, 1)
+
+    def cons_of(dist):
+        inv = []
+        for lo, hi in pairs[:-1]:
+            n_rows = int(((dist < lo) | (dist > hi)).sum())
+            inv.append(1.0 / (2.0 * n_rows) if n_rows else 0.0)
+        return ConsistencySpec(0.1, pairs, inv + [0.0], 2)
+
+    # (i) oracle, 2 000 rows
+    B = 2000
+    g = torch.Generator().manual_seed(11)
+    coords = torch.rand(B, 3, generator=g) * 2 - 1
+    gt = torch.randn(B, 2, generator=g) * 0.2
+    dist = torch.sqrt(coords[:, 1] ** 2 + coords[:, 2] ** 2).contiguous()
+    l32, g32 = _ms_oracle_step(sd, enc.B.cpu(), coords, gt, dist, net, eps, torch.float32)
+    l64, g64 = _ms_oracle_step(sd, enc.B.cpu(), coords, gt, dist, net, eps, torch.float64)
+    loss = float(eng.train_step(coords.to(dev), enc.B.contiguous(), gt.to(dev), spec, dist=dist.to(dev), scale=0.5,
+                                cons=cons_of(dist)))
+    flat = eng.grads.cpu()
+    live = torch.cat([flat[o:o + n] for (o, n, s, c), lv in zip(model._layout, model._live) if lv])
+    e_gpu, e_cpu = rel_l2(live, g64), rel_l2(g32, g64)
+    le_gpu, le_cpu = abs(loss - float(l64)) / abs(float(l64)), abs(float(l32) - float(l64)) / abs(float(l64))
+    record_parity("config4:lsl_cons_2000", e_gpu=e_gpu, e_cpu=e_cpu, loss_e_gpu=le_gpu, loss_e_cpu=le_cpu)
+    assert e_gpu <= max(4 * e_cpu, 1e-5), (e_gpu, e_cpu)
+    assert le_gpu <= max(4 * le_cpu, 1e-5), (le_gpu, le_cpu)
+
+    # (ii) batch 100 000
+    B = 100000
+    coords = (torch.rand(B, 3, generator=g) * 2 - 1)
+    gt = (torch.randn(B, 2, generator=g) * 0.2).to(dev)
+    dist = torch.sqrt(coords[:, 1] ** 2 + coords[:, 2] ** 2).contiguous()
+    cons = cons_of(dist)
+    coords, dist = coords.to(dev), dist.to(dev)
+    nt, nb = eng.launch_dims(B)
+    assert nt == 1563 and nb == 256
+
+    def step(lo, hi):
+        l = float(eng.train_step(coords[lo:hi], enc.B.contiguous(), gt[lo:hi], spec, count=B, dist=dist[lo:hi],
+                                 scale=0.5, cons=cons))
+        return l, eng.grads.clone()
+
+    l_all, g_all = step(0, B)
+    assert np.isfinite(l_all)
+    parts = [step(lo, hi) for lo, hi in ((0, 33333), (33333, 70001), (70001, B))]
+    e_add = rel_l2(sum(p[1] for p in parts), g_all)
+    record_parity("config4:lsl_cons_100000", what="additivity", e_gpu=e_add)
+    assert abs(sum(p[0] for p in parts) - l_all) <= 5e-6 * abs(l_all) and e_add < 5e-6
+    assert torch.equal(step(0, B)[1], g_all)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# config 1: SIREN 4x256 image-space fit, L2
+# ---------------------------------------------------------------------------------------------------------------
+def test_config1_siren_image_space(dev):
+    """configs/config_siren_image.yaml (the reference's config/remote/config_siren_image.yaml: transform True, batch
+    300 000): two steps over a 4-coil 320x320 image-space slice (409 600 rows: one full and one short batch) against
+    the oracle's loop, then the validation chain WITHOUT the inverse FFT (train.py:139-141,227-229) against the
+    oracle's on the oracle's own prediction."""
+    from inr_mi355x.synthetic import make_kspace
+    from inr_mi355x.train import INRTrainer
+    cfg = _cfg("config_siren_image.yaml")
+    assert cfg["transform"] is True and cfg["batch_size"] == 300000 and cfg["net"]["network_depth"] == 4
+    image, coords, shape = make_kspace(4, 320, 320, seed=5, normalization=cfg["normalization"], image_space=True)
+    tr = INRTrainer(cfg, image, coords, shape, dev, seed=0)
+    assert tr.steps_per_epoch == 2
+    sd = {k: v.detach().cpu().clone() for k, v in tr.model.state_dict().items()}
+    want = O.train_single_scale(cfg, sd, tr.encoder.B.cpu(), coords, image, 2)
+    got = np.array([s[1] for s in tr.fit(2, log_every=1)])
+    record_parity("config1:image_space", got=list(map(float, got)), want=list(map(float, want)))
+    np.testing.assert_allclose(got, np.array(want), rtol=1e-5)
+    flat = torch.cat([sd[k].reshape(-1) for k in tr.model.state_dict().keys()])
+    assert rel_l2(tr.engine.params.cpu(), flat) < 1e-5
+    with torch.no_grad():
+        pred = O.model_forward("SIREN", sd, O.encode(coords, tr.encoder.B.cpu(), "gauss"), cfg["net"])
+    p_ref = float(O.psnr(O.reconstruct(image, shape, True), O.reconstruct(pred, shape, True)))
+    p_got = tr.evaluate()
+    record_parity("config1:image_space", psnr_gpu=p_got, psnr_oracle=p_ref)
+    assert abs(p_got - p_ref) < 1e-2
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# f4: a checkpoint written by the REFERENCE's classes + stock torch.optim.Adam resumes in the fused trainer
+# ---------------------------------------------------------------------------------------------------------------
+def test_reference_written_checkpoint_resumes(dev, tmp_path):
+    """tests/golden/ref_checkpoint_SIREN_L2_step5.pt = torch.save({'net','enc','opt'}) exactly as train.py:244-250
+    writes it, taken from the reference's SIREN + torch.optim.Adam after 5 steps of the golden SIREN_L2 trajectory
+    (tools/make_golden.py).  Loaded through config['pretrain'] (train.py:117-121), the fused trainer must continue
+    on the reference's own loss curve."""
+    from inr_mi355x.train import INRTrainer
+    arrs = dict(np.load(os.path.join(GOLD, "trajectory.npz")))
+    meta = json.load(open(os.path.join(GOLD, "trajectory_meta.json")))
+    k0 = meta["checkpoint_step"]
+    path = os.path.join(GOLD, "ref_checkpoint_SIREN_L2_step%d.pt" % k0)
+    ck = torch.load(path, map_location="cpu")
+    assert set(ck) == {"net", "enc", "opt"} and all(int(v["step"]) == k0 for v in ck["opt"]["state"].values())
+    cfg = dict(meta["cases"]["SIREN_L2"], pretrain=path)
+    coords, image = torch.from_numpy(arrs["coords"]), torch.from_numpy(arrs["image"])
+    tr = INRTrainer(cfg, image, coords, tuple(meta["shape"]), dev, seed=12345)  # different init: all from the file
+    assert tr.engine.step == k0
+    assert list(tr.model.state_dict().keys()) == list(ck["net"].keys())
+    tr.global_step = k0
+    got = []
+    for s in range(k0, meta["steps"]):
+        got.append(float(tr.step(s // tr.steps_per_epoch, s % tr.steps_per_epoch)))
+    np.testing.assert_allclose(np.array(got), arrs["SIREN_L2/losses"][k0:], rtol=2e-4)
+    for k, v in tr.model.state_dict().items():
+        torch.testing.assert_close(v.cpu(), torch.from_numpy(arrs[f"SIREN_L2/final_sd/{k}"]), rtol=1e-4, atol=2e-6)

@@ -262,16 +262,13 @@ def test_trajectory_golden(dev):
     arrs = _load("trajectory.npz")
     meta = json.load(open(os.path.join(GOLD, "trajectory_meta.json")))
     coords, image = _t(arrs["coords"]), _t(arrs["image"])
-    for tag in ("SIREN_L2", "SIREN_L2_reg"):
+    for tag in ("SIREN_L2", "SIREN_L2_reg", "SIREN_regL2"):  # plain | + Regularization_L1 + weight decay | + Regularization_L2
         cfg = meta["cases"][tag]
         tr = INRTrainer(cfg, image, coords, tuple(meta["shape"]), dev, seed=meta["seed"])
         got = [s[1] for s in tr.fit(meta["steps"], log_every=1)]
         ref = arrs[tag + "/losses"]
-        if tag == "SIREN_L2_reg":  # the logged loss of the reference includes the L1 penalty value
-            with torch.no_grad():
-                pass
-        else:
-            np.testing.assert_allclose(np.array(got), ref, rtol=2e-4, err_msg=tag)
+        # (SIREN_L2_reg: the logged loss of the reference includes the L1 penalty value, train.py:185-192)
+        np.testing.assert_allclose(np.array(got), ref, rtol=2e-4, err_msg=tag)
         out = tr.predict_all().cpu()
         torch.testing.assert_close(out, _t(arrs[tag + "/final_out"]), rtol=1e-3, atol=2e-5, msg=lambda m: f"{tag}: {m}")
         for k, v in tr.model.state_dict().items():

@@ -3,8 +3,9 @@
 runs zero-padded in the next larger build.  The reference accepts any ``network_width``
 (networks.py:100-119, :206-250; mfn.py:61-83), so the drop-in must too.
 
-Criterion as in test_gpu_wire.py: as close to a float64 evaluation of the oracle as the oracle's own
-fp32 evaluation is (x10, floor 2e-5) -- forward, loss and flat gradient, fused and ragged batch."""
+Criterion: SIREN / FFN are held to 1e-5 relative against a float64 evaluation of the oracle; WIRE / WIRE2D /
+filter networks (numerically chaotic in fp32, see test_gpu_wire.py) must be as close to float64 as the
+oracle's own fp32 evaluation is (x FACTOR, floor 1e-5) -- forward, loss and flat gradient, fused and ragged batch."""
 import pytest
 import torch
 
@@ -43,12 +44,21 @@ def _ref(kind, sd, net, coords, enc_B, gt, dtype):
     return torch.stack([o.detach() for o in outs]), loss.detach(), torch.cat([_real(g).reshape(-1) for g in grads])
 
 
-def _check(got_out, got_loss, got_grad, r32, r64):
+FACTOR = 4.0  # HIP-vs-float64 error allowed as a multiple of the oracle's own fp32-vs-float64 error (chaotic shapes)
+
+
+def _check(got_out, got_loss, got_grad, r32, r64, tag="", plain=False):
+    """plain: SIREN / FFN -- well-conditioned, held to the north-star's 1e-5 relative directly (against the float64
+    evaluation, which the fp32 oracle itself matches to ~1e-7).  Otherwise (complex Gabor / filter networks at
+    widths where fp32 is chaotic, see test_gpu_wire.py) FACTOR x the oracle's own fp32 error, floor 1e-5.
+    The measured pairs go to gpurun_out/parity_errors.jsonl."""
+    from conftest import record_parity
     for name, got, a32, a64 in (("out", got_out, r32[0], r64[0]), ("grad", got_grad, r32[2], r64[2])):
         e_gpu, e_cpu = rel_l2(got, a64), rel_l2(a32, a64)
-        assert e_gpu <= max(10 * e_cpu, 2e-5), (name, e_gpu, e_cpu)
+        record_parity("widths:" + tag, what=name, e_gpu=e_gpu, e_cpu=e_cpu)
+        assert e_gpu <= (1e-5 if plain else max(FACTOR * e_cpu, 1e-5)), (name, e_gpu, e_cpu)
     l32, l64 = float(r32[1]), float(r64[1])
-    assert abs(float(got_loss) - l64) <= max(10 * abs(l32 - l64), 2e-5 * abs(l64))
+    assert abs(float(got_loss) - l64) <= (1e-5 * abs(l64) if plain else max(FACTOR * abs(l32 - l64), 1e-5 * abs(l64)))
 
 
 @pytest.mark.parametrize("width", [1, 17, 33, 64, 100, 128, 200, 300, 512])
@@ -72,19 +82,19 @@ def test_mlp_widths(dev, model, width):
     eng = mdl.fused_engine(24)
     out = eng.forward(coords.to(dev), enc.B.contiguous(), save=False).cpu()[None]
     loss = eng.train_step(coords.to(dev), enc.B.contiguous(), gt.to(dev), M.LossSpec(L.LOSS_L2_HALF))
-    _check(out, loss, eng.grads.cpu(), r32, r64)
+    _check(out, loss, eng.grads.cpu(), r32, r64, f"{model}-{width}", plain=True)
     # tier 1 (unfused forward / backward kernels on a materialised encoding)
     o1 = mdl(enc.embedding(coords.to(dev)))
     (0.5 * torch.nn.functional.mse_loss(o1, gt.to(dev))).backward()
     g1 = torch.cat([p.grad.reshape(-1) for p in mdl.parameters()]).cpu()
-    _check(o1.detach().cpu()[None], loss, g1, r32, r64)
+    _check(o1.detach().cpu()[None], loss, g1, r32, r64, f"{model}-{width}-tier1", plain=True)
     # one Adam step re-packs the padded images consistently
     eng.adam_step(1e-3, 0.9, 0.999, 1e-8, 0.0)
     sd2 = {k: v.detach().cpu().clone() for k, v in mdl.state_dict().items()}
     out2 = eng.forward(coords.to(dev), enc.B.contiguous(), save=False).cpu()[None]
     q32 = _ref(model, sd2, net, coords, enc.B.cpu(), gt, torch.float32)
     q64 = _ref(model, sd2, net, coords, enc.B.cpu(), gt, torch.float64)
-    assert rel_l2(out2, q64[0]) <= max(10 * rel_l2(q32[0], q64[0]), 2e-5)
+    assert rel_l2(out2, q64[0]) <= 1e-5
 
 
 @pytest.mark.parametrize("depth", [2, 3, 7])
@@ -112,14 +122,14 @@ def test_batch_dw_gemm_depths(dev, model, width, depth):
     assert eng.step_save_by_tile
     out = eng.forward(coords.to(dev), enc.B.contiguous(), save=False).cpu()[None]
     loss = eng.train_step(coords.to(dev), enc.B.contiguous(), gt.to(dev), M.LossSpec(L.LOSS_L2_HALF))
-    _check(out, loss, eng.grads.cpu(), r32, r64)
+    _check(out, loss, eng.grads.cpu(), r32, r64, f"dwgemm-{model}-{width}-d{depth}", plain=True)
     g_first = eng.grads.clone()
     eng.train_step(coords.to(dev), enc.B.contiguous(), gt.to(dev), M.LossSpec(L.LOSS_L2_HALF))
     assert torch.equal(eng.grads, g_first)  # chunk partials are summed in a fixed order
     o1 = mdl(enc.embedding(coords.to(dev)))  # tier 1: materialised encoding, separate forward / backward kernels
     (0.5 * torch.nn.functional.mse_loss(o1, gt.to(dev))).backward()
     g1 = torch.cat([p.grad.reshape(-1) for p in mdl.parameters()]).cpu()
-    _check(o1.detach().cpu()[None], loss, g1, r32, r64)
+    _check(o1.detach().cpu()[None], loss, g1, r32, r64, f"dwgemm-{model}-{width}-d{depth}-tier1", plain=True)
     # the backward consumed the stash (dZ over act'): a second one without a forward must refuse, not return garbage
     e1 = mdl._engine()
     x1 = enc.embedding(coords.to(dev))
@@ -152,7 +162,7 @@ def test_wire_widths(dev, width):
     eng = mdl._engine()
     out = eng.forward(coords.to(dev), None, save=False).cpu()[None]
     loss = eng.train_step(coords.to(dev), None, gt.to(dev), M.LossSpec(L.LOSS_L2_HALF))
-    _check(out, loss, eng.grads.cpu(), r32, r64)
+    _check(out, loss, eng.grads.cpu(), r32, r64, f"WIRE-{width}")
 
 
 @pytest.mark.parametrize("last_tanh", [False, True])
@@ -177,7 +187,7 @@ def test_wire2d_widths(dev, width, last_tanh):
     eng = mdl._engine()
     out = eng.forward(coords.to(dev), None, save=False).cpu()[None]
     loss = eng.train_step(coords.to(dev), None, gt.to(dev), M.LossSpec(L.LOSS_L2_HALF))
-    _check(out, loss, eng.grads.cpu(), r32, r64)
+    _check(out, loss, eng.grads.cpu(), r32, r64, f"WIRE2D-{width}-tanh{int(last_tanh)}")
 
 
 @pytest.mark.parametrize("width", [20, 48, 128, 160, 384])
@@ -205,7 +215,15 @@ def test_mfn_widths(dev, kind, width):
     loss = eng.train_step(coords.to(dev), enc.B.contiguous(), gt.to(dev), M.LossSpec(L.LOSS_L2_HALF))
     flat = eng.grads.cpu()
     live = torch.cat([flat[o:o + n] for (o, n, s, c), lv in zip(mdl._layout, mdl._live) if lv])
-    _check(out, loss, live, r32, r64)
+    _check(out, loss, live, r32, r64, f"{kind}-{width}")
+    # the reference's call contract (mfn.py:34-43): the same model on the ENCODED input, no bound encoder
+    ex = mdl._engine("x")
+    x = enc.embedding(coords.to(dev)).contiguous()
+    out_x = ex.forward(x, None, save=False).cpu()
+    loss_x = ex.train_step(x, None, gt.to(dev), M.LossSpec(L.LOSS_L2_HALF))
+    fx = ex.grads.cpu()
+    _check(out_x, loss_x, torch.cat([fx[o:o + n] for (o, n, s, c), lv in zip(mdl._layout, mdl._live) if lv]), r32, r64,
+           f"{kind}-{width}-x")
 
 
 def test_unsupported_width_fails_loudly(dev):

@@ -23,7 +23,7 @@ def test_abi_header_symbols_exported():
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.inr_abi_version() == 2
+    assert lib.inr_abi_version() == 3
 
 
 def test_plan_validation_and_sizes():
@@ -72,6 +72,69 @@ def test_plan_validation_and_sizes():
     # null arguments are rejected before anything touches a GPU
     assert lib.inr_forward(None, None, None, None, None, 10, None, None, None) < 0
     assert lib.inr_adam_step(None, None, None, None, None, None, 1e-3, .9, .999, 1e-8, 0, 0, 0, 1, None) < 0
+
+
+def test_short_workspaces_are_invalid_arguments():
+    """A stash or slab buffer shorter than inr_plan_workspace reports is INR_ERR_INVALID at the ABI -- checked on the
+    host, before any launch -- never an out-of-bounds GPU write (pointers here are never dereferenced)."""
+    from inr_mi355x import _lib as L
+    lib = L.load()
+    fake = 0x1000  # non-null; the size checks come before any use
+    for kind, kw in ((L.KIND_SIREN, dict(in_features=512, width=256, depth=5, enc_size=256, input=L.INPUT_GAUSS, w0=30.0,
+                                        last_act=L.ACT_TANH)),
+                     (L.KIND_MSFOURIER, dict(in_features=512, width=512, depth=8, enc_size=256, input=L.INPUT_GAUSS)),
+                     (L.KIND_MSFOURIER, dict(in_features=512, width=512, depth=8, input=L.INPUT_X))):
+        plan = C.c_void_p()
+        assert lib.inr_plan_create(C.byref(L.NetDesc(kind=kind, out_features=2, **kw)), C.byref(plan)) == 0, L.last_error()
+        sz = L.Sizes()
+        lib.inr_plan_sizes(plan, C.byref(sz))
+        B = 25000
+        slots, n_slabs = C.c_int64(), C.c_int64()
+        assert lib.inr_plan_workspace(plan, B, C.byref(slots), C.byref(n_slabs)) == 0
+        need_save = slots.value * (sz.save_bytes_per_tile // 4)
+        need_slab = n_slabs.value * sz.slab_floats
+        ld = L.LossDesc(kind=L.LOSS_L2_HALF, inv_count=1.0 / B)
+        multi = kind != L.KIND_SIREN
+
+        def step(ws):
+            if multi:
+                return lib.inr_train_step_multi(plan, C.byref(ld), fake, fake, fake, fake, fake, fake, None, B,
+                                                C.byref(ws), fake, fake, None)
+            return lib.inr_train_step(plan, C.byref(ld), fake, fake, fake, fake, fake, None, B, C.byref(ws), fake, fake,
+                                      None)
+
+        for ws, frag in ((L.Workspace(fake, need_save - 1, fake, need_slab), "stash"),
+                         (L.Workspace(fake, need_save, fake, need_slab - 1), "slab"),
+                         (L.Workspace(None, 0, fake, need_slab), "stash"),
+                         (L.Workspace(fake, need_save, None, 0), "slab")):
+            assert step(ws) == -1 and frag in L.last_error(), (kind, frag, L.last_error())
+        nt, nb = C.c_int64(), C.c_int64()
+        lib.inr_plan_launch_dims(plan, B, C.byref(nt), C.byref(nb))
+        short = L.Workspace(fake, nt.value * (sz.save_bytes_per_tile // 4) - 1, fake, need_slab)
+        if multi:
+            assert lib.inr_backward_multi(plan, fake, fake, fake, fake, fake, B, fake, C.byref(short), fake, None) == -1
+            assert lib.inr_forward_multi(plan, fake, fake, fake, fake, fake, B, fake, C.byref(short), 0, None) == -1
+        else:
+            assert lib.inr_backward(plan, fake, fake, fake, fake, B, fake, C.byref(short), fake, None) == -1
+            assert lib.inr_forward(plan, fake, fake, fake, fake, B, fake, C.byref(short), None) == -1
+        assert "stash" in L.last_error()
+        lib.inr_plan_destroy(plan)
+
+
+def test_mfn_plans_accept_the_encoded_input():
+    """INR_INPUT_X for the filter networks (the reference's call contract, mfn.py:34-43): any in_features, no
+    encoder; the feature image in the stash spans in_features rounded up to whole 32-row blocks."""
+    from inr_mi355x import _lib as L
+    lib = L.load()
+    for in_f in (3, 16, 42, 512):
+        for kind in (L.KIND_FOURIER, L.KIND_GABOR, L.KIND_MSBOUNDED):
+            plan = C.c_void_p()
+            d = L.NetDesc(kind=kind, in_features=in_f, width=48, depth=3, out_features=2, input=L.INPUT_X)
+            assert lib.inr_plan_create(C.byref(d), C.byref(plan)) == 0, L.last_error()
+            lib.inr_plan_destroy(plan)
+    plan = C.c_void_p()
+    bad = L.NetDesc(kind=L.KIND_FOURIER, in_features=500, width=48, depth=3, out_features=2, input=L.INPUT_GAUSS, enc_size=256)
+    assert lib.inr_plan_create(C.byref(bad), C.byref(plan)) < 0 and "2*enc_size" in L.last_error()
 
 
 def _sha(t):

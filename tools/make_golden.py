@@ -293,6 +293,10 @@ def trajectory():
                              beta1=0.9, beta2=0.999, regularization=dict(type="L1", strenght=1e-5),
                              net=dict(network_input_size=16, network_output_size=2, network_depth=3, network_width=32),
                              encoder=dict(embedding="gauss", scale=2, embedding_size=8, coordinates_size=3)),
+        "SIREN_regL2": dict(model="SIREN", loss="L2", lr=1e-4, batch_size=300, max_epoch=3, weight_decay=0.0,
+                            beta1=0.9, beta2=0.999, regularization=dict(type="L2", strenght=1e-4),
+                            net=dict(network_input_size=16, network_output_size=2, network_depth=3, network_width=32),
+                            encoder=dict(embedding="gauss", scale=2, embedding_size=8, coordinates_size=3)),
         "WIRE_HDR": dict(model="WIRE", loss="HDR", lr=1e-4, batch_size=240, max_epoch=3, weight_decay=0.0,
                          beta1=0.9, beta2=0.999,
                          loss_opts=dict(hdr_eps=1e-3, hdr_ff_sigma=2, hdr_ff_factor=0.5),
@@ -305,7 +309,8 @@ def trajectory():
                              encoder=dict(embedding="gauss", scale=2, embedding_size=8, coordinates_size=3)),
     }
     arrs = {"image": npy(image), "coords": npy(coords)}
-    meta = {"shape": [C, H, W], "cases": cases, "seed": 3, "steps": 12}
+    CKPT_STEP = 5
+    meta = {"shape": [C, H, W], "cases": cases, "seed": 3, "steps": 12, "checkpoint_step": CKPT_STEP}
     for tag, cfg in cases.items():
         torch.manual_seed(3)
         encoder = Positional_Encoder(cfg["encoder"], device="cpu")
@@ -321,6 +326,8 @@ def trajectory():
         reg = None
         if cfg.get("regularization", {}).get("type") == "L1":
             reg = Regularization_L1(reg_strength=cfg["regularization"]["strenght"])
+        elif cfg.get("regularization", {}).get("type") == "L2":
+            reg = Regularization_L2(reg_strength=cfg["regularization"]["strenght"])
         sched = LambdaLR(optim, lambda x: 0.2 ** min(x / cfg["max_epoch"], 1))
         bs = cfg["batch_size"]
         losses, step = [], 0
@@ -346,6 +353,11 @@ def trajectory():
                 optim.step()
                 losses.append(float(loss.detach()))
                 step += 1
+                if tag == "SIREN_L2" and step == CKPT_STEP:
+                    # a checkpoint exactly as the reference writes it (train.py:244-250): reference SIREN state_dict,
+                    # encoder.B, stock torch.optim.Adam state -- tensors only, loaded by tests/test_gpu_configs.py
+                    torch.save({"net": model.state_dict(), "enc": encoder.B, "opt": optim.state_dict()},
+                               os.path.join(OUT, "ref_checkpoint_SIREN_L2_step%d.pt" % CKPT_STEP))
             sched.step()
         arrs[tag + "/losses"] = np.array(losses, dtype=np.float64)
         with torch.no_grad():
@@ -404,6 +416,11 @@ def multiscale_trajectory():
                 optim.step()
                 losses.append(float(loss.detach()))
                 step += 1
+                if tag == "SIREN_L2" and step == CKPT_STEP:
+                    # a checkpoint exactly as the reference writes it (train.py:244-250): reference SIREN state_dict,
+                    # encoder.B, stock torch.optim.Adam state -- tensors only, loaded by tests/test_gpu_configs.py
+                    torch.save({"net": model.state_dict(), "enc": encoder.B, "opt": optim.state_dict()},
+                               os.path.join(OUT, "ref_checkpoint_SIREN_L2_step%d.pt" % CKPT_STEP))
             sched.step()
         arrs[tag + "/losses"] = np.array(losses, dtype=np.float64)
         with torch.no_grad():
@@ -548,12 +565,9 @@ def clustering_vectors():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    clustering_vectors()
-    undersampling_vectors()
-    init_hashes()
-    model_vectors()
-    loss_vectors()
-    trajectory()
-    multiscale_trajectory()
+    parts = dict(clustering=clustering_vectors, undersampling=undersampling_vectors, init=init_hashes,
+                 models=model_vectors, losses=loss_vectors, trajectory=trajectory, multiscale=multiscale_trajectory)
+    for name in (sys.argv[1:] or list(parts)):  # python tools/make_golden.py [part ...]; default: everything
+        parts[name]()
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("golden fixtures written to", OUT, f"({tot / 1e6:.2f} MB)")
