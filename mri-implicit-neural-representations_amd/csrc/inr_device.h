@@ -115,10 +115,26 @@ __device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (
 #endif
 __device__ __forceinline__ int swz(int feat, int col) { return feat * INR_LDS_LD + col; }
 
-// Branch-free sincos for |x| <= 2^16: three-constant Cody-Waite reduction by pi/2 with FMA, then
-// the cephes single-precision minimax polynomials on [-pi/4, pi/4] (abs error ~1e-7; validated
-// against a float64 reference in tests/test_gpu_kernels.py).  The OCML sincosf carries a
-// Payne-Hanek slow path whose branches would split every MFMA k-step into basic blocks.
+// sincos for the fp32 parity path, branch-free (the OCML sincosf carries a Payne-Hanek slow path whose branches
+// would split every MFMA k-step into basic blocks).
+//
+// Default: the hardware v_sin_f32 / v_cos_f32 (argument in revolutions) behind a two-constant Cody-Waite
+// reduction by 2 pi: k = rint(x / 2pi), r = x - k 2pi in two FMAs (2pi = hi - lo with hi = float(2pi)), r / 2pi in
+// [-0.5, 0.5].  Measured on MI355X against double precision (tools/probes/sin_probe.hip): max abs error 3.8e-7,
+// mean 5.5e-8 for |x| <= 300 rad -- 7 VALU issue slots + 2 transcendentals, against 26 VALU for the polynomial
+// form below, and on the fp32 MFMA path every VALU instruction is time added to the matrix pipe's.
+// -DINR_SINCOS_POLY: three-constant Cody-Waite by pi/2 + cephes minimax polynomials on [-pi/4, pi/4] (max abs
+// error 9e-8, mean 1.6e-8): kept for A/B runs (make poly).
+#ifndef INR_SINCOS_POLY
+__device__ __forceinline__ void sincos_cw(float x, float& sn, float& cs) {
+  const float k = rintf(x * 0.15915494309189535f);
+  float r = fmaf(k, -6.2831854820251465f, x);  // k * float(2 pi) is exact inside the FMA for |k| < 2^24 / 2pi ...
+  r = fmaf(k, 1.7484555e-7f, r);               // ... + k * (float(2 pi) - 2 pi)
+  const float rev = r * 0.15915494309189535f;
+  sn = __builtin_amdgcn_sinf(rev);
+  cs = __builtin_amdgcn_cosf(rev);
+}
+#else
 __device__ __forceinline__ void sincos_cw(float x, float& sn, float& cs) {
   const float k = rintf(x * 0.63661977236758134f);
   float r = fmaf(k, -1.5707963705062866f, x);      // pi/2 hi
@@ -137,6 +153,7 @@ __device__ __forceinline__ void sincos_cw(float x, float& sn, float& cs) {
   sn = (q & 2) ? -a : a;
   cs = ((q + 1) & 2) ? -b : b;
 }
+#endif
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);

@@ -155,6 +155,13 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* p, in
   return __builtin_amdgcn_make_buffer_rsrc(q, 0, bytes, 0x00020000);
 }
 
+// One dword per lane into the stash through an SGPR buffer descriptor: the address is  descriptor base + per-lane
+// byte offset `voff` (formed once) + wave-uniform byte offset `soff` (SALU), so a store inside a GEMM loop costs no
+// vector-ALU address arithmetic -- on the fp32 MFMA path every VALU instruction is time added to the matrix pipe's.
+__device__ __forceinline__ void stash_store(__amdgpu_buffer_rsrc_t rs, int voff, int soff, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, voff, soff, 0);
+}
+
 // acc (+bias) -> this wave's LDS image rows [0, NBM*32).  Rows of register group g = r>>2 are
 // 32m + 8g + 4*half + (0..3): one float4 of bias per group.  `bias` is the zero-padded bias image
 // (NBM*32 entries) kept inside the packed buffer.
@@ -243,14 +250,14 @@ template <int NB, int TL, bool SAVE>
 __device__ __forceinline__ void gauss_group(f32x16 (&acc)[NB], const f32x4 (&a_use)[NB], f32x4 (&a_load)[NB],
                                             const f32x4* p_next, const float* encB_lds, int s4_next, float xs0,
                                             float xs1, float xs2, int half, const float (&b_use)[4],
-                                            float (&b_load)[4], float* __restrict__ sv_enc_s4) {
+                                            float (&b_load)[4], __amdgpu_buffer_rsrc_t rs, int voff, int s4) {
   load_afrag<NB>(a_load, p_next);
   __builtin_amdgcn_sched_barrier(0);  // the next group's A fragments fly behind this group's MFMAs
 #pragma unroll
   for (int e = 0; e < 4; ++e) b_load[e] = gauss_feature(encB_lds, 4 * s4_next + e, xs0, xs1, xs2, half);
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    if (SAVE) sv_enc_s4[e * TL] = b_use[e];  // feature row (half ? E : 0) + 4*s4 + e, reused by dW_0
+    if (SAVE) stash_store(rs, voff, (4 * s4 + e) * TL * 4, b_use[e]);  // feature row (half ? E : 0) + 4*s4 + e, reused by dW_0
 #pragma unroll
     for (int m = 0; m < NB; ++m) acc[m] = mfma32(a_use[m][e], b_use[e], acc[m]);
   }
@@ -265,7 +272,8 @@ __device__ __forceinline__ void fwd_layer0_gauss(f32x16 (&acc)[NB], const float*
                                                  const float* encB_lds, int E, float xs0, float xs1, float xs2,
                                                  float* __restrict__ sv_enc, int wcol, int lane) {
   const int half = lane >> 5;
-  float* sve = SAVE ? sv_enc + (half ? E : 0) * TL + wcol : nullptr;
+  const __amdgpu_buffer_rsrc_t rs = uniform_rsrc(SAVE ? sv_enc : wp, 2 * E * TL * 4);
+  const int voff = ((half ? E : 0) * TL + wcol) * 4;
   const f32x4* p = reinterpret_cast<const f32x4*>(wp) + lane;
   const int n4 = E >> 2;  // even (E % 8 == 0)
   f32x4 A0[NB], A1[NB];
@@ -277,9 +285,9 @@ __device__ __forceinline__ void fwd_layer0_gauss(f32x16 (&acc)[NB], const float*
   for (int s4 = 0; s4 < n4; s4 += 2) {
     const int n2 = (s4 + 2 < n4) ? (s4 + 2) : s4;
     gauss_group<NB, TL, SAVE>(acc, A0, A1, p + (size_t)(s4 + 1) * NBT * 64, encB_lds, s4 + 1, xs0, xs1, xs2, half, F0,
-                              F1, sve + 4 * s4 * TL);
+                              F1, rs, voff, s4);
     gauss_group<NB, TL, SAVE>(acc, A1, A0, p + (size_t)n2 * NBT * 64, encB_lds, n2, xs0, xs1, xs2, half, F1, F0,
-                              sve + 4 * (s4 + 1) * TL);
+                              rs, voff, s4 + 1);
   }
 }
 
@@ -371,6 +379,7 @@ __device__ __forceinline__ void fwd_group(f32x16 (&acc)[NBOUT], const f32x4 (&a_
                                           float (&zp_buf)[4], float (&zo_buf)[4], float (&zq_buf)[4],
                                           const float* Rcol, int s4_next2, int s4,
                                           const ActParams& ap, int half, float* __restrict__ svl, int hsz,
+                                          __amdgpu_buffer_rsrc_t rs, int voff,
                                           const float (&h_use)[4], const float (&d_use)[4],
                                           const float (&d2_use)[4], const float (&d3_use)[4],
                                           const float (&d4_use)[4], float (&h_load)[4], float (&d_load)[4],
@@ -387,12 +396,13 @@ __device__ __forceinline__ void fwd_group(f32x16 (&acc)[NBOUT], const f32x4 (&a_
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     if (SAVE) {
-      svl[(8 * s4 + 2 * e) * TL] = h_use[e];
-      svl[hsz + (8 * s4 + 2 * e) * TL] = d_use[e];
-      if (HACT == ACT_GABOR || G2D) svl[2 * hsz + (8 * s4 + 2 * e) * TL] = d2_use[e];
+      const int so = (8 * s4 + 2 * e) * TL * 4;  // bytes; the tensors of a layer are hsz floats apart
+      stash_store(rs, voff, so, h_use[e]);
+      stash_store(rs, voff, so + hsz * 4, d_use[e]);
+      if (HACT == ACT_GABOR || G2D) stash_store(rs, voff, so + 2 * hsz * 4, d2_use[e]);
       if (G2D) {
-        svl[3 * hsz + (8 * s4 + 2 * e) * TL] = d3_use[e];
-        svl[4 * hsz + (8 * s4 + 2 * e) * TL] = d4_use[e];
+        stash_store(rs, voff, so + 3 * hsz * 4, d3_use[e]);
+        stash_store(rs, voff, so + 4 * hsz * 4, d4_use[e]);
       }
     }
 #pragma unroll
@@ -420,6 +430,8 @@ __device__ __forceinline__ void fwd_layer(f32x16 (&acc)[NBOUT], const float* R, 
   constexpr bool PAIR = HACT == ACT_GABOR || G2D;
   const float* Rcol = R + col;
   float* svl = (SAVE || G2D) ? sv + half * TL + wcol : nullptr;  // stash row k = 8*s4 + 2e + half
+  const __amdgpu_buffer_rsrc_t rs = uniform_rsrc(SAVE ? (const void*)sv : (const void*)wp, 5 * hsz * 4);
+  const int voff = (half * TL + wcol) * 4;
   f32x4 A0[NBOUT], A1[NBOUT];
   float Z[4], ZP[4], ZO[4], ZQ[4], H0[4], D0[4], E0[4], F0[4], G0[4], H1[4], D1[4], E1[4], F1[4], G1[4];
   load_afrag<NBOUT>(A0, p);
@@ -433,9 +445,9 @@ __device__ __forceinline__ void fwd_layer(f32x16 (&acc)[NBOUT], const float* R, 
     const int n2 = (s4 + 2 < n4) ? (s4 + 2) : s4;
     const int n3 = (s4 + 3 < n4) ? (s4 + 3) : s4;
     fwd_group<NBOUT, TL, HACT, SAVE>(acc, A0, A1, p + (size_t)(s4 + 1) * NBT * 64, Z, ZP, ZO, ZQ, Rcol, n2, s4, ap,
-                                     half, svl, hsz, H0, D0, E0, F0, G0, H1, D1, E1, F1, G1);
+                                     half, svl, hsz, rs, voff, H0, D0, E0, F0, G0, H1, D1, E1, F1, G1);
     fwd_group<NBOUT, TL, HACT, SAVE>(acc, A1, A0, p + (size_t)n2 * NBT * 64, Z, ZP, ZO, ZQ, Rcol, n3, s4 + 1, ap,
-                                     half, svl, hsz, H1, D1, E1, F1, G1, H0, D0, E0, F0, G0);
+                                     half, svl, hsz, rs, voff, H1, D1, E1, F1, G1, H0, D0, E0, F0, G0);
   }
 }
 

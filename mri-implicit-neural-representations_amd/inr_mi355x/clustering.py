@@ -5,7 +5,6 @@ The ring statistics run on whatever device holds the k-space (3.5 M points x 40 
 the k-means itself is 40 numbers and uses the same ``sklearn.cluster.KMeans(init="random", n_init=10,
 max_iter=200, random_state=42)`` call as the reference, on the host.  Nothing is plotted.
 """
-from collections import OrderedDict
 from math import sqrt
 from typing import Tuple
 
@@ -42,12 +41,18 @@ def partition_kspace(img: torch.Tensor, kcoords: torch.Tensor, no_steps: int = 4
     kmeans = KMeans(init="random", n_clusters=no_parts, n_init=10, max_iter=200, random_state=42)
     kmeans.fit(means)
     labels = kmeans.labels_
-    unique_elements, indices, counts = np.unique(labels, return_counts=True, return_index=True)
-    order = np.argsort(indices)  # clusters in order of first appearance going outwards
-    unique_elements, counts = unique_elements[order], counts[order]
-    normalized_counts = sqrt(2) * np.cumsum(counts / len(labels))
-    radii = np.array([0] + list(OrderedDict(zip(unique_elements, normalized_counts)).values()))
-    radii[no_parts] = 5  # last one covers the entire range (clustering.py:82)
+    # Walking outwards, every cluster claims as many of the initial rings as carry its label, in the order in which
+    # the clusters are first met (clustering.py:72-84): boundary j = sqrt(2) * (rings claimed by the first j clusters)
+    # / no_steps.  (Rings of one cluster are counted together even if another cluster's ring sits between them.)
+    first_met, ring_count = [], {}
+    for lab in labels.tolist():
+        if lab not in ring_count:
+            first_met.append(lab)
+            ring_count[lab] = 0
+        ring_count[lab] += 1
+    claimed = np.cumsum([ring_count[lab] / len(labels) for lab in first_met])
+    radii = np.concatenate(([0.0], sqrt(2) * claimed))
+    radii[no_parts] = 5  # the outermost partition is "everything beyond" (clustering.py:82)
     return labels, radii
 
 

@@ -105,6 +105,7 @@ class MLPEngine:
         # one extra word behind the gradient: the data-parallel step all-reduces gradient AND loss in ONE collective
         self.gbuf = torch.zeros(self.n_params + 1, device=dev)
         self.grads = self.gbuf[:self.n_params]
+        self._loss_word = self.gbuf[self.n_params:]  # the fused steps write their loss here, next to the gradient
         self.exp_avg = torch.zeros(self.n_params, device=dev)
         self.exp_avg_sq = torch.zeros(self.n_params, device=dev)
         self.packed = torch.zeros(self.packed_floats, device=dev)  # padding entries stay zero forever
@@ -238,8 +239,8 @@ class MLPEngine:
         L.check(self.lib.inr_train_step(self.plan, C.byref(ld), _ptr(self.params, "params"),
                                         _ptr(self.packed, "packed"), _ptr(x, "x"), _ptr(enc_B, "enc_B"),
                                         _ptr(gt, "gt"), _ptr(mask, "mask", torch.uint8), B, C.byref(ws),
-                                        _ptr(self.grads, "grads"), _ptr(self._loss, "loss"), self._stream()))
-        return self._loss[0]
+                                        _ptr(self.grads, "grads"), self._loss_word.data_ptr(), self._stream()))
+        return self._loss_word[0]
 
     def adam_step(self, lr: float, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,
                   weight_decay: float = 0.0, l1: float = 0.0, l2: float = 0.0) -> None:
@@ -371,5 +372,5 @@ class MFNEngine(MLPEngine):
                                               _ptr(self.packed, "packed"), _ptr(coords, "coords"),
                                               _ptr(enc_B, "enc_B"), _ptr(gt, "gt"), _ptr(dist, "dist"),
                                               _ptr(mask, "mask", torch.uint8), B, C.byref(ws),
-                                              _ptr(self.grads, "grads"), _ptr(self._loss, "loss"), self._stream()))
-        return self._loss[0]
+                                              _ptr(self.grads, "grads"), self._loss_word.data_ptr(), self._stream()))
+        return self._loss_word[0]

@@ -80,7 +80,8 @@ def allreduce_step_outputs(grads: torch.Tensor, loss: torch.Tensor, world: int, 
     import torch.distributed as dist
     if gbuf is not None:
         assert gbuf.data_ptr() == grads.data_ptr() and gbuf.numel() == grads.numel() + 1
-        gbuf[-1:].copy_(loss.reshape(1))
+        if loss.data_ptr() != gbuf[-1:].data_ptr():  # the fused steps already left their loss in that word
+            gbuf[-1:].copy_(loss.reshape(1))
         dist.all_reduce(gbuf, op=dist.ReduceOp.SUM, group=group)
         return gbuf[-1].clone()
     dist.all_reduce(grads, op=dist.ReduceOp.SUM, group=group)
