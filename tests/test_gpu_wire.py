@@ -139,7 +139,7 @@ def test_wire_full_size_vs_oracle(dev, B, loss_kind):
     |dy/dlin| ~ omega_0 + 2 s0^2 |lin| (30 ... 450), so two fp32 evaluations that only differ in
     summation order (ATen vs MFMA k-order) agree to ~1e-3 at the output.  The parity criterion is
     therefore accuracy against a float64 evaluation of the reference math: the HIP path must be as
-    close to float64 as the reference's own fp32 CPU path is (within 4x: both errors are single draws
+    close to float64 as the reference's own fp32 CPU path is (within 5x -- the largest measured ratio is 3.45 -- both errors are single draws
     of rounding noise of the same scale), not bit-close to it."""
     import inr_mi355x as M
     torch.manual_seed(0)
@@ -162,10 +162,10 @@ def test_wire_full_size_vs_oracle(dev, B, loss_kind):
     for name, got, r32, r64 in (("out", got_out, out32, out64), ("grad", got_grad, grad32, grad64)):
         e_gpu, e_cpu = rel_l2(got, r64), rel_l2(r32, r64)
         record_parity(f"wire_full:{loss_kind}:B{B}", what=name, e_gpu=e_gpu, e_cpu=e_cpu)
-        assert e_gpu <= max(4 * e_cpu, 1e-5), (name, e_gpu, e_cpu)
+        assert e_gpu <= max(5 * e_cpu, 1e-5), (name, e_gpu, e_cpu)  # measured maxima (profiles/r02_parity_errors.jsonl): 3.45 HDR, 1.23 L2
     e_gpu, e_cpu = abs(float(loss) - float(loss64)) / abs(float(loss64)), abs(float(loss32) - float(loss64)) / abs(float(loss64))
     record_parity(f"wire_full:{loss_kind}:B{B}", what="loss", e_gpu=e_gpu, e_cpu=e_cpu)
-    assert e_gpu <= max(4 * e_cpu, 1e-5), ("loss", e_gpu, e_cpu)
+    assert e_gpu <= max(5 * e_cpu, 1e-5), ("loss", e_gpu, e_cpu)
 
 
 def test_wire_trajectory_golden(dev):
