@@ -13,6 +13,8 @@
 
 #include "inr_aux.h"
 #include "inr_dw_gemm.h"
+#include "inr_dw_gemm_bf16.h"
+#include "inr_w2.h"
 
 namespace {
 
@@ -200,6 +202,7 @@ static int create_mfn_plan(const inr_net_desc* d, inr_plan** out) {
   nd.slab_loss_off = goff;
   nd.slab_floats = round_up(goff + 4, 64);
   // stash: [f | l cos u | h] per stage, encoder features, |x|^2 [TL]
+  nd.w2_off = nd.w2_bias_off = -1;
   nd.save_floats_per_tile = 3 * nd.mfn_stages * NB * 32 * TL + nd.L[0].Kblk * 32 * TL + TL;  // Kblk*32 >= 2 E'
   p->packed_floats = pk;
   *out = p;
@@ -373,6 +376,15 @@ int inr_plan_create(const inr_net_desc* d, inr_plan** out) {
   nd.save_floats_per_tile = ns * (D - 1) * NB * 32 * TL + 4 * TL +
                             (d->input == INR_INPUT_GAUSS ? nd.L[0].Kblk * 32 * TL : 0) +
                             (wire2d ? NB * 32 * TL : 0);  // WIRE2D: copy of a layer's output gradient
+  nd.w2_off = nd.w2_bias_off = -1;
+  if (nd.bf16 && (d->enc_size % 32) == 0 && D <= 8) {
+    // second image set of the bf16 plans: the "weights in LDS" chunk stream of the fused step (inr_w2.h) + fp32 biases
+    pk = (pk + 3) & ~(int64_t)3;  // 16-byte aligned: the chunks are read by 16-byte LDS-DMA pieces
+    nd.w2_off = (int)pk;
+    pk += (int64_t)w2_nq(D, d->enc_size) * W2_CHUNK_FLOATS;
+    nd.w2_bias_off = (int)pk;
+    pk += (int64_t)D * 256;
+  }
   p->packed_floats = pk;
   *out = p;
   return INR_OK;
@@ -459,6 +471,37 @@ static bool dw_gemm_setup(const inr_plan* plan, int64_t nt, inr::DwGemmArgs* g, 
   return true;
 }
 
+// bf16 plans with the "weights in LDS" fused kernel: every weight gradient comes from inr_dw_gemm_bf16.hip
+static bool w2_plan(const inr_plan* plan) { return plan->nd.bf16 && plan->nd.w2_off >= 0; }
+
+static void dw_gemm_bf16_setup(const inr_plan* plan, int64_t nt, inr::DwGemmBf16Args* g) {
+  const NetDesc& nd = plan->nd;
+  memset(g, 0, sizeof(*g));
+  const int D = nd.D, T = 256 * 128 / 2;  // dwords per stashed 2-byte tensor [256 rows][128 coordinates]
+  const float inv2pi = 0.15915494309189535f;
+  int k = 0;
+  for (int n0 = 0; n0 < nd.L[0].K; n0 += 256) {  // first layer: B = encoder features, 2E columns
+    inr::DwGemmBf16Unit& u = g->unit[k++];
+    u.dz_off = (D - 1) * T, u.z_off = -1, u.krev = 0.f;
+    u.gw_off = nd.L[0].gw_off, u.gb_off = nd.L[0].gb_off, u.M = 256, u.K = nd.L[0].K, u.n0 = n0;
+  }
+  for (int l = 1; l <= D - 1; ++l) {
+    inr::DwGemmBf16Unit& u = g->unit[k++];
+    const bool last = l == D - 1;
+    u.dz_off = last ? 2 * (D - 1) * T : (D - 1 + l) * T;
+    u.z_off = (l - 1) * T;
+    u.krev = nd.L[l - 1].omega * inv2pi;
+    u.gw_off = nd.L[l].gw_off, u.gb_off = nd.L[l].gb_off;
+    u.M = last ? nd.L[l].M : 256, u.K = nd.L[l].K, u.n0 = 0;
+  }
+  g->n_units = k;
+  g->TL = 128, g->E = nd.E;
+  g->save_floats_per_tile = nd.save_floats_per_tile, g->slab_floats = nd.slab_floats, g->n_tiles = (int)nt;
+  const int target = std::max(1, 256 / k);  // about one workgroup per CU
+  g->tiles_per_chunk = (int)((nt + target - 1) / target);
+  g->n_chunks = (int)((nt + g->tiles_per_chunk - 1) / g->tiles_per_chunk);
+}
+
 static bool dw_gemm_plan(const inr_plan* plan) {
   inr::DwGemmArgs g;
   inr::SlabSplit split;
@@ -466,7 +509,7 @@ static bool dw_gemm_plan(const inr_plan* plan) {
 }
 
 // fused steps of these plans stash per TILE (n_tiles slots): a batch-level GEMM reads the whole batch's stash
-static bool step_save_by_tile(const inr_plan* plan) { return dw_gemm_plan(plan); }
+static bool step_save_by_tile(const inr_plan* plan) { return dw_gemm_plan(plan) || w2_plan(plan); }
 
 // a call's scratch against what the plan needs: `save_slots` stash slots (0: none), `n_slabs` slabs (0: none)
 static int check_ws(const inr_plan* plan, const inr_workspace* ws, int64_t save_slots, int64_t n_slabs,
@@ -505,6 +548,11 @@ int inr_plan_workspace(const inr_plan* plan, int64_t B, int64_t* step_save_slots
   if (rc != INR_OK) return rc;
   *step_save_slots = step_save_by_tile(plan) ? nt : nb;
   *n_slabs = nb;
+  if (w2_plan(plan)) {  // (the unfused backward of these plans needs nb slabs only: covered)
+    inr::DwGemmBf16Args g;
+    dw_gemm_bf16_setup(plan, nt, &g);
+    *n_slabs = nb + g.n_chunks;
+  }
   if (dw_gemm_plan(plan)) {
     inr::DwGemmArgs g;
     inr::SlabSplit split;
@@ -549,6 +597,8 @@ static int launch(const inr_plan* plan, const LossDesc& ld, const inr::MlpArgs& 
       case 8: e = inr::launch_wire_nb8(nd, ld, a, mode, grid, st); break;
       default: e = inr::launch_wire_nb12(nd, ld, a, mode, grid, st); break;
     }
+  else if (nd.bf16 && mode == 2 && nd.w2_off >= 0)
+    e = inr::launch_siren_bf16(nd, ld, a, grid, st);  // fused step: weights in LDS, dW by inr_dw_gemm_bf16.hip
   else if (nd.bf16)
     e = inr::launch_mlp_nb8_bf16(nd, ld, a, mode, grid, st);
   else
@@ -630,7 +680,18 @@ static int finish_gradients(const inr_plan* plan, const inr::MlpArgs& a, int64_t
                             float* loss_out, const float* params, const float* packed, hipStream_t st,
                             const char* who) {
   inr::SlabSplit split{0, 0, 0, 0};
-  if (a.dw_gemm) {
+  if (a.dw_gemm == 2) {  // bf16 fused step: all of dW / db from the bf16 batch GEMM, summed over its chunk slabs
+    inr::DwGemmBf16Args g;
+    dw_gemm_bf16_setup(plan, nt, &g);
+    g.save = a.save;
+    g.slabs = a.slabs + (size_t)nb * plan->nd.slab_floats;
+    g.coords = a.x;
+    g.encB = a.encB;
+    g.B = a.B;
+    hipError_t e = inr::launch_dw_gemm_bf16(g, st);
+    if (e != hipSuccess) return hip_fail(e, (std::string(who) + ": bf16 weight-gradient GEMM").c_str());
+    split.lo = 0, split.hi = (plan->nd.P + 3) & ~3, split.n2 = g.n_chunks;  // (a multiple of 4: the fast reduction works on float4)
+  } else if (a.dw_gemm) {
     inr::DwGemmArgs g;
     dw_gemm_setup(plan, nt, &g, &split);
     g.save = a.save;
@@ -774,7 +835,7 @@ int inr_train_step(const inr_plan* plan, const inr_loss_desc* loss, const float*
   a.slabs = ws->slabs;
   a.B = B;
   a.n_tiles = (int)nt;
-  a.dw_gemm = dw_gemm_plan(plan) ? 1 : 0;
+  a.dw_gemm = w2_plan(plan) ? 2 : (dw_gemm_plan(plan) ? 1 : 0);
   a.save_by_block = a.dw_gemm ? 0 : 1;
 #ifdef INR_STAMPS
   a.dbg = g_stamp_buf;

@@ -3,6 +3,7 @@
 // kernels; none reshapes its work into a GEMM.
 #include "inr_device.h"
 #include "inr_aux.h"
+#include "inr_w2.h"
 
 namespace inr {
 
@@ -270,8 +271,7 @@ __global__ __launch_bounds__(256) void reduce_slabs_bf16_any_kernel(const NetDes
 
 hipError_t launch_reduce_slabs(const NetDesc& nd, const float* slabs, int n_blocks, float* grads, float* loss_out,
                                const float* params, const float* packed, hipStream_t st, SlabSplit split) {
-  if (split.n2 > 0 && nd.bf16) return hipErrorInvalidValue;
-  if (nd.bf16) {
+  if (nd.bf16 && split.n2 == 0) {  // unfused bf16 backward: bf16 slabs of the first bf16 kernel
     bool same = true;  // slab element offsets == flat offsets (hidden width = whole row blocks, e.g. 256)
     for (int l = 0; l < nd.ND; ++l) same = same && nd.L[l].gw_off == nd.L[l].w_off && nd.L[l].gb_off == nd.L[l].b_off;
     if (same) {
@@ -340,6 +340,27 @@ __device__ __forceinline__ void put_tr_bf16(const LayerDesc& L, float* packed, i
   put_bf16(packed, L.pb_off, ((size_t)((s >> 3) * L.Kblk + (k >> 5)) * 64 + h * 32 + (k & 31)) * 8 + (s & 7), v);
 }
 
+// "weights in LDS" images of the bf16 fused step (inr_siren_bf16_impl.h; layout: inr_w2.h): weight W_l[row][k] goes
+// into the forward chunk image of layer l and, for l >= 1, into the transposed image (out index = k, contraction
+// index = row); biases into the fp32 table.  Plain SIREN plans only (every layer LT_REAL, hidden rows = 256 padded).
+__device__ __forceinline__ void put_w2(const NetDesc& nd, int l, float* packed, int row, int k, float v) {
+  __bf16* img = reinterpret_cast<__bf16*>(packed + nd.w2_off);
+  int t, h, j;
+  if (l == 0) {  // gauss features: K-step t = sines (half 0) / cosines (half 1) of features 8t .. 8t+7
+    h = k >= nd.E;
+    const int kk = h ? k - nd.E : k;
+    t = kk >> 3;
+    j = kk & 7;
+  } else {
+    w2_kperm_inv(k, t, h, j);
+  }
+  img[w2_index(w2_qf(l, nd.E) + (t >> 2), t & 3, row >> 5, h * 32 + (row & 31), j)] = (__bf16)v;
+  if (l >= 1) {
+    w2_kperm_inv(row, t, h, j);
+    img[w2_index(w2_qt(l, nd.D, nd.E) + (t >> 2), t & 3, k >> 5, h * 32 + (k & 31), j)] = (__bf16)v;
+  }
+}
+
 __global__ __launch_bounds__(256) void adam_pack_kernel(const NetDesc nd, float* __restrict__ params,
                                                         const float* __restrict__ grads, float* __restrict__ m1,
                                                         float* __restrict__ m2, float* __restrict__ packed,
@@ -379,11 +400,13 @@ __global__ __launch_bounds__(256) void adam_pack_kernel(const NetDesc nd, float*
           if (nd.bf16) put_tr_bf16(L, packed, row, k, p);
           else put_tr(L, packed, row, k, p);
         }
+        if (nd.bf16 && nd.w2_off >= 0) put_w2(nd, l, packed, row, k, p);
         return;
       }
       const int ob = i - L.b_off;
       if (ob >= 0 && ob < L.bn) {
         packed[L.pbias_off + ob] = p;
+        if (nd.bf16 && nd.w2_off >= 0) packed[nd.w2_bias_off + l * 256 + ob] = p;
         return;
       }
     }

@@ -6,12 +6,14 @@ namespace inr {
 
 #define INR_DWGB_MAX_UNITS 48
 
-// one 256-row x 256-column block of one layer's dW
+// one 256-row x 256-column block of one layer's dW.  Offsets into a tile's stash are in DWORDS (= row pairs x
+// coordinates: rows (2p, 2p+1) of coordinate c share the dword at p * TL + c).
 struct DwGemmBf16Unit {
-  int dz_off;          // 2-byte elements from the start of a tile's stash to dZ_l [256][TL] (bf16)
-  int z_off;           // ... to z_{l-1} [K][TL] (fp16); < 0: first layer, h = gauss encoder features of the coordinates
+  int dz_off;          // dwords from the start of a tile's stash to dZ_l (bf16 pairs)
+  int z_off;           // ... to z_{l-1} (fp16 pairs); < 0: first layer, h = gauss encoder features of the coordinates
   float krev;          // w0 / (2 pi) of the layer that produced z_{l-1}
-  int gw_off, gb_off;  // slab offsets (floats) of dW [256 x K] and db [256]
+  int gw_off, gb_off;  // slab offsets (floats) of dW [M x K] and db [M]
+  int M;               // rows of dW stored (256 for the hidden layers' padded slabs, out_features for the last layer)
   int K;               // columns of dW
   int n0;              // first column of this block
 };

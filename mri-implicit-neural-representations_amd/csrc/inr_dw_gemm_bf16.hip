@@ -1,23 +1,26 @@
-// inr_dw_gemm_bf16.hip -- batch-level weight gradients of the bf16 throughput path:  dW_l = dZ_l^T h_{l-1}  over all
-// coordinates of a chunk of tiles, on v_mfma_f32_32x32x16_bf16 (fp32 accumulate), split-K over chunks of tiles.
+// inr_dw_gemm_bf16.hip -- batch-level weight gradients of the bf16 throughput path:  dW_l = dZ_l^T h_{l-1},
+// db_l = sum_c dZ_l  over all coordinates of a chunk of tiles, on v_mfma_f32_32x32x16_bf16 (fp32 accumulate),
+// split-K over chunks of tiles; inr_siren_bf16_impl.h leaves the operands behind.
 //
-// Why it exists: with the matrix pipe 16x faster than on the fp32 path the fused bf16 kernel was paced by what it
-// WROTE -- one private 0.66 MB gradient slab per 128-coordinate tile (196 of them at 25 000 rows: 129 MB per launch,
-// in 2-byte stores).  Here the fused kernel only leaves its operands behind (z_l as fp16, dZ_l as bf16, 4 KB per
-// coordinate) and ~50 workgroups-per-layer each keep a 256 x 256 block of dW in registers across ~10 tiles: the slab
-// stream shrinks from (tiles x 0.66 MB) to (chunks x 1.3 MB), written once in 16-byte fp32 stores.
+// Why it exists: with the matrix pipe 16x faster than on the fp32 path the first fused bf16 kernel was paced by what
+// it WROTE -- one private 0.66 MB gradient slab per 128-coordinate tile (196 of them at 25 000 rows: 129 MB per
+// launch, in 2-byte stores) -- and spent half its cycles in the in-kernel dW passes.  Here ~40 workgroups per layer
+// each keep a 256 x 256 block of dW in registers across ~13 tiles: the slab stream is (chunks x 1.3 MB), written once
+// in fp32.
 //
-// Operands (stash of inr_mlp_bf16_kernel, per tile of TL = 128 coordinates, element (row r, coordinate c) at
-// [r * TL + c]):  A = dZ_l  bf16;  B = h_{l-1} = sin(w0 z_{l-1}) RECOMPUTED here from the stashed fp16 z_{l-1} with the
-// hardware sine (the fused kernel never stores h), or, for the first layer, the gauss encoder features regenerated from
-// the tile's coordinates exactly as the forward pass formed them (sin of x.B_j revolutions, + 1/4 turn for the cosine
-// half).  db_l = row sums of dZ_l come out of the same matrix pipe: one extra MFMA per A fragment against a constant
-// all-ones B fragment (every column of that accumulator is the row sum).
+// Operands (stash of inr_siren_bf16_kernel, per tile of TL coordinates, ROW-PAIR layout: rows (2p, 2p+1) of
+// coordinate c share the dword at p * TL + c):  A = dZ_l, bf16;  B = h_{l-1} = sin(w0 z_{l-1}) RECOMPUTED here from
+// the stashed fp16 z_{l-1} with the hardware sine (the fused kernel never stores h), or, for the first layer, the gauss
+// encoder features regenerated from the tile's coordinates exactly as the forward pass formed them (sine of x.B_j
+// revolutions, + 1/4 turn for the cosine half).  A thread stages (row pair, 8 coordinates) items: two 16-byte loads,
+// de-interleaved into one 16-byte LDS piece per row (v_perm_b32 for dZ; for z the sine pass unpacks anyway); the row
+// sums db come from the same registers (v_dot2_f32_bf16 against a constant pair of ones), reduced over the 8 threads
+// of a row at the end.
 //
 // Workgroup = one 256 x 256 block of one layer's dW over one chunk of tiles; four waves 2 x 2, 4 x 4 MFMA blocks each
-// (256 accumulator registers); K-steps of 64 coordinates (whole 128-byte lines of both operands) staged through two
-// LDS stages, rows pitched 144 B so that the 16-byte fragment reads of 16 consecutive rows hit 16 distinct 4-bank
-// slots; the sine of stage s+1 is computed in the shadow of the MFMAs of stage s (4.5 VALU per MFMA).
+// (256 accumulator registers); K-steps of 64 coordinates staged through two LDS stages, rows pitched 144 B so that the
+// 16-byte fragment reads of 16 consecutive rows hit 16 distinct 4-bank slots; the sines of stage s+1 are computed in
+// the shadow of the MFMAs of stage s.
 #include <hip/hip_runtime.h>
 
 #include "inr_dw_gemm_bf16.h"
@@ -26,38 +29,78 @@
 namespace inr {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int GB_KS = 64;                 // coordinates per stage
 constexpr int GB_PITCH = 72;              // LDS row pitch in 2-byte elements: 64 coordinates + 16 bytes of padding
 constexpr int GB_TILE = 256 * GB_PITCH;   // one operand tile (elements)
 constexpr int GB_STAGE = 2 * GB_TILE;     // A tile + B tile
-constexpr int GB_NF = 8;                  // 16-byte pieces per thread, operand and stage (256 rows x 8 pieces / 256 threads)
+constexpr int GB_NI = 4;                  // (row pair, 8 coordinates) items per thread, operand and stage
 
-__device__ __forceinline__ bf16x8 sin_of_z(const f16x8 z, float krev) {
-  f32x8 o;
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+  f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+
+// 8 dwords (coordinates c .. c+7, each = rows (2p, 2p+1)) -> the two rows as 8 bf16 each
+__device__ __forceinline__ void split_rows(const u32x4& a, const u32x4& b, u32x4& even, u32x4& odd) {
+  even[0] = __builtin_amdgcn_perm(a[1], a[0], 0x05040100u);
+  even[1] = __builtin_amdgcn_perm(a[3], a[2], 0x05040100u);
+  even[2] = __builtin_amdgcn_perm(b[1], b[0], 0x05040100u);
+  even[3] = __builtin_amdgcn_perm(b[3], b[2], 0x05040100u);
+  odd[0] = __builtin_amdgcn_perm(a[1], a[0], 0x07060302u);
+  odd[1] = __builtin_amdgcn_perm(a[3], a[2], 0x07060302u);
+  odd[2] = __builtin_amdgcn_perm(b[1], b[0], 0x07060302u);
+  odd[3] = __builtin_amdgcn_perm(b[3], b[2], 0x07060302u);
+}
+
+__device__ __forceinline__ float sum8(const u32x4& v, float acc) {
+  const bf16x2 one2 = {(__bf16)1.0f, (__bf16)1.0f};
 #pragma unroll
-  for (int j = 0; j < 8; ++j) o[j] = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf((float)z[j] * krev));
-  return __builtin_convertvector(o, bf16x8);
+  for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, v[i]), one2, acc, false);
+  return acc;
+}
+
+// 8 fp16 pairs (rows 2p, 2p+1 of 8 coordinates) -> sin(w0 z) of each row as 8 bf16
+__device__ __forceinline__ void sin_rows(const u32x4& a, const u32x4& b, float krev, u32x4& even, u32x4& odd) {
+  float e[8], o[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const f16x2 z = __builtin_bit_cast(f16x2, i < 4 ? a[i] : b[i - 4]);
+    e[i] = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf((float)z[0] * krev));
+    o[i] = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf((float)z[1] * krev));
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    even[i] = pk_bf16(e[2 * i], e[2 * i + 1]);
+    odd[i] = pk_bf16(o[2 * i], o[2 * i + 1]);
+  }
 }
 
 // feature `row` (< E: sine, >= E: cosine of the same phase) of 8 consecutive coordinates whose (x0,x1,x2) sit in xs
-__device__ __forceinline__ bf16x8 gauss_features(const float* xs, const float* encB, int E, int row) {
-  const int s = row < E ? row : row - E;
+__device__ __forceinline__ u32x4 gauss_features(const float* xs, const float* encB, int E, int row) {
+  int s = row < E ? row : row - E;
+  s = s < E ? s : E - 1;  // rows past 2E (column blocks wider than the layer) are computed and never stored
   const float quarter = row < E ? 0.f : 0.25f;
   const float b0 = encB[3 * s + 0], b1 = encB[3 * s + 1], b2 = encB[3 * s + 2];
-  f32x8 o;
+  float f[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const float rev = fmaf(xs[3 * j + 2], b2, fmaf(xs[3 * j + 1], b1, fmaf(xs[3 * j], b0, quarter)));
-    o[j] = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(rev));
-  }
-  return __builtin_convertvector(o, bf16x8);
+  for (int j = 0; j < 8; ++j)
+    f[j] = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(fmaf(xs[3 * j + 2], b2, fmaf(xs[3 * j + 1], b1, fmaf(xs[3 * j], b0, quarter)))));
+  u32x4 o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = pk_bf16(f[2 * i], f[2 * i + 1]);
+  return o;
 }
 
-template <int TL, bool ENC, bool BIAS>
+// ENC: B = encoder features (first layer); BIAS: this column block also produces db; LASTROWS: dZ has only its first
+// two row pairs (the out_features <= 4 rows of the last layer): the rest of the A tile stays zero
+template <int TL, bool ENC, bool BIAS, bool LASTROWS>
 __device__ __forceinline__ void dwgb_body(const DwGemmBf16Args& a, const DwGemmBf16Unit& it, int kc, char* lds_raw) {
   __bf16* lds = reinterpret_cast<__bf16*>(lds_raw);
   float* xs_lds = reinterpret_cast<float*>(lds_raw + (size_t)2 * GB_STAGE * 2);  // [2 stages][64 coords][3]
@@ -71,68 +114,83 @@ __device__ __forceinline__ void dwgb_body(const DwGemmBf16Args& a, const DwGemmB
   if (n_mine > a.tiles_per_chunk) n_mine = a.tiles_per_chunk;
   const int n_steps = (n_mine > 0 ? n_mine : 0) * KS_PER_TILE;
 
-  f32x16 acc[4][4], accb[BIAS ? 4 : 1];
+  f32x16 acc[4][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    if (BIAS)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) accb[i][r] = 0.f;
-  }
-  if (ENC) {
+  if (ENC)
     for (int i = t; i < 3 * a.E; i += 256) encB_lds[i] = a.encB[i];
+  if (LASTROWS) {  // rows the loader never writes must read as zeros (both stages; B tiles are always written whole)
+    u32x4 z4 = {0u, 0u, 0u, 0u};
+    for (int i = t; i < 2 * 256 * 9; i += 256) {
+      const int st = i / (256 * 9), rem = i - st * 256 * 9, row = rem / 9, piece = rem - row * 9;
+      *reinterpret_cast<u32x4*>(lds + (size_t)st * GB_STAGE + row * GB_PITCH + 8 * piece) = z4;
+    }
   }
-  // loader: piece p = t & 7 (8 coordinates = 16 bytes), rows (t >> 3) + 32 k
-  const int seg = t & 7, row0 = t >> 3;
-  const __bf16* sv = reinterpret_cast<const __bf16*>(a.save);
-  const size_t tile_elems = (size_t)a.save_floats_per_tile * 2;
-  bf16x8 ra[GB_NF];
-  f16x8 rb[GB_NF];
+  // loader: item k of thread t = row pair (t >> 3) + 32 k, coordinates 8 (t & 7) .. + 7 of the stage
+  const int seg = t & 7, pair0 = t >> 3;
+  const unsigned* sv = reinterpret_cast<const unsigned*>(a.save);
+  const size_t tile_dwords = (size_t)a.save_floats_per_tile;
+  u32x4 ra[GB_NI][2], rb[GB_NI][2];
+  float bsum[GB_NI][2];
+#pragma unroll
+  for (int k = 0; k < GB_NI; ++k) bsum[k][0] = bsum[k][1] = 0.f;
 
   auto fetch = [&](int s) {
     const int tile = t0 + s / KS_PER_TILE, c0 = (s % KS_PER_TILE) * GB_KS;
-    const __bf16* base = sv + (size_t)tile * tile_elems;
+    const unsigned* base = sv + (size_t)tile * tile_dwords;
 #pragma unroll
-    for (int k = 0; k < GB_NF; ++k) {
-      const int row = row0 + 32 * k;
-      ra[k] = *reinterpret_cast<const bf16x8*>(base + it.dz_off + (size_t)row * TL + c0 + 8 * seg);
-      if (!ENC)
-        rb[k] = *reinterpret_cast<const f16x8*>(reinterpret_cast<const _Float16*>(base) + it.z_off +
-                                                (size_t)(it.n0 + row) * TL + c0 + 8 * seg);
+    for (int k = 0; k < GB_NI; ++k) {
+      const int pair = pair0 + 32 * k;
+      if (!LASTROWS || pair < 2) {
+        const unsigned* p = base + it.dz_off + (size_t)pair * TL + c0 + 8 * seg;
+        ra[k][0] = *reinterpret_cast<const u32x4*>(p);
+        ra[k][1] = *reinterpret_cast<const u32x4*>(p + 4);
+      }
+      if (!ENC) {
+        const unsigned* p = base + it.z_off + (size_t)(it.n0 / 2 + pair) * TL + c0 + 8 * seg;
+        rb[k][0] = *reinterpret_cast<const u32x4*>(p);
+        rb[k][1] = *reinterpret_cast<const u32x4*>(p + 4);
+      }
     }
     if (ENC && t < GB_KS * 3) {  // the stage's 64 coordinates, 192 floats: rows past B read as coordinate 0
       const long long r = (long long)tile * TL + c0 + t / 3;
       xs_lds[(s & 1) * GB_KS * 3 + t] = r < a.B ? a.coords[3 * r + (t % 3)] : 0.f;
     }
   };
-  // second half of a stage's staging: A pieces as they are, B pieces through the sine; `part` = which two of the 8
-  auto stash_part = [&](int s, int part) {
+  // staging of item `k` of stage s: A rows as they are (and into the row sums, once: `count`), B rows through the sine
+  auto stash_item = [&](int s, int k, bool count) {
     __bf16* st = lds + (size_t)(s & 1) * GB_STAGE;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int k = 2 * part + kk, row = row0 + 32 * k;
-      *reinterpret_cast<bf16x8*>(st + row * GB_PITCH + 8 * seg) = ra[k];
-      bf16x8 hb;
-      if (ENC)
-        hb = gauss_features(xs_lds + (s & 1) * GB_KS * 3 + 24 * seg, encB_lds, a.E, it.n0 + row);
-      else
-        hb = sin_of_z(rb[k], it.krev);
-      *reinterpret_cast<bf16x8*>(st + GB_TILE + row * GB_PITCH + 8 * seg) = hb;
+    const int pair = pair0 + 32 * k;
+    if (!LASTROWS || pair < 2) {
+      u32x4 ev, od;
+      split_rows(ra[k][0], ra[k][1], ev, od);
+      *reinterpret_cast<u32x4*>(st + (2 * pair) * GB_PITCH + 8 * seg) = ev;
+      *reinterpret_cast<u32x4*>(st + (2 * pair + 1) * GB_PITCH + 8 * seg) = od;
+      if (BIAS && count) {
+        bsum[k][0] = sum8(ev, bsum[k][0]);
+        bsum[k][1] = sum8(od, bsum[k][1]);
+      }
     }
+    u32x4 ev, od;
+    if (ENC) {
+      ev = gauss_features(xs_lds + (s & 1) * GB_KS * 3 + 24 * seg, encB_lds, a.E, it.n0 + 2 * pair);
+      od = gauss_features(xs_lds + (s & 1) * GB_KS * 3 + 24 * seg, encB_lds, a.E, it.n0 + 2 * pair + 1);
+    } else {
+      sin_rows(rb[k][0], rb[k][1], it.krev, ev, od);
+    }
+    *reinterpret_cast<u32x4*>(st + GB_TILE + (2 * pair) * GB_PITCH + 8 * seg) = ev;
+    *reinterpret_cast<u32x4*>(st + GB_TILE + (2 * pair + 1) * GB_PITCH + 8 * seg) = od;
   };
-
-  bf16x8 ones;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
 
   if (n_steps > 0) {
     fetch(0);
-    if (ENC) __syncthreads();  // xs of stage 0 (and the encoder matrix) are in LDS
+    if (ENC || LASTROWS) __syncthreads();  // xs of stage 0, the encoder matrix, the zeroed A tiles
 #pragma unroll
-    for (int part = 0; part < 4; ++part) stash_part(0, part);
+    for (int k = 0; k < GB_NI; ++k) stash_item(0, k, true);
   }
   __syncthreads();
   const __bf16* As = lds + (wm * 128 + li) * GB_PITCH + 8 * half;
@@ -140,32 +198,33 @@ __device__ __forceinline__ void dwgb_body(const DwGemmBf16Args& a, const DwGemmB
 #pragma unroll 1
   for (int s = 0; s < n_steps; ++s) {
     // stage s+1 is fetched and staged while stage s multiplies.  The last iteration re-stages stage s itself
-    // (identical bytes over identical bytes) instead of branching: one basic block per iteration, so that the
-    // scheduler may lay the sines between the MFMAs.
-    const int sn = s + 1 < n_steps ? s + 1 : s;
+    // (identical bytes over identical bytes; not counted into the row sums) instead of branching: one basic block per
+    // iteration, so that the scheduler may lay the sines between the MFMAs.
+    const bool more = s + 1 < n_steps;
+    const int sn = more ? s + 1 : s;
     fetch(sn);
     const __bf16* Ab = As + (size_t)(s & 1) * GB_STAGE;
     const __bf16* Bb = Bs + (size_t)(s & 1) * GB_STAGE;
-    if (ENC) __syncthreads();  // xs of stage sn is complete before any stash_part(sn, .) reads it
+    if (ENC) __syncthreads();  // xs of stage sn is complete before any stash_item(sn, .) reads it
 #pragma unroll
     for (int q = 0; q < 4; ++q) {  // four K = 16 sub-steps of the stage's 64 coordinates
       bf16x8 A[4], B[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) A[i] = *reinterpret_cast<const bf16x8*>(Ab + i * 32 * GB_PITCH + 16 * q);
+      for (int i = 0; i < (LASTROWS ? 1 : 4); ++i) A[i] = *reinterpret_cast<const bf16x8*>(Ab + i * 32 * GB_PITCH + 16 * q);
 #pragma unroll
       for (int j = 0; j < 4; ++j) B[j] = *reinterpret_cast<const bf16x8*>(Bb + j * 32 * GB_PITCH + 16 * q);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < (LASTROWS ? 1 : 4); ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i], B[j], acc[i][j], 0, 0, 0);
-        if (BIAS) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i], ones, accb[i], 0, 0, 0);
-      }
-      stash_part(sn, q);  // a quarter of the next stage's sines in the shadow of this sub-step's MFMAs
+      stash_item(sn, q, more);  // a quarter of the next stage's staging in the shadow of this sub-step's MFMAs
+      if (!LASTROWS) {
 #pragma unroll
-      for (int n = 0; n < (BIAS ? 20 : 16); ++n) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 // one MFMA
-        __builtin_amdgcn_sched_group_barrier(0x002, BIAS ? 4 : 5, 0);      // the VALU work it hides
+        for (int n = 0; n < 16; ++n) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);  // the VALU work it hides
+        }
       }
     }
     __syncthreads();
@@ -173,7 +232,7 @@ __device__ __forceinline__ void dwgb_body(const DwGemmBf16Args& a, const DwGemmB
   // ---- chunk slab: dW rows follow the MFMA C layout (register r of lane (li, half): row (r&3)+8(r>>2)+4 half, col li)
   float* slab = a.slabs + (size_t)kc * a.slab_floats;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < (LASTROWS ? 1 : 4); ++i) {
     const int rb0 = 32 * (4 * wm + i);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -182,13 +241,23 @@ __device__ __forceinline__ void dwgb_body(const DwGemmBf16Args& a, const DwGemmB
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = rb0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          slab[it.gw_off + (size_t)row * it.K + col] = acc[i][j][r];
+          if (row < it.M) slab[it.gw_off + (size_t)row * it.K + col] = acc[i][j][r];
         }
       }
     }
-    if (BIAS && wn == 0 && li == 0) {  // every column of accb is the row sum: column 0 stores it
+  }
+  if (BIAS) {  // the 8 threads of a row pair (consecutive lanes) each hold the sum of their 8-coordinate segments
 #pragma unroll
-      for (int r = 0; r < 16; ++r) slab[it.gb_off + rb0 + (r & 3) + 8 * (r >> 2) + 4 * half] = accb[i][r];
+    for (int k = 0; k < GB_NI; ++k) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        float v = bsum[k][e];
+        v += __shfl_xor(v, 1);
+        v += __shfl_xor(v, 2);
+        v += __shfl_xor(v, 4);
+        const int row = 2 * (pair0 + 32 * k) + e;
+        if (seg == 0 && row < it.M) slab[it.gb_off + row] = v;
+      }
     }
   }
 }
@@ -200,11 +269,13 @@ __global__ __launch_bounds__(256) void dw_gemm_bf16_kernel(const DwGemmBf16Args 
   const DwGemmBf16Unit& it = a.unit[blockIdx.x - kc * a.n_units];
   if (it.z_off < 0) {
     if (it.n0 == 0)
-      dwgb_body<TL, true, true>(a, it, kc, lds_raw);
+      dwgb_body<TL, true, true, false>(a, it, kc, lds_raw);
     else
-      dwgb_body<TL, true, false>(a, it, kc, lds_raw);
+      dwgb_body<TL, true, false, false>(a, it, kc, lds_raw);
+  } else if (it.M <= 4) {
+    dwgb_body<TL, false, true, true>(a, it, kc, lds_raw);  // last layer: out_features <= 4 rows of dZ
   } else {
-    dwgb_body<TL, false, true>(a, it, kc, lds_raw);  // hidden layers: one column tile (K <= 256), always with db
+    dwgb_body<TL, false, true, false>(a, it, kc, lds_raw);  // hidden layers: one column tile (K <= 256), always with db
   }
 }
 

@@ -1,0 +1,355 @@
+// inr_siren_bf16_impl.h -- fused SIREN training step on the bf16 matrix pipe, second design ("weights in LDS,
+// activations in registers"): forward + pointwise loss + backward-to-inputs for tiles of 128 coordinates; the weight
+// gradients are left to inr_dw_gemm_bf16.hip, which reads the operands this kernel stashes.
+//
+// Why a second design.  The first bf16 kernel (inr_mlp_bf16_impl.h, still used for the unfused forward / backward
+// entry points) kept the fp32 kernel's mapping: every wave streams every weight fragment from L2 for its own 32
+// coordinates.  At fp32 MFMA rates that stream is hidden; at bf16 rates (8 MFMAs = 256 cycles per 8 KB of fragments
+// per wave) it is the bound -- phase stamps show its GEMM loops at 5-6x their MFMA time -- and half of the kernel
+// went into per-tile weight-gradient slabs.  Here:
+//   * the layer's weights travel HBM/L2 -> LDS ONCE per workgroup and K-chunk (LDS-DMA, global_load_lds_dwordx4, no
+//     VGPRs, no VALU), as pre-packed MFMA A fragments: a chunk = 64 input features x 256 output rows = 32 fragments
+//     of 1 KB = 32 KB; a 4-slot ring (128 KB) keeps three chunks in flight ahead of the one being multiplied; the four
+//     waves of the workgroup read the same fragments (conflict-free ds_read_b128: lane l reads bytes [16 l, 16 l + 16));
+//   * activations never touch LDS: the fp32 accumulator of layer l (features in registers, coordinates on lanes),
+//     after bias + sin + v_cvt_pk_bf16_f32, IS the B operand of layer l+1 (cdna_hip_programming.md section 3, "An
+//     accumulator tile as the next MFMA's operand"): element j of lane-half h of K-step (m, s) is feature
+//     32 m + 16 s + 8 (j >> 2) + 4 h + (j & 3), and the weight fragments are packed with the same k order
+//     (adam_pack_kernel, put_w2);
+//   * backward mirrors it with the transposed images: dZ_l = dH_l * w0 cos(w0 z_l) is formed in registers from the
+//     accumulator of the previous dX GEMM and the stashed z_l, and is the B operand of dH_{l-1} = W_l^T dZ_l;
+//   * the stash holds z_l (fp16) and dZ_l (bf16), 4 KB per coordinate, in "row-pair" layout: element (row 2p + e,
+//     coordinate c) of a tile at dword p * TL + c, half e -- registers (4g, 4g+1) of an accumulator are rows
+//     (2p, 2p+1) of the lane's coordinate, so one v_cvt_pk + one dword store per pair, 128 contiguous bytes per
+//     half-wave; the GEMM kernel de-interleaves while staging.
+// Chunk stream: the packed image (NetDesc::w2_off) holds the chunks in the order a tile consumes them -- forward
+// layers 0 .. D-1, then the transposed images of layers D-1 .. 1 -- so chunk q of the stream is base + 32 KB * q.
+#pragma once
+#include "inr_mlp_impl.h"
+#include "inr_w2.h"
+
+namespace inr {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int W2_SLOTS = 4;  // ring slots of W2_CHUNK_BYTES
+
+__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+  f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ unsigned pack_f16(float a, float b) {
+  f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+}
+__device__ __forceinline__ bf16x8 pack8(const float (&v)[8]) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 u = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
+  return __builtin_bit_cast(bf16x8, u);
+}
+
+// ---- the weight-chunk ring ------------------------------------------------------------------------------------
+// issue: this wave's quarter (8 fragments of 1 KB) of chunk image `img` into ring slot `slot`
+__device__ __forceinline__ void w2_issue(const char* __restrict__ gbase, int img, int slot, char* ring, int w, int lane) {
+  const char* src = gbase + (size_t)img * W2_CHUNK_BYTES + (size_t)(8 * w) * 1024 + lane * 16;
+  char* dst = ring + slot * W2_CHUNK_BYTES + (8 * w) * 1024;
+#pragma unroll
+  for (int n = 0; n < 8; ++n)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + n * 1024),
+                                     (__attribute__((address_space(3))) void*)(dst + n * 1024), 16, 0, 0);
+}
+
+// Before multiplying chunk q: its fragments (every wave's quarter) are in LDS and every wave is done with chunk
+// q - 1, whose slot then takes chunk q + 3.  FIRST: the chunk follows an epilogue that issued other vector-memory
+// operations (the counter is in order, so only "everything older is done" can be expressed: vmcnt(0)); otherwise only
+// the DMAs of chunks q+1, q+2 (16 operations of this wave) may still be in flight.
+template <bool FIRST>
+__device__ __forceinline__ void w2_acquire(const char* __restrict__ gbase, int q, int NQ, char* ring, int w, int lane) {
+  if (FIRST)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  // keep the stream three chunks ahead: stream position q + 3 = image (q + 3) mod NQ (a tile's chunk sequence
+  // repeats), into the slot chunk q - 1 just left.  Past the end of the launch the extra loads are harmless and keep
+  // the number of operations in flight what the waits assume.
+  w2_issue(gbase, (q + 3) % NQ, (q + 3) & (W2_SLOTS - 1), ring, w, lane);
+}
+
+__device__ __forceinline__ bf16x8 w2_frag(const char* ring, int q, int s_l, int mo, int lane) {
+  return *reinterpret_cast<const bf16x8*>(ring + (q & (W2_SLOTS - 1)) * W2_CHUNK_BYTES + ((s_l * 8 + mo) * 64 + lane) * 16);
+}
+
+// one chunk = four K = 16 steps against B fragments b[0..3]; NBM row blocks (8, or 1 for the 2-row last layer)
+template <int NBM>
+__device__ __forceinline__ void w2_chunk_mma(f32x16 (&acc)[NBM], const char* ring, int q, const bf16x8 (&b)[4], int lane) {
+  bf16x8 A0[NBM], A1[NBM];
+#pragma unroll
+  for (int m = 0; m < NBM; ++m) A0[m] = w2_frag(ring, q, 0, m, lane);
+#pragma unroll
+  for (int s = 0; s < 4; s += 2) {
+#pragma unroll
+    for (int m = 0; m < NBM; ++m) A1[m] = w2_frag(ring, q, s + 1, m, lane);
+#pragma unroll
+    for (int m = 0; m < NBM; ++m) acc[m] = mfma_bf16(A0[m], b[s], acc[m]);
+    if (s + 2 < 4) {
+#pragma unroll
+      for (int m = 0; m < NBM; ++m) A0[m] = w2_frag(ring, q, s + 2, m, lane);
+    }
+#pragma unroll
+    for (int m = 0; m < NBM; ++m) acc[m] = mfma_bf16(A1[m], b[s + 1], acc[m]);
+  }
+}
+
+// ---- the kernel ---------------------------------------------------------------------------------------------------
+// Tile = 128 coordinates, wave w owns coordinates [32 w, 32 w + 32): lane (col, half).  MODE_FUSED only.
+__global__ __launch_bounds__(256) void inr_siren_bf16_kernel(const NetDesc nd, const LossDesc ld, const MlpArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+  constexpr int TL = 128, NB = 8;
+  constexpr int HSZ2 = NB * 32 * TL;  // 2-byte elements per stashed tensor
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: LDS-DMA destinations go through M0
+  const int half = lane >> 5, col = lane & 31;
+  const int wcol = w * 32 + col;
+  char* ring = lds_raw;
+  float* bias_lds = reinterpret_cast<float*>(lds_raw + W2_SLOTS * W2_CHUNK_BYTES);  // [D][256]
+  float* encB_lds = bias_lds + nd.D * 256;                                          // [E][3]
+  float* red_lds = encB_lds + 3 * nd.E;                                             // [4]
+  const int D = nd.D, E = nd.E;
+  const char* gbase = reinterpret_cast<const char*>(a.packed + nd.w2_off);
+  for (int i = tid; i < D * 256; i += 256) bias_lds[i] = a.packed[nd.w2_bias_off + i];
+  for (int i = tid; i < 3 * E; i += 256) encB_lds[i] = a.encB[i];
+  const int nq0 = w2_nq0(E), NQ = w2_nq(D, E);
+  // prime the ring: stream positions 0, 1, 2 (three in flight; every acquire adds position q + 3)
+  w2_issue(gbase, 0, 0, ring, w, lane);
+  w2_issue(gbase, 1 % NQ, 1, ring, w, lane);
+  w2_issue(gbase, 2 % NQ, 2, ring, w, lane);
+  __syncthreads();  // tables in LDS (the DMAs are waited for by the first acquire)
+  float loss_acc = 0.f;
+  int qs = 0;  // stream position (chunks consumed so far by this workgroup); chunk image = qs % NQ
+  const float w0 = nd.w0, krev = nd.w0 * 0.15915494309189535f;
+
+  for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+    const long long crow = (long long)tile * TL + wcol;
+    const bool valid = crow < a.B;
+    unsigned* sv = reinterpret_cast<unsigned*>(a.save + (size_t)tile * nd.save_floats_per_tile);  // dwords = row pairs
+    // per-lane dword offset inside a stashed tensor: pair (2 half) of block 0 group 0, own coordinate
+    const int voff = (2 * half * TL + wcol) * 4;
+    float x0 = 0.f, x1 = 0.f, x2 = 0.f;
+    if (valid) {
+      x0 = a.x[3 * crow + 0];
+      x1 = a.x[3 * crow + 1];
+      x2 = a.x[3 * crow + 2];
+    }
+    const float quarter = half ? 0.25f : 0.f;
+    bf16x8 hB[16];  // B operands of the next GEMM: K-step t = 2 m + s  <-  registers 8s .. 8s+7 of accumulator block m
+    f32x16 acc[NB];
+
+    // epilogue of a forward hidden layer l: z = acc + bias -> stash (fp16 pairs), h = sin(w0 z) -> hB
+    auto fwd_epilogue = [&](int l) {
+      const __amdgpu_buffer_rsrc_t rs = uniform_rsrc(sv + (size_t)l * (HSZ2 / 2), HSZ2 * 2);
+      const float* bl = bias_lds + l * 256 + 4 * half;
+#pragma unroll
+      for (int m = 0; m < NB; ++m) {
+        float hv[16];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(bl + 32 * m + 8 * g);
+          float z[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            z[j] = acc[m][4 * g + j] + b4[j];
+            hv[4 * g + j] = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(z[j] * krev));
+          }
+          const int so = (16 * m + 4 * g) * TL * 4;  // pair 16 m + 4 g (+ 2 half in voff), then the next pair
+          __builtin_amdgcn_raw_buffer_store_b32(pack_f16(z[0], z[1]), rs, voff, so, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(pack_f16(z[2], z[3]), rs, voff, so + TL * 4, 0);
+        }
+        float lo[8], hi[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          lo[j] = hv[j];
+          hi[j] = hv[8 + j];
+        }
+        hB[2 * m] = pack8(lo);
+        hB[2 * m + 1] = pack8(hi);
+      }
+    };
+
+    // ================================ forward =================================
+    // ---- layer 0: 2E encoder features generated per K-step (half 0: sines, half 1: cosines of features 8t .. 8t+7)
+#pragma unroll
+    for (int m = 0; m < NB; ++m) acc[m] = zero16();
+    for (int ch = 0; ch < nq0; ++ch) {
+      if (ch == 0)
+        w2_acquire<true>(gbase, qs, NQ, ring, w, lane);
+      else
+        w2_acquire<false>(gbase, qs, NQ, ring, w, lane);
+      bf16x8 b[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int t = 4 * ch + s;
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float* bj = encB_lds + 3 * (8 * t + j);
+          f[j] = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(fmaf(x2, bj[2], fmaf(x1, bj[1], fmaf(x0, bj[0], quarter)))));
+        }
+        b[s] = pack8(f);
+      }
+      w2_chunk_mma<NB>(acc, ring, qs, b, lane);
+      ++qs;
+    }
+    fwd_epilogue(0);
+    // ---- hidden layers 1 .. D-2
+    for (int l = 1; l < D - 1; ++l) {
+#pragma unroll
+      for (int m = 0; m < NB; ++m) acc[m] = zero16();
+#pragma unroll
+      for (int ch = 0; ch < 4; ++ch) {
+        if (ch == 0)
+          w2_acquire<true>(gbase, qs, NQ, ring, w, lane);
+        else
+          w2_acquire<false>(gbase, qs, NQ, ring, w, lane);
+        const bf16x8 b[4] = {hB[4 * ch], hB[4 * ch + 1], hB[4 * ch + 2], hB[4 * ch + 3]};
+        w2_chunk_mma<NB>(acc, ring, qs, b, lane);
+        ++qs;
+      }
+      fwd_epilogue(l);
+    }
+    // ---- last layer: one row block (rows 0 .. out_f-1 live)
+    f32x16 accL[1];
+    accL[0] = zero16();
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) {
+      if (ch == 0)
+        w2_acquire<true>(gbase, qs, NQ, ring, w, lane);
+      else
+        w2_acquire<false>(gbase, qs, NQ, ring, w, lane);
+      const bf16x8 b[4] = {hB[4 * ch], hB[4 * ch + 1], hB[4 * ch + 2], hB[4 * ch + 3]};
+      w2_chunk_mma<1>(accL, ring, qs, b, lane);
+      ++qs;
+    }
+    float y[4], dy[4], g[4];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      float z = accL[0][o];  // half 0: rows 0..3
+      if (o < nd.out_f) z += bias_lds[(D - 1) * 256 + o];
+      act_fwd_rt(nd.last_act, z, w0, y[o], dy[o]);
+      g[o] = 0.f;
+      if (half == 0 && valid && o < nd.out_f && a.out != nullptr) a.out[crow * nd.out_f + o] = y[o];
+    }
+    if (half == 0 && valid && (a.mask == nullptr || a.mask[crow] != 0)) {
+      float t[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int o = 0; o < nd.out_f; ++o) t[o] = a.gt[crow * nd.out_f + o];
+      loss_acc += loss_row(ld, nd.out_f, y, t, g);
+    }
+    float dzl[4];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) dzl[o] = (half == 0 && o < nd.out_f) ? g[o] * dy[o] : 0.f;
+    // dZ_last rows (0,1), (2,3) of this coordinate: two dwords behind the hidden tensors (read by the GEMM kernel)
+    if (half == 0) {
+      unsigned* dzL = sv + (size_t)2 * (D - 1) * (HSZ2 / 2);
+      dzL[wcol] = pack_bf16(dzl[0], dzl[1]);
+      dzL[TL + wcol] = pack_bf16(dzl[2], dzl[3]);
+    }
+
+    // ================================ backward ================================
+    // dH_{D-2} = W_last^T dZ_last: one K-step (k = output row: element j of half 0 is row j for j < 4)
+    bf16x8 gB[16];
+    {
+      float v[8] = {dzl[0], dzl[1], dzl[2], dzl[3], 0.f, 0.f, 0.f, 0.f};
+      const bf16x8 b0 = pack8(v);
+      bf16x8 zero8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) zero8[j] = (__bf16)0.f;
+#pragma unroll
+      for (int m = 0; m < NB; ++m) acc[m] = zero16();
+      w2_acquire<true>(gbase, qs, NQ, ring, w, lane);
+      const bf16x8 b[4] = {b0, zero8, zero8, zero8};  // K-steps 1..3 of this chunk carry zero weights
+      w2_chunk_mma<NB>(acc, ring, qs, b, lane);
+      ++qs;
+    }
+    for (int l = D - 2; l >= 0; --l) {
+      // dZ_l = dH_l * w0 cos(w0 z_l): z_l back from the stash (row pairs), dZ_l to the stash and into gB
+      const __amdgpu_buffer_rsrc_t rz = uniform_rsrc(sv + (size_t)l * (HSZ2 / 2), HSZ2 * 2);
+      const __amdgpu_buffer_rsrc_t rg = uniform_rsrc(sv + (size_t)(D - 1 + l) * (HSZ2 / 2), HSZ2 * 2);
+#pragma unroll
+      for (int m = 0; m < NB; ++m) {
+        unsigned zz[8];
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const int so = (16 * m + 4 * gq) * TL * 4;
+          zz[2 * gq] = __builtin_amdgcn_raw_buffer_load_b32(rz, voff, so, 0);
+          zz[2 * gq + 1] = __builtin_amdgcn_raw_buffer_load_b32(rz, voff, so + TL * 4, 0);
+        }
+        float dz[16];
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const f16x2 zp = __builtin_bit_cast(f16x2, zz[2 * gq + e]);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+              const float c = __builtin_amdgcn_cosf(__builtin_amdgcn_fractf((float)zp[k] * krev));
+              dz[4 * gq + 2 * e + k] = acc[m][4 * gq + 2 * e + k] * (w0 * c);
+            }
+          }
+          const int so = (16 * m + 4 * gq) * TL * 4;
+          __builtin_amdgcn_raw_buffer_store_b32(pack_bf16(dz[4 * gq], dz[4 * gq + 1]), rg, voff, so, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(pack_bf16(dz[4 * gq + 2], dz[4 * gq + 3]), rg, voff, so + TL * 4, 0);
+        }
+        float lo[8], hi[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          lo[j] = dz[j];
+          hi[j] = dz[8 + j];
+        }
+        gB[2 * m] = pack8(lo);
+        gB[2 * m + 1] = pack8(hi);
+      }
+      if (l == 0) break;
+      // dH_{l-1} = W_l^T dZ_l
+#pragma unroll
+      for (int m = 0; m < NB; ++m) acc[m] = zero16();
+#pragma unroll
+      for (int ch = 0; ch < 4; ++ch) {
+        if (ch == 0)
+          w2_acquire<true>(gbase, qs, NQ, ring, w, lane);
+        else
+          w2_acquire<false>(gbase, qs, NQ, ring, w, lane);
+        const bf16x8 b[4] = {gB[4 * ch], gB[4 * ch + 1], gB[4 * ch + 2], gB[4 * ch + 3]};
+        w2_chunk_mma<NB>(acc, ring, qs, b, lane);
+        ++qs;
+      }
+    }
+  }
+  // every DMA this wave issued has landed before the workgroup (and its LDS) goes away
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // block loss partial -> slab loss word (fixed order: wave shuffle tree, then waves in order)
+  float v = loss_acc;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  __syncthreads();
+  if (lane == 0) red_lds[w] = v;
+  __syncthreads();
+  if (tid == 0) a.slabs[(size_t)blockIdx.x * nd.slab_floats + nd.slab_loss_off] = ((red_lds[0] + red_lds[1]) + red_lds[2]) + red_lds[3];
+}
+
+inline hipError_t launch_siren_bf16_fused(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int grid, hipStream_t st) {
+  const size_t lds_bytes = (size_t)W2_SLOTS * W2_CHUNK_BYTES + ((size_t)nd.D * 256 + 3 * (size_t)nd.E + 4) * sizeof(float);
+  if (lds_bytes > 160 * 1024 || a.save == nullptr || a.slabs == nullptr || a.save_by_block) return hipErrorInvalidValue;
+  hipError_t e = allow_full_lds<inr_siren_bf16_kernel>();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(inr_siren_bf16_kernel, dim3(grid), dim3(256), lds_bytes, st, nd, ld, a);
+  return hipGetLastError();
+}
+
+}  // namespace inr

@@ -56,6 +56,13 @@ def test_bf16_step_close_to_fp32(dev, B, width, depth):
     l16 = float(e16.train_step(coords, encB, gt, spec, count=cnt, mask=mask))
     assert abs(l16 - l32) <= 2e-2 * abs(l32)
     assert rel_l2(e16.grads, e32.grads) < 6e-2, rel_l2(e16.grads, e32.grads)
+    # tensor by tensor (a bias vector is a millionth of the gradient's norm: a wrong row sum would hide in the total)
+    bad = []
+    for (name, p_), (o, n, s_, c) in zip(m16.named_parameters(), m16._layout):
+        a, b = e16.grads[o:o + n], e32.grads[o:o + n]
+        if float(b.norm()) > 0 and rel_l2(a, b) > 1e-1:
+            bad.append((name, rel_l2(a, b)))
+    assert not bad, bad
     # deterministic: a second launch reproduces the first bit for bit
     g1 = e16.grads.clone()
     e16.train_step(coords, encB, gt, spec, count=cnt, mask=mask)
@@ -93,8 +100,9 @@ def test_bf16_plan_limits(dev):
 
 
 def test_bf16_unfused_halves_match_fused(dev):
-    """inr_forward(save) + inr_loss_grad + inr_backward on a bf16 plan (what the per-coil TV step uses) gives the
-    fused bf16 step's gradient: same kernels' loops, only the loss gradient travels through memory."""
+    """inr_forward(save) + inr_loss_grad + inr_backward on a bf16 plan (what the per-coil TV step uses; the first bf16
+    kernel, per-wave weight streams and in-kernel dW) against the fused bf16 step (weights in LDS + batch dW GEMM):
+    different kernels, same bf16 operand roundings up to summation order."""
     import inr_mi355x as M
     from inr_mi355x import _lib as L
     enc, m32, m16, e32, e16 = _pair(dev, 11)
@@ -109,5 +117,5 @@ def test_bf16_unfused_halves_match_fused(dev):
     out = e16.forward(coords, encB, save=True)
     loss, dout = e16.loss_grad(spec, out, gt, B)
     gu = e16.backward(coords, encB, dout)
-    assert abs(float(loss) - lf) <= 1e-6 * abs(lf)
-    assert rel_l2(gu, gf) < 1e-5
+    assert abs(float(loss) - lf) <= 2e-3 * abs(lf)
+    assert rel_l2(gu, gf) < 2e-2, rel_l2(gu, gf)
