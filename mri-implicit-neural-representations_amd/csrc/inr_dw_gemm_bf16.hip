@@ -14,7 +14,7 @@
 // encoder features regenerated from the tile's coordinates exactly as the forward pass formed them (sine of x.B_j
 // revolutions, + 1/4 turn for the cosine half).  A thread stages (row pair, 8 coordinates) items: two 16-byte loads,
 // de-interleaved into one 16-byte LDS piece per row (v_perm_b32 for dZ; for z the sine pass unpacks anyway); the row
-// sums db come from the same registers (v_dot2_f32_bf16 against a constant pair of ones), reduced over the 8 threads
+// sums db come from the same registers (bf16 -> fp32 on the integer bits, fp32 adds), reduced over the 8 threads
 // of a row at the end.
 //
 // Workgroup = one 256 x 256 block of one layer's dW over one chunk of tiles; four waves 2 x 2, 4 x 4 MFMA blocks each
@@ -59,10 +59,15 @@ __device__ __forceinline__ void split_rows(const u32x4& a, const u32x4& b, u32x4
   odd[3] = __builtin_amdgcn_perm(b[3], b[2], 0x07060302u);
 }
 
+// sum of 8 bf16 (4 dwords) into acc.  (Written on the integer bits: with v_dot2_f32_bf16 against a pair of ones hipcc 7.2
+// selected the FIRST dword for all four dot products of an unrolled loop over the vector's elements -- the row sums came
+// out as 4 x the first coordinate pair.)
 __device__ __forceinline__ float sum8(const u32x4& v, float acc) {
-  const bf16x2 one2 = {(__bf16)1.0f, (__bf16)1.0f};
 #pragma unroll
-  for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, v[i]), one2, acc, false);
+  for (int i = 0; i < 4; ++i) {
+    const unsigned d = v[i];
+    acc += __builtin_bit_cast(float, d << 16) + __builtin_bit_cast(float, d & 0xffff0000u);
+  }
   return acc;
 }
 

@@ -55,14 +55,14 @@ def test_bf16_step_close_to_fp32(dev, B, width, depth):
     l32 = float(e32.train_step(coords, encB, gt, spec, count=cnt, mask=mask))
     l16 = float(e16.train_step(coords, encB, gt, spec, count=cnt, mask=mask))
     assert abs(l16 - l32) <= 2e-2 * abs(l32)
-    assert rel_l2(e16.grads, e32.grads) < 6e-2, rel_l2(e16.grads, e32.grads)
     # tensor by tensor (a bias vector is a millionth of the gradient's norm: a wrong row sum would hide in the total)
     bad = []
     for (name, p_), (o, n, s_, c) in zip(m16.named_parameters(), m16._layout):
         a, b = e16.grads[o:o + n], e32.grads[o:o + n]
         if float(b.norm()) > 0 and rel_l2(a, b) > 1e-1:
-            bad.append((name, rel_l2(a, b)))
+            bad.append((name, round(rel_l2(a, b), 4), round(float(a.norm() / b.norm()), 4)))
     assert not bad, bad
+    assert rel_l2(e16.grads, e32.grads) < 6e-2, rel_l2(e16.grads, e32.grads)
     # deterministic: a second launch reproduces the first bit for bit
     g1 = e16.grads.clone()
     e16.train_step(coords, encB, gt, spec, count=cnt, mask=mask)
