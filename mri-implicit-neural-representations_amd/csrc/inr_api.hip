@@ -569,6 +569,10 @@ int inr_plan_launch_dims(const inr_plan* plan, int64_t B, int64_t* n_tiles, int6
   const int tl = 32 * plan->nd.NW;
   *n_tiles = (B + tl - 1) / tl;
   *n_blocks = *n_tiles < kMaxBlocks ? *n_tiles : kMaxBlocks;
+  if (plan->nd.bf16 && plan->nd.w2_off >= 0) {  // the fused bf16 kernel's workgroups take two 128-coordinate tiles each
+    const int64_t wt = *n_tiles > kMaxBlocks ? (*n_tiles + 1) / 2 : *n_tiles;  // (one each while that fills fewer CUs)
+    *n_blocks = wt < kMaxBlocks ? wt : kMaxBlocks;
+  }
   return INR_OK;
 }
 

@@ -354,7 +354,10 @@ __device__ __forceinline__ void put_w2(const NetDesc& nd, int l, float* packed, 
   } else {
     w2_kperm_inv(k, t, h, j);
   }
-  img[w2_index(w2_qf(l, nd.E) + (t >> 2), t & 3, row >> 5, h * 32 + (row & 31), j)] = (__bf16)v;
+  if (l == nd.D - 1)  // last layer (rows < 32): its 16 K-steps x 1 row block in one chunk
+    img[w2_index_last(w2_qf(l, nd.D, nd.E), t, h * 32 + row, j)] = (__bf16)v;
+  else
+    img[w2_index(w2_qf(l, nd.D, nd.E) + (t >> 2), t & 3, row >> 5, h * 32 + (row & 31), j)] = (__bf16)v;
   if (l >= 1) {
     w2_kperm_inv(row, t, h, j);
     img[w2_index(w2_qt(l, nd.D, nd.E) + (t >> 2), t & 3, k >> 5, h * 32 + (k & 31), j)] = (__bf16)v;

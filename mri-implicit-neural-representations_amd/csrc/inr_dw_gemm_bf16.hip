@@ -17,10 +17,10 @@
 // sums db come from the same registers (bf16 -> fp32 on the integer bits, fp32 adds), reduced over the 8 threads
 // of a row at the end.
 //
-// Workgroup = one 256 x 256 block of one layer's dW over one chunk of tiles; four waves 2 x 2, 4 x 4 MFMA blocks each
-// (256 accumulator registers); K-steps of 64 coordinates staged through two LDS stages, rows pitched 144 B so that the
-// 16-byte fragment reads of 16 consecutive rows hit 16 distinct 4-bank slots; the sines of stage s+1 are computed in
-// the shadow of the MFMAs of stage s.
+// Workgroup = one 256 x 256 block of one layer's dW over one chunk of tiles; EIGHT waves 4 x 2 (two per SIMD), 2 x 4
+// MFMA blocks each (128 accumulator registers): the staging of the next stage -- as many VALU cycles as the stage has
+// MFMA cycles -- runs in one wave of a SIMD while the other multiplies.  K-steps of 64 coordinates staged through two
+// LDS stages, rows pitched 144 B so that the 16-byte fragment reads of 16 consecutive rows hit 16 distinct 4-bank slots.
 #include <hip/hip_runtime.h>
 
 #include "inr_dw_gemm_bf16.h"
@@ -40,7 +40,8 @@ constexpr int GB_KS = 64;                 // coordinates per stage
 constexpr int GB_PITCH = 72;              // LDS row pitch in 2-byte elements: 64 coordinates + 16 bytes of padding
 constexpr int GB_TILE = 256 * GB_PITCH;   // one operand tile (elements)
 constexpr int GB_STAGE = 2 * GB_TILE;     // A tile + B tile
-constexpr int GB_NI = 4;                  // (row pair, 8 coordinates) items per thread, operand and stage
+constexpr int GB_NT = 512;                // threads: eight waves, two per SIMD (staging of one hides under MFMAs of the other)
+constexpr int GB_NI = 2;                  // (row pair, 8 coordinates) items per thread, operand and stage
 
 __device__ __forceinline__ unsigned pk_bf16(float a, float b) {
   f32x2 v = {a, b};
@@ -112,67 +113,81 @@ __device__ __forceinline__ void dwgb_body(const DwGemmBf16Args& a, const DwGemmB
   float* encB_lds = xs_lds + 2 * GB_KS * 3;                                      // [E][3]
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int half = lane >> 5, li = lane & 31;
-  const int wm = w >> 1, wn = w & 1;
+  const int wm = w >> 1, wn = w & 1;  // wave tile: rows [64 wm, +64) x columns [128 wn, +128) = 2 x 4 MFMA blocks
   constexpr int KS_PER_TILE = TL / GB_KS;
   const int t0 = kc * a.tiles_per_chunk;
   int n_mine = a.n_tiles - t0;
   if (n_mine > a.tiles_per_chunk) n_mine = a.tiles_per_chunk;
   const int n_steps = (n_mine > 0 ? n_mine : 0) * KS_PER_TILE;
 
-  f32x16 acc[4][4];
+  f32x16 acc[2][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   if (ENC)
-    for (int i = t; i < 3 * a.E; i += 256) encB_lds[i] = a.encB[i];
+    for (int i = t; i < 3 * a.E; i += GB_NT) encB_lds[i] = a.encB[i];
   if (LASTROWS) {  // rows the loader never writes must read as zeros (both stages; B tiles are always written whole)
     u32x4 z4 = {0u, 0u, 0u, 0u};
-    for (int i = t; i < 2 * 256 * 9; i += 256) {
+    for (int i = t; i < 2 * 256 * 9; i += GB_NT) {
       const int st = i / (256 * 9), rem = i - st * 256 * 9, row = rem / 9, piece = rem - row * 9;
       *reinterpret_cast<u32x4*>(lds + (size_t)st * GB_STAGE + row * GB_PITCH + 8 * piece) = z4;
     }
   }
-  // loader: item k of thread t = row pair (t >> 3) + 32 k, coordinates 8 (t & 7) .. + 7 of the stage
+  // loader: item k of thread t = row pair (t >> 3) + 64 k, coordinates 8 (t & 7) .. + 7 of the stage
   const int seg = t & 7, pair0 = t >> 3;
   const unsigned* sv = reinterpret_cast<const unsigned*>(a.save);
   const size_t tile_dwords = (size_t)a.save_floats_per_tile;
-  u32x4 ra[GB_NI][2], rb[GB_NI][2];
+  // two register sets: while stage s multiplies, set (s+1)&1 -- fetched a whole stage earlier -- is staged into LDS and
+  // then refilled with stage s+3 (global latency is several microseconds under load; a stage is ~1)
+  u32x4 ra[2][GB_NI][2], rb[2][GB_NI][2];
   float bsum[GB_NI][2];
 #pragma unroll
   for (int k = 0; k < GB_NI; ++k) bsum[k][0] = bsum[k][1] = 0.f;
 
-  auto fetch = [&](int s) {
+  auto fetch = [&](int s, u32x4 (&A)[GB_NI][2], u32x4 (&B)[GB_NI][2]) {
+    if (s >= n_steps) s = n_steps - 1;  // past the end: the last stage again (loaded, never multiplied)
     const int tile = t0 + s / KS_PER_TILE, c0 = (s % KS_PER_TILE) * GB_KS;
     const unsigned* base = sv + (size_t)tile * tile_dwords;
 #pragma unroll
     for (int k = 0; k < GB_NI; ++k) {
-      const int pair = pair0 + 32 * k;
+      const int pair = pair0 + 64 * k;
       if (!LASTROWS || pair < 2) {
         const unsigned* p = base + it.dz_off + (size_t)pair * TL + c0 + 8 * seg;
-        ra[k][0] = *reinterpret_cast<const u32x4*>(p);
-        ra[k][1] = *reinterpret_cast<const u32x4*>(p + 4);
+        A[k][0] = *reinterpret_cast<const u32x4*>(p);
+        A[k][1] = *reinterpret_cast<const u32x4*>(p + 4);
       }
       if (!ENC) {
         const unsigned* p = base + it.z_off + (size_t)(it.n0 / 2 + pair) * TL + c0 + 8 * seg;
-        rb[k][0] = *reinterpret_cast<const u32x4*>(p);
-        rb[k][1] = *reinterpret_cast<const u32x4*>(p + 4);
+        B[k][0] = *reinterpret_cast<const u32x4*>(p);
+        B[k][1] = *reinterpret_cast<const u32x4*>(p + 4);
       }
     }
-    if (ENC && t < GB_KS * 3) {  // the stage's 64 coordinates, 192 floats: rows past B read as coordinate 0
+  };
+  // the coordinates of stage s (first-layer units: the encoder features are regenerated from them): 64 coordinates =
+  // 192 floats, one per thread t < 192, loaded a stage before they are put into LDS; rows past B read as coordinate 0
+  auto xs_get = [&](int s) -> float {
+    float v = 0.f;
+    if (ENC && t < GB_KS * 3) {
+      if (s >= n_steps) s = n_steps - 1;
+      const int tile = t0 + s / KS_PER_TILE, c0 = (s % KS_PER_TILE) * GB_KS;
       const long long r = (long long)tile * TL + c0 + t / 3;
-      xs_lds[(s & 1) * GB_KS * 3 + t] = r < a.B ? a.coords[3 * r + (t % 3)] : 0.f;
+      if (r < a.B) v = a.coords[3 * r + (t % 3)];
     }
+    return v;
+  };
+  auto xs_put = [&](int s, float v) {
+    if (ENC && t < GB_KS * 3) xs_lds[(s & 1) * GB_KS * 3 + t] = v;
   };
   // staging of item `k` of stage s: A rows as they are (and into the row sums, once: `count`), B rows through the sine
-  auto stash_item = [&](int s, int k, bool count) {
+  auto stash_item = [&](int s, int k, bool count, const u32x4 (&A)[GB_NI][2], const u32x4 (&B)[GB_NI][2]) {
     __bf16* st = lds + (size_t)(s & 1) * GB_STAGE;
-    const int pair = pair0 + 32 * k;
+    const int pair = pair0 + 64 * k;
     if (!LASTROWS || pair < 2) {
       u32x4 ev, od;
-      split_rows(ra[k][0], ra[k][1], ev, od);
+      split_rows(A[k][0], A[k][1], ev, od);
       *reinterpret_cast<u32x4*>(st + (2 * pair) * GB_PITCH + 8 * seg) = ev;
       *reinterpret_cast<u32x4*>(st + (2 * pair + 1) * GB_PITCH + 8 * seg) = od;
       if (BIAS && count) {
@@ -185,60 +200,66 @@ __device__ __forceinline__ void dwgb_body(const DwGemmBf16Args& a, const DwGemmB
       ev = gauss_features(xs_lds + (s & 1) * GB_KS * 3 + 24 * seg, encB_lds, a.E, it.n0 + 2 * pair);
       od = gauss_features(xs_lds + (s & 1) * GB_KS * 3 + 24 * seg, encB_lds, a.E, it.n0 + 2 * pair + 1);
     } else {
-      sin_rows(rb[k][0], rb[k][1], it.krev, ev, od);
+      sin_rows(B[k][0], B[k][1], it.krev, ev, od);
     }
     *reinterpret_cast<u32x4*>(st + GB_TILE + (2 * pair) * GB_PITCH + 8 * seg) = ev;
     *reinterpret_cast<u32x4*>(st + GB_TILE + (2 * pair + 1) * GB_PITCH + 8 * seg) = od;
   };
-
-  if (n_steps > 0) {
-    fetch(0);
-    if (ENC || LASTROWS) __syncthreads();  // xs of stage 0, the encoder matrix, the zeroed A tiles
-#pragma unroll
-    for (int k = 0; k < GB_NI; ++k) stash_item(0, k, true);
-  }
-  __syncthreads();
-  const __bf16* As = lds + (wm * 128 + li) * GB_PITCH + 8 * half;
+  const __bf16* As = lds + (wm * 64 + li) * GB_PITCH + 8 * half;
   const __bf16* Bs = lds + GB_TILE + (wn * 128 + li) * GB_PITCH + 8 * half;
-#pragma unroll 1
-  for (int s = 0; s < n_steps; ++s) {
-    // stage s+1 is fetched and staged while stage s multiplies.  The last iteration re-stages stage s itself
-    // (identical bytes over identical bytes; not counted into the row sums) instead of branching: one basic block per
-    // iteration, so that the scheduler may lay the sines between the MFMAs.
+  // stage s multiplies out of LDS stage s & 1 while register set `N` (stage s+1) is staged into the other one
+  auto compute = [&](int s, u32x4 (&NA)[GB_NI][2], u32x4 (&NB)[GB_NI][2]) {
     const bool more = s + 1 < n_steps;
-    const int sn = more ? s + 1 : s;
-    fetch(sn);
     const __bf16* Ab = As + (size_t)(s & 1) * GB_STAGE;
     const __bf16* Bb = Bs + (size_t)(s & 1) * GB_STAGE;
-    if (ENC) __syncthreads();  // xs of stage sn is complete before any stash_item(sn, .) reads it
 #pragma unroll
     for (int q = 0; q < 4; ++q) {  // four K = 16 sub-steps of the stage's 64 coordinates
-      bf16x8 A[4], B[4];
+      bf16x8 A[2], B[4];
 #pragma unroll
-      for (int i = 0; i < (LASTROWS ? 1 : 4); ++i) A[i] = *reinterpret_cast<const bf16x8*>(Ab + i * 32 * GB_PITCH + 16 * q);
+      for (int i = 0; i < (LASTROWS ? 1 : 2); ++i) A[i] = *reinterpret_cast<const bf16x8*>(Ab + i * 32 * GB_PITCH + 16 * q);
 #pragma unroll
       for (int j = 0; j < 4; ++j) B[j] = *reinterpret_cast<const bf16x8*>(Bb + j * 32 * GB_PITCH + 16 * q);
 #pragma unroll
-      for (int i = 0; i < (LASTROWS ? 1 : 4); ++i)
+      for (int i = 0; i < (LASTROWS ? 1 : 2); ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i], B[j], acc[i][j], 0, 0, 0);
-      stash_item(sn, q, more);  // a quarter of the next stage's staging in the shadow of this sub-step's MFMAs
-      if (!LASTROWS) {
-#pragma unroll
-        for (int n = 0; n < 16; ++n) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
-          __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);  // the VALU work it hides
-        }
-      }
+      if (q < GB_NI) stash_item(s + 1, q, more, NA, NB);  // half of the next stage's staging per sub-step
     }
+  };
+
+  float xs_next = 0.f;
+  if (n_steps > 0) {  // n_steps is even (two stages per tile)
+    fetch(0, ra[0], rb[0]);
+    xs_put(0, xs_get(0));
+    xs_next = xs_get(1);
+    fetch(1, ra[1], rb[1]);
+    if (ENC || LASTROWS) __syncthreads();  // xs of stage 0, the encoder matrix, the zeroed A tiles
+#pragma unroll
+    for (int k = 0; k < GB_NI; ++k) stash_item(0, k, true, ra[0], rb[0]);
+    fetch(2, ra[0], rb[0]);
+    xs_put(1, xs_next);
+    xs_next = xs_get(2);
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int s = 0; s < n_steps; s += 2) {
+    compute(s, ra[1], rb[1]);       // stage s+1 -> LDS from set 1 ...
+    fetch(s + 3, ra[1], rb[1]);     // ... which then takes stage s+3
+    xs_put(s + 2, xs_next);         // xs buffer s & 1: last read while stage s was staged, one barrier ago
+    xs_next = xs_get(s + 3);
+    __syncthreads();
+    compute(s + 1, ra[0], rb[0]);
+    fetch(s + 4, ra[0], rb[0]);
+    xs_put(s + 3, xs_next);
+    xs_next = xs_get(s + 4);
     __syncthreads();
   }
   // ---- chunk slab: dW rows follow the MFMA C layout (register r of lane (li, half): row (r&3)+8(r>>2)+4 half, col li)
   float* slab = a.slabs + (size_t)kc * a.slab_floats;
 #pragma unroll
-  for (int i = 0; i < (LASTROWS ? 1 : 4); ++i) {
-    const int rb0 = 32 * (4 * wm + i);
+  for (int i = 0; i < (LASTROWS ? 1 : 2); ++i) {
+    const int rb0 = 32 * (2 * wm + i);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int col = it.n0 + 32 * (4 * wn + j) + li;
@@ -260,7 +281,7 @@ __device__ __forceinline__ void dwgb_body(const DwGemmBf16Args& a, const DwGemmB
         v += __shfl_xor(v, 1);
         v += __shfl_xor(v, 2);
         v += __shfl_xor(v, 4);
-        const int row = 2 * (pair0 + 32 * k) + e;
+        const int row = 2 * (pair0 + 64 * k) + e;
         if (seg == 0 && row < it.M) slab[it.gb_off + row] = v;
       }
     }
@@ -268,7 +289,7 @@ __device__ __forceinline__ void dwgb_body(const DwGemmBf16Args& a, const DwGemmB
 }
 
 template <int TL>
-__global__ __launch_bounds__(256) void dw_gemm_bf16_kernel(const DwGemmBf16Args a) {
+__global__ __launch_bounds__(GB_NT, 2) void dw_gemm_bf16_kernel(const DwGemmBf16Args a) {
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
   const int kc = blockIdx.x / a.n_units;
   const DwGemmBf16Unit& it = a.unit[blockIdx.x - kc * a.n_units];
@@ -292,7 +313,7 @@ hipError_t launch_dw_gemm_bf16(const DwGemmBf16Args& a, hipStream_t st) {
   if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
   hipError_t e = allow_full_lds<dw_gemm_bf16_kernel<128>>();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(dw_gemm_bf16_kernel<128>, dim3((unsigned)(a.n_chunks * a.n_units)), dim3(256), lds_bytes, st, a);
+  hipLaunchKernelGGL(dw_gemm_bf16_kernel<128>, dim3((unsigned)(a.n_chunks * a.n_units)), dim3(GB_NT), lds_bytes, st, a);
   return hipGetLastError();
 }
 

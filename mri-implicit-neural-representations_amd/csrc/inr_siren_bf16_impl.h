@@ -1,5 +1,5 @@
 // inr_siren_bf16_impl.h -- fused SIREN training step on the bf16 matrix pipe, second design ("weights in LDS,
-// activations in registers"): forward + pointwise loss + backward-to-inputs for tiles of 128 coordinates; the weight
+// activations in registers"): forward + pointwise loss + backward-to-inputs for tiles of 256 coordinates; the weight
 // gradients are left to inr_dw_gemm_bf16.hip, which reads the operands this kernel stashes.
 //
 // Why a second design.  The first bf16 kernel (inr_mlp_bf16_impl.h, still used for the unfused forward / backward
@@ -9,7 +9,7 @@
 // went into per-tile weight-gradient slabs.  Here:
 //   * the layer's weights travel HBM/L2 -> LDS ONCE per workgroup and K-chunk (LDS-DMA, global_load_lds_dwordx4, no
 //     VGPRs, no VALU), as pre-packed MFMA A fragments: a chunk = 64 input features x 256 output rows = 32 fragments
-//     of 1 KB = 32 KB; a 4-slot ring (128 KB) keeps three chunks in flight ahead of the one being multiplied; the four
+//     of 1 KB = 32 KB; a 4-slot ring (128 KB) keeps three chunks in flight ahead of the one being multiplied; the eight
 //     waves of the workgroup read the same fragments (conflict-free ds_read_b128: lane l reads bytes [16 l, 16 l + 16));
 //   * activations never touch LDS: the fp32 accumulator of layer l (features in registers, coordinates on lanes),
 //     after bias + sin + v_cvt_pk_bf16_f32, IS the B operand of layer l+1 (cdna_hip_programming.md section 3, "An
@@ -56,26 +56,38 @@ __device__ __forceinline__ bf16x8 pack8(const float (&v)[8]) {
 }
 
 // ---- the weight-chunk ring ------------------------------------------------------------------------------------
-// issue: this wave's quarter (8 fragments of 1 KB) of chunk image `img` into ring slot `slot`
+// A workgroup is EIGHT waves = two per SIMD: while one wave of a SIMD issues LDS-DMA pieces (~60-100 cycles of issue
+// each), runs an epilogue (VALU + stash traffic) or sits in a wait, its partner keeps the matrix pipe busy.  (With one
+// wave per SIMD the phase stamps showed the GEMM phases at 3x their MFMA time: 8 DMA issues + 32 fragment reads + a
+// barrier per 32 MFMAs, all in one in-order stream.)  Hence <= 256 registers per wave.
+constexpr int W2_WAVES = 8;
+constexpr int W2_FPW = 32 / W2_WAVES;  // fragments (1 KB LDS-DMA pieces) per wave and chunk
+
+// issue: this wave's share of chunk image `img` into ring slot `slot`
 __device__ __forceinline__ void w2_issue(const char* __restrict__ gbase, int img, int slot, char* ring, int w, int lane) {
-  const char* src = gbase + (size_t)img * W2_CHUNK_BYTES + (size_t)(8 * w) * 1024 + lane * 16;
-  char* dst = ring + slot * W2_CHUNK_BYTES + (8 * w) * 1024;
+  const char* src = gbase + (size_t)img * W2_CHUNK_BYTES + (size_t)(W2_FPW * w) * 1024 + lane * 16;
+  char* dst = ring + slot * W2_CHUNK_BYTES + (W2_FPW * w) * 1024;
 #pragma unroll
-  for (int n = 0; n < 8; ++n)
+  for (int n = 0; n < W2_FPW; ++n)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + n * 1024),
                                      (__attribute__((address_space(3))) void*)(dst + n * 1024), 16, 0, 0);
 }
 
-// Before multiplying chunk q: its fragments (every wave's quarter) are in LDS and every wave is done with chunk
-// q - 1, whose slot then takes chunk q + 3.  FIRST: the chunk follows an epilogue that issued other vector-memory
-// operations (the counter is in order, so only "everything older is done" can be expressed: vmcnt(0)); otherwise only
-// the DMAs of chunks q+1, q+2 (16 operations of this wave) may still be in flight.
-template <bool FIRST>
+// Before multiplying chunk q: its fragments (every wave's share) are in LDS and every wave is done with chunk
+// q - 1, whose slot then takes chunk q + 3.
+// AFTER: what this wave issued since the DMAs of chunk q -- 0: only the DMAs of chunks q+1, q+2 (2 x W2_FPW operations
+// may stay in flight); 1: those plus an epilogue of at least 64 stores (the counter is in order and tops out at 63: "at
+// most 63 outstanding" already implies every DMA, which is older than the stores, has landed -- without draining the
+// stores); 2: anything else (drain).
+template <int AFTER>
 __device__ __forceinline__ void w2_acquire(const char* __restrict__ gbase, int q, int NQ, char* ring, int w, int lane) {
-  if (FIRST)
+  static_assert(W2_FPW == 4, "the in-GEMM wait below is vmcnt(2 * W2_FPW)");
+  if (AFTER == 2)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if (AFTER == 1)
+    asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
   else
-    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   // keep the stream three chunks ahead: stream position q + 3 = image (q + 3) mod NQ (a tile's chunk sequence
   // repeats), into the slot chunk q - 1 just left.  Past the end of the launch the extra loads are harmless and keep
@@ -87,45 +99,37 @@ __device__ __forceinline__ bf16x8 w2_frag(const char* ring, int q, int s_l, int 
   return *reinterpret_cast<const bf16x8*>(ring + (q & (W2_SLOTS - 1)) * W2_CHUNK_BYTES + ((s_l * 8 + mo) * 64 + lane) * 16);
 }
 
-// one chunk = four K = 16 steps against B fragments b[0..3]; NBM row blocks (8, or 1 for the 2-row last layer)
-template <int NBM>
-__device__ __forceinline__ void w2_chunk_mma(f32x16 (&acc)[NBM], const char* ring, int q, const bf16x8 (&b)[4], int lane) {
-  bf16x8 A0[NBM], A1[NBM];
+// one chunk = four K = 16 steps against B fragments b[0..3], 8 row blocks (the partner wave hides the LDS latency)
+__device__ __forceinline__ void w2_chunk_mma(f32x16 (&acc)[8], const char* ring, int q, const bf16x8 (&b)[4], int lane) {
 #pragma unroll
-  for (int m = 0; m < NBM; ++m) A0[m] = w2_frag(ring, q, 0, m, lane);
+  for (int s = 0; s < 4; ++s) {
+    bf16x8 A[8];
 #pragma unroll
-  for (int s = 0; s < 4; s += 2) {
+    for (int m = 0; m < 8; ++m) A[m] = w2_frag(ring, q, s, m, lane);
 #pragma unroll
-    for (int m = 0; m < NBM; ++m) A1[m] = w2_frag(ring, q, s + 1, m, lane);
-#pragma unroll
-    for (int m = 0; m < NBM; ++m) acc[m] = mfma_bf16(A0[m], b[s], acc[m]);
-    if (s + 2 < 4) {
-#pragma unroll
-      for (int m = 0; m < NBM; ++m) A0[m] = w2_frag(ring, q, s + 2, m, lane);
-    }
-#pragma unroll
-    for (int m = 0; m < NBM; ++m) acc[m] = mfma_bf16(A1[m], b[s + 1], acc[m]);
+    for (int m = 0; m < 8; ++m) acc[m] = mfma_bf16(A[m], b[s], acc[m]);
   }
 }
 
 // ---- the kernel ---------------------------------------------------------------------------------------------------
-// Tile = 128 coordinates, wave w owns coordinates [32 w, 32 w + 32): lane (col, half).  MODE_FUSED only.
-__global__ __launch_bounds__(256) void inr_siren_bf16_kernel(const NetDesc nd, const LossDesc ld, const MlpArgs a) {
+// Workgroup tile = 256 coordinates = two stash tiles of TL = 128 (what the GEMM kernel and the host count in); wave w
+// owns coordinates [32 (w & 3), + 32) of stash tile 2 * (workgroup tile) + (w >> 2): lane (col, half).  MODE_FUSED only.
+__global__ __launch_bounds__(512, 2) void inr_siren_bf16_kernel(const NetDesc nd, const LossDesc ld, const MlpArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
-  constexpr int TL = 128, NB = 8;
+  constexpr int TL = 128, NB = 8, NW = W2_WAVES;
   constexpr int HSZ2 = NB * 32 * TL;  // 2-byte elements per stashed tensor
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: LDS-DMA destinations go through M0
   const int half = lane >> 5, col = lane & 31;
-  const int wcol = w * 32 + col;
+  const int wcol = (w & 3) * 32 + col;
   char* ring = lds_raw;
   float* bias_lds = reinterpret_cast<float*>(lds_raw + W2_SLOTS * W2_CHUNK_BYTES);  // [D][256]
   float* encB_lds = bias_lds + nd.D * 256;                                          // [E][3]
-  float* red_lds = encB_lds + 3 * nd.E;                                             // [4]
+  float* red_lds = encB_lds + 3 * nd.E;                                             // [8]
   const int D = nd.D, E = nd.E;
   const char* gbase = reinterpret_cast<const char*>(a.packed + nd.w2_off);
-  for (int i = tid; i < D * 256; i += 256) bias_lds[i] = a.packed[nd.w2_bias_off + i];
-  for (int i = tid; i < 3 * E; i += 256) encB_lds[i] = a.encB[i];
+  for (int i = tid; i < D * 256; i += 64 * NW) bias_lds[i] = a.packed[nd.w2_bias_off + i];
+  for (int i = tid; i < 3 * E; i += 64 * NW) encB_lds[i] = a.encB[i];
   const int nq0 = w2_nq0(E), NQ = w2_nq(D, E);
   // prime the ring: stream positions 0, 1, 2 (three in flight; every acquire adds position q + 3)
   w2_issue(gbase, 0, 0, ring, w, lane);
@@ -135,26 +139,49 @@ __global__ __launch_bounds__(256) void inr_siren_bf16_kernel(const NetDesc nd, c
   float loss_acc = 0.f;
   int qs = 0;  // stream position (chunks consumed so far by this workgroup); chunk image = qs % NQ
   const float w0 = nd.w0, krev = nd.w0 * 0.15915494309189535f;
+  // two stash tiles per workgroup tile -- unless the batch is too small to fill the chip that way (25 000 rows = 196
+  // tiles: 98 workgroups on 256 CUs): then one, and waves 4..7 only help with the weight stream
+  const int tpw = a.n_tiles > 256 ? 2 : 1;
+  const int n_wtiles = (a.n_tiles + tpw - 1) / tpw;
 
-  for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
-    const long long crow = (long long)tile * TL + wcol;
-    const bool valid = crow < a.B;
-    unsigned* sv = reinterpret_cast<unsigned*>(a.save + (size_t)tile * nd.save_floats_per_tile);  // dwords = row pairs
-    // per-lane dword offset inside a stashed tensor: pair (2 half) of block 0 group 0, own coordinate
+  for (int wtile = blockIdx.x; wtile < n_wtiles; wtile += gridDim.x) {
+    const int stile = tpw * wtile + (w >> 2);     // this wave's stash tile
+    const bool tile_ok = (w >> 2) < tpw && stile < a.n_tiles;  // (odd tile counts: the last workgroup tile is half empty)
+    if ((w >> 2) >= tpw) {  // small batches: this half of the workgroup has no tile -- it only feeds the ring
+      for (int q = 0; q < NQ; ++q) {
+        if (q == 0)
+          w2_acquire<2>(gbase, qs, NQ, ring, w, lane);
+        else
+          w2_acquire<0>(gbase, qs, NQ, ring, w, lane);
+        ++qs;
+      }
+      continue;
+    }
+    const long long crow = (long long)stile * TL + wcol;
+    const bool valid = tile_ok && crow < a.B;
+    unsigned* sv = reinterpret_cast<unsigned*>(a.save + (size_t)(tile_ok ? stile : 0) * nd.save_floats_per_tile);
+    const int ts_bytes = tile_ok ? HSZ2 * 2 : 0;  // extent of a stashed tensor: 0 makes every buffer access a no-op
+    // per-lane byte offset inside a stashed tensor: pair (2 half) of block 0 group 0, own coordinate
     const int voff = (2 * half * TL + wcol) * 4;
-    float x0 = 0.f, x1 = 0.f, x2 = 0.f;
+    float x0 = 0.f, x1 = 0.f, x2 = 0.f, gtv[4] = {0.f, 0.f, 0.f, 0.f};
+    bool sampled = false;
     if (valid) {
       x0 = a.x[3 * crow + 0];
       x1 = a.x[3 * crow + 1];
       x2 = a.x[3 * crow + 2];
+      if (half == 0) {
+        sampled = a.mask == nullptr || a.mask[crow] != 0;
+        for (int o = 0; o < nd.out_f; ++o) gtv[o] = a.gt[crow * nd.out_f + o];
+      }
     }
     const float quarter = half ? 0.25f : 0.f;
     bf16x8 hB[16];  // B operands of the next GEMM: K-step t = 2 m + s  <-  registers 8s .. 8s+7 of accumulator block m
     f32x16 acc[NB];
+    int si = 0;  // diagnostic builds: phase stamps 0, 1, 2, ... in program order (tools/stamps.py bf16)
 
     // epilogue of a forward hidden layer l: z = acc + bias -> stash (fp16 pairs), h = sin(w0 z) -> hB
     auto fwd_epilogue = [&](int l) {
-      const __amdgpu_buffer_rsrc_t rs = uniform_rsrc(sv + (size_t)l * (HSZ2 / 2), HSZ2 * 2);
+      const __amdgpu_buffer_rsrc_t rs = uniform_rsrc(sv + (size_t)l * (HSZ2 / 2), ts_bytes);
       const float* bl = bias_lds + l * 256 + 4 * half;
 #pragma unroll
       for (int m = 0; m < NB; ++m) {
@@ -184,14 +211,15 @@ __global__ __launch_bounds__(256) void inr_siren_bf16_kernel(const NetDesc nd, c
     };
 
     // ================================ forward =================================
+    INR_STAMP(si); ++si;
     // ---- layer 0: 2E encoder features generated per K-step (half 0: sines, half 1: cosines of features 8t .. 8t+7)
 #pragma unroll
     for (int m = 0; m < NB; ++m) acc[m] = zero16();
     for (int ch = 0; ch < nq0; ++ch) {
       if (ch == 0)
-        w2_acquire<true>(gbase, qs, NQ, ring, w, lane);
+        w2_acquire<2>(gbase, qs, NQ, ring, w, lane);  // tile start: behind the previous tile's last epilogue / the x loads
       else
-        w2_acquire<false>(gbase, qs, NQ, ring, w, lane);
+        w2_acquire<0>(gbase, qs, NQ, ring, w, lane);
       bf16x8 b[4];
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
@@ -204,10 +232,12 @@ __global__ __launch_bounds__(256) void inr_siren_bf16_kernel(const NetDesc nd, c
         }
         b[s] = pack8(f);
       }
-      w2_chunk_mma<NB>(acc, ring, qs, b, lane);
+      w2_chunk_mma(acc, ring, qs, b, lane);
       ++qs;
     }
+    INR_STAMP(si); ++si;
     fwd_epilogue(0);
+    INR_STAMP(si); ++si;
     // ---- hidden layers 1 .. D-2
     for (int l = 1; l < D - 1; ++l) {
 #pragma unroll
@@ -215,81 +245,80 @@ __global__ __launch_bounds__(256) void inr_siren_bf16_kernel(const NetDesc nd, c
 #pragma unroll
       for (int ch = 0; ch < 4; ++ch) {
         if (ch == 0)
-          w2_acquire<true>(gbase, qs, NQ, ring, w, lane);
+          w2_acquire<1>(gbase, qs, NQ, ring, w, lane);  // behind fwd_epilogue(l - 1): 64 stores
         else
-          w2_acquire<false>(gbase, qs, NQ, ring, w, lane);
+          w2_acquire<0>(gbase, qs, NQ, ring, w, lane);
         const bf16x8 b[4] = {hB[4 * ch], hB[4 * ch + 1], hB[4 * ch + 2], hB[4 * ch + 3]};
-        w2_chunk_mma<NB>(acc, ring, qs, b, lane);
+        w2_chunk_mma(acc, ring, qs, b, lane);
         ++qs;
       }
+      INR_STAMP(si); ++si;
       fwd_epilogue(l);
+      INR_STAMP(si); ++si;
     }
-    // ---- last layer: one row block (rows 0 .. out_f-1 live)
-    f32x16 accL[1];
-    accL[0] = zero16();
+    // ---- last layer: one row block (rows 0 .. out_f-1 live), its 16 K-steps in ONE chunk
+    f32x16 accL = zero16();
+    w2_acquire<1>(gbase, qs, NQ, ring, w, lane);  // behind fwd_epilogue(D - 2): 64 stores
 #pragma unroll
-    for (int ch = 0; ch < 4; ++ch) {
-      if (ch == 0)
-        w2_acquire<true>(gbase, qs, NQ, ring, w, lane);
-      else
-        w2_acquire<false>(gbase, qs, NQ, ring, w, lane);
-      const bf16x8 b[4] = {hB[4 * ch], hB[4 * ch + 1], hB[4 * ch + 2], hB[4 * ch + 3]};
-      w2_chunk_mma<1>(accL, ring, qs, b, lane);
-      ++qs;
+    for (int t = 0; t < 16; ++t) {
+      const bf16x8 A = *reinterpret_cast<const bf16x8*>(ring + (qs & (W2_SLOTS - 1)) * W2_CHUNK_BYTES + (t * 64 + lane) * 16);
+      accL = mfma_bf16(A, hB[t], accL);
     }
+    ++qs;
+    INR_STAMP(si); ++si;
     float y[4], dy[4], g[4];
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
-      float z = accL[0][o];  // half 0: rows 0..3
+      float z = accL[o];  // half 0: rows 0..3
       if (o < nd.out_f) z += bias_lds[(D - 1) * 256 + o];
       act_fwd_rt(nd.last_act, z, w0, y[o], dy[o]);
       g[o] = 0.f;
       if (half == 0 && valid && o < nd.out_f && a.out != nullptr) a.out[crow * nd.out_f + o] = y[o];
     }
-    if (half == 0 && valid && (a.mask == nullptr || a.mask[crow] != 0)) {
-      float t[4] = {0.f, 0.f, 0.f, 0.f};
-      for (int o = 0; o < nd.out_f; ++o) t[o] = a.gt[crow * nd.out_f + o];
-      loss_acc += loss_row(ld, nd.out_f, y, t, g);
-    }
+    if (sampled) loss_acc += loss_row(ld, nd.out_f, y, gtv, g);
     float dzl[4];
 #pragma unroll
     for (int o = 0; o < 4; ++o) dzl[o] = (half == 0 && o < nd.out_f) ? g[o] * dy[o] : 0.f;
     // dZ_last rows (0,1), (2,3) of this coordinate: two dwords behind the hidden tensors (read by the GEMM kernel)
-    if (half == 0) {
+    if (half == 0 && tile_ok) {
       unsigned* dzL = sv + (size_t)2 * (D - 1) * (HSZ2 / 2);
       dzL[wcol] = pack_bf16(dzl[0], dzl[1]);
       dzL[TL + wcol] = pack_bf16(dzl[2], dzl[3]);
     }
 
     // ================================ backward ================================
+    INR_STAMP(si); ++si;
     // dH_{D-2} = W_last^T dZ_last: one K-step (k = output row: element j of half 0 is row j for j < 4)
-    bf16x8 gB[16];
     {
       float v[8] = {dzl[0], dzl[1], dzl[2], dzl[3], 0.f, 0.f, 0.f, 0.f};
       const bf16x8 b0 = pack8(v);
-      bf16x8 zero8;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) zero8[j] = (__bf16)0.f;
 #pragma unroll
       for (int m = 0; m < NB; ++m) acc[m] = zero16();
-      w2_acquire<true>(gbase, qs, NQ, ring, w, lane);
-      const bf16x8 b[4] = {b0, zero8, zero8, zero8};  // K-steps 1..3 of this chunk carry zero weights
-      w2_chunk_mma<NB>(acc, ring, qs, b, lane);
+      w2_acquire<2>(gbase, qs, NQ, ring, w, lane);  // behind the loss section (a few loads / stores): drain
+#pragma unroll
+      for (int m = 0; m < NB; ++m) acc[m] = mfma_bf16(w2_frag(ring, qs, 0, m, lane), b0, acc[m]);  // K-steps 1..3: zero weights
       ++qs;
     }
+    INR_STAMP(si); ++si;
     for (int l = D - 2; l >= 0; --l) {
-      // dZ_l = dH_l * w0 cos(w0 z_l): z_l back from the stash (row pairs), dZ_l to the stash and into gB
-      const __amdgpu_buffer_rsrc_t rz = uniform_rsrc(sv + (size_t)l * (HSZ2 / 2), HSZ2 * 2);
-      const __amdgpu_buffer_rsrc_t rg = uniform_rsrc(sv + (size_t)(D - 1 + l) * (HSZ2 / 2), HSZ2 * 2);
+      // dZ_l = dH_l * w0 cos(w0 z_l): z_l back from the stash (row pairs), dZ_l to the stash and into hB
+      const __amdgpu_buffer_rsrc_t rz = uniform_rsrc(sv + (size_t)l * (HSZ2 / 2), ts_bytes);
+      const __amdgpu_buffer_rsrc_t rg = uniform_rsrc(sv + (size_t)(D - 1 + l) * (HSZ2 / 2), ts_bytes);
+      // the layer's 64 row pairs of this coordinate, all in flight before the first use (the B operands of the GEMM
+      // that just ended are dead, the next ones not yet formed: the registers are there)
+      unsigned zall[NB][8];
 #pragma unroll
-      for (int m = 0; m < NB; ++m) {
-        unsigned zz[8];
+      for (int m = 0; m < NB; ++m)
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
           const int so = (16 * m + 4 * gq) * TL * 4;
-          zz[2 * gq] = __builtin_amdgcn_raw_buffer_load_b32(rz, voff, so, 0);
-          zz[2 * gq + 1] = __builtin_amdgcn_raw_buffer_load_b32(rz, voff, so + TL * 4, 0);
+          zall[m][2 * gq] = __builtin_amdgcn_raw_buffer_load_b32(rz, voff, so, 0);
+          zall[m][2 * gq + 1] = __builtin_amdgcn_raw_buffer_load_b32(rz, voff, so + TL * 4, 0);
         }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < NB; ++m) {
+        const unsigned (&zz)[8] = zall[m];
         float dz[16];
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
@@ -312,9 +341,10 @@ __global__ __launch_bounds__(256) void inr_siren_bf16_kernel(const NetDesc nd, c
           lo[j] = dz[j];
           hi[j] = dz[8 + j];
         }
-        gB[2 * m] = pack8(lo);
-        gB[2 * m + 1] = pack8(hi);
+        hB[2 * m] = pack8(lo);  // (hB is free: the forward pass is over)
+        hB[2 * m + 1] = pack8(hi);
       }
+      INR_STAMP(si); ++si;
       if (l == 0) break;
       // dH_{l-1} = W_l^T dZ_l
 #pragma unroll
@@ -322,13 +352,14 @@ __global__ __launch_bounds__(256) void inr_siren_bf16_kernel(const NetDesc nd, c
 #pragma unroll
       for (int ch = 0; ch < 4; ++ch) {
         if (ch == 0)
-          w2_acquire<true>(gbase, qs, NQ, ring, w, lane);
+          w2_acquire<1>(gbase, qs, NQ, ring, w, lane);  // behind the backward epilogue: 64 loads (consumed) + 64 stores
         else
-          w2_acquire<false>(gbase, qs, NQ, ring, w, lane);
-        const bf16x8 b[4] = {gB[4 * ch], gB[4 * ch + 1], gB[4 * ch + 2], gB[4 * ch + 3]};
-        w2_chunk_mma<NB>(acc, ring, qs, b, lane);
+          w2_acquire<0>(gbase, qs, NQ, ring, w, lane);
+        const bf16x8 b[4] = {hB[4 * ch], hB[4 * ch + 1], hB[4 * ch + 2], hB[4 * ch + 3]};
+        w2_chunk_mma(acc, ring, qs, b, lane);
         ++qs;
       }
+      INR_STAMP(si); ++si;
     }
   }
   // every DMA this wave issued has landed before the workgroup (and its LDS) goes away
@@ -340,15 +371,19 @@ __global__ __launch_bounds__(256) void inr_siren_bf16_kernel(const NetDesc nd, c
   __syncthreads();
   if (lane == 0) red_lds[w] = v;
   __syncthreads();
-  if (tid == 0) a.slabs[(size_t)blockIdx.x * nd.slab_floats + nd.slab_loss_off] = ((red_lds[0] + red_lds[1]) + red_lds[2]) + red_lds[3];
+  if (tid == 0) {
+    float t = 0.f;
+    for (int i = 0; i < NW; ++i) t += red_lds[i];
+    a.slabs[(size_t)blockIdx.x * nd.slab_floats + nd.slab_loss_off] = t;
+  }
 }
 
 inline hipError_t launch_siren_bf16_fused(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int grid, hipStream_t st) {
-  const size_t lds_bytes = (size_t)W2_SLOTS * W2_CHUNK_BYTES + ((size_t)nd.D * 256 + 3 * (size_t)nd.E + 4) * sizeof(float);
+  const size_t lds_bytes = (size_t)W2_SLOTS * W2_CHUNK_BYTES + ((size_t)nd.D * 256 + 3 * (size_t)nd.E + W2_WAVES) * sizeof(float);
   if (lds_bytes > 160 * 1024 || a.save == nullptr || a.slabs == nullptr || a.save_by_block) return hipErrorInvalidValue;
   hipError_t e = allow_full_lds<inr_siren_bf16_kernel>();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(inr_siren_bf16_kernel, dim3(grid), dim3(256), lds_bytes, st, nd, ld, a);
+  hipLaunchKernelGGL(inr_siren_bf16_kernel, dim3(grid), dim3(64 * W2_WAVES), lds_bytes, st, nd, ld, a);
   return hipGetLastError();
 }
 

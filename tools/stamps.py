@@ -72,11 +72,18 @@ else:
              21: "dZ1 -> stash", 41: "dZ0 -> stash", 42: "sync"}
     # (the 256-row builds leave dW of the hidden-width layers to inr_dw_gemm.hip: no dW phases in the kernel)
     order = [0, 1, 2, 3, 4, 10, 11, 12, 13, 26, 29, 22, 25, 18, 21, 41, 42]
-    if PREC != "f32":
-        names.update({27: "sync", 28: "dW L3", 29: "sync+store", 23: "sync", 24: "dW L2", 25: "sync+store", 19: "sync",
-                      20: "dW L1", 21: "sync+store", 40: "dz0+sync", 41: "dW L0"})
-        order = [0, 1, 2, 3, 4, 10, 11, 12, 13, 26, 27, 28, 29, 22, 23, 24, 25, 18, 19, 20, 21, 40, 41, 42]
     last = 42
+    if PREC != "f32":  # inr_siren_bf16_kernel: stamps 0, 1, 2, ... in program order
+        labels = ["start", "L0 GEMM", "L0 epilogue"]
+        for l in (1, 2, 3):
+            labels += [f"L{l} GEMM", f"L{l} epilogue"]
+        labels += ["last GEMM", "loss", "dX last"]
+        for l in (3, 2, 1):
+            labels += [f"bwd epilogue {l}", f"dX L{l}"]
+        labels += ["bwd epilogue 0"]
+        names = dict(enumerate(labels))
+        order = list(range(len(labels)))
+        last = len(labels) - 1
 tot = (d[:, :, last] - d[:, :, 0])
 print(f"B={B} blocks={nb} (last tile of each) total cycles/wave: mean {tot.mean():.0f} min {tot.min():.0f} max {tot.max():.0f}")
 prev = order[0]
