@@ -78,8 +78,8 @@ __device__ __forceinline__ void sin_rows(const u32x4& a, const u32x4& b, float k
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const f16x2 z = __builtin_bit_cast(f16x2, i < 4 ? a[i] : b[i - 4]);
-    e[i] = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf((float)z[0] * krev));
-    o[i] = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf((float)z[1] * krev));
+    e[i] = __builtin_amdgcn_sinf((float)z[0] * krev);  // |w0 z / 2 pi| <= 256: the instruction's own range (see the fused kernel)
+    o[i] = __builtin_amdgcn_sinf((float)z[1] * krev);
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {

@@ -16,6 +16,9 @@
 //     accumulator tile as the next MFMA's operand"): element j of lane-half h of K-step (m, s) is feature
 //     32 m + 16 s + 8 (j >> 2) + 4 h + (j & 3), and the weight fragments are packed with the same k order
 //     (adam_pack_kernel, put_w2);
+//   * sin / cos of the hidden layers: v_sin_f32 / v_cos_f32 on w0 z / 2 pi directly -- the instruction reduces its
+//     argument itself for |revolutions| <= 256, i.e. |z| <= 53 at w0 = 30, an order of magnitude beyond what a SIREN's
+//     pre-activations reach (the encoder phases, which scale with the configured embedding scale, keep their v_fract);
 //   * backward mirrors it with the transposed images: dZ_l = dH_l * w0 cos(w0 z_l) is formed in registers from the
 //     accumulator of the previous dX GEMM and the stashed z_l, and is the B operand of dH_{l-1} = W_l^T dZ_l;
 //   * the stash holds z_l (fp16) and dZ_l (bf16), 4 KB per coordinate, in "row-pair" layout: element (row 2p + e,
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(512, 2) void inr_siren_bf16_kernel(const NetDesc nd
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             z[j] = acc[m][4 * g + j] + b4[j];
-            hv[4 * g + j] = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(z[j] * krev));
+            hv[4 * g + j] = __builtin_amdgcn_sinf(z[j] * krev);
           }
           const int so = (16 * m + 4 * g) * TL * 4;  // pair 16 m + 4 g (+ 2 half in voff), then the next pair
           __builtin_amdgcn_raw_buffer_store_b32(pack_f16(z[0], z[1]), rs, voff, so, 0);
@@ -327,7 +330,7 @@ __global__ __launch_bounds__(512, 2) void inr_siren_bf16_kernel(const NetDesc nd
             const f16x2 zp = __builtin_bit_cast(f16x2, zz[2 * gq + e]);
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-              const float c = __builtin_amdgcn_cosf(__builtin_amdgcn_fractf((float)zp[k] * krev));
+              const float c = __builtin_amdgcn_cosf((float)zp[k] * krev);
               dz[4 * gq + 2 * e + k] = acc[m][4 * gq + 2 * e + k] * (w0 * c);
             }
           }
