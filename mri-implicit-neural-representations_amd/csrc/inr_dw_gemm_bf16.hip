@@ -190,17 +190,26 @@ __device__ __forceinline__ void dwgb_body(const DwGemmBf16Args& a, const DwGemmB
       split_rows(A[k][0], A[k][1], ev, od);
       *reinterpret_cast<u32x4*>(st + (2 * pair) * GB_PITCH + 8 * seg) = ev;
       *reinterpret_cast<u32x4*>(st + (2 * pair + 1) * GB_PITCH + 8 * seg) = od;
+#ifndef GB_EXP_NOSUM
       if (BIAS && count) {
         bsum[k][0] = sum8(ev, bsum[k][0]);
         bsum[k][1] = sum8(od, bsum[k][1]);
       }
+#endif
     }
     u32x4 ev, od;
+#ifdef GB_EXP_NOENC
+    if (ENC) { ev = u32x4{1u,2u,3u,(unsigned)pair}; od = ev; } else
+#endif
     if (ENC) {
       ev = gauss_features(xs_lds + (s & 1) * GB_KS * 3 + 24 * seg, encB_lds, a.E, it.n0 + 2 * pair);
       od = gauss_features(xs_lds + (s & 1) * GB_KS * 3 + 24 * seg, encB_lds, a.E, it.n0 + 2 * pair + 1);
     } else {
+#ifdef GB_EXP_NOSIN
+      split_rows(B[k][0], B[k][1], ev, od);
+#else
       sin_rows(B[k][0], B[k][1], it.krev, ev, od);
+#endif
     }
     *reinterpret_cast<u32x4*>(st + GB_TILE + (2 * pair) * GB_PITCH + 8 * seg) = ev;
     *reinterpret_cast<u32x4*>(st + GB_TILE + (2 * pair + 1) * GB_PITCH + 8 * seg) = od;
@@ -223,7 +232,11 @@ __device__ __forceinline__ void dwgb_body(const DwGemmBf16Args& a, const DwGemmB
       for (int i = 0; i < (LASTROWS ? 1 : 2); ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
+#ifdef GB_EXP_NOMFMA
+          acc[i][j][q] += (float)A[i][0] + (float)B[j][0];
+#else
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i], B[j], acc[i][j], 0, 0, 0);
+#endif
       if (q < GB_NI) stash_item(s + 1, q, more, NA, NB);  // half of the next stage's staging per sub-step
     }
   };

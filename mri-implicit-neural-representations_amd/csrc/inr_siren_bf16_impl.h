@@ -76,26 +76,48 @@ __device__ __forceinline__ void w2_issue(const char* __restrict__ gbase, int img
                                      (__attribute__((address_space(3))) void*)(dst + n * 1024), 16, 0, 0);
 }
 
-// Before multiplying chunk q: its fragments (every wave's share) are in LDS and every wave is done with chunk
-// q - 1, whose slot then takes chunk q + 3.
-// AFTER: what this wave issued since the DMAs of chunk q -- 0: only the DMAs of chunks q+1, q+2 (2 x W2_FPW operations
-// may stay in flight); 1: those plus an epilogue of at least 64 stores (the counter is in order and tops out at 63: "at
-// most 63 outstanding" already implies every DMA, which is older than the stores, has landed -- without draining the
-// stores); 2: anything else (drain).
-template <int AFTER>
-__device__ __forceinline__ void w2_acquire(const char* __restrict__ gbase, int q, int NQ, char* ring, int w, int lane) {
-  static_assert(W2_FPW == 4, "the in-GEMM wait below is vmcnt(2 * W2_FPW)");
-  if (AFTER == 2)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else if (AFTER == 1)
-    asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
-  else
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+// Ring protocol.  The GEMMs come in PHASES (one layer's chunks) with an epilogue between them, and an epilogue is 64
+// stash stores per wave -- 128 KB per workgroup, a whole GEMM phase's worth of the CU's share of HBM write bandwidth.
+// The vector-memory counter retires IN ORDER, so a DMA issued behind those stores cannot be waited for without
+// draining them.  Hence every DMA a phase needs is issued BEFORE the epilogue in front of it:
+//   * chunk stream position p lives in slot p & 3; four chunks are in flight or in use at any time;
+//   * w2_chunk<WAIT, FIRST>(p): wait for this wave's pieces of chunk p, barrier (all pieces landed; everyone is done
+//     with chunk p - 1), then -- except for the first chunk of a phase, whose predecessor's slot was refilled by
+//     w2_phase_end -- request chunk p + 3 into the slot chunk p - 1 just left;
+//   * w2_phase_end(p_next): barrier (everyone is done with the phase's last chunk p_next - 1), request chunk
+//     p_next + 3 into its slot: the one request that would otherwise sit behind the epilogue's stores.
+// WAIT is the s_waitcnt vmcnt operand: "at most WAIT operations outstanding" covers chunk p when at least WAIT
+// vector-memory operations were issued after its DMAs.  Chunk p was requested when chunk p - 4 was done, so for the
+// first four chunks after a 64-store epilogue that is >= 64 (the field's maximum, 63, then retires only the oldest
+// few of those stores, a GEMM phase old); otherwise only the requests of chunks p + 1, p + 2 are guaranteed: 8.
+// Stream position p holds chunk image p mod NQ (a tile's chunk sequence repeats); past the end of the launch the extra
+// requests are harmless and keep the number of operations in flight what the waits assume.
+template <int WAIT, bool FIRST>
+__device__ __forceinline__ void w2_chunk(const char* __restrict__ gbase, int p, int NQ, char* ring, int w, int lane) {
+  static_assert(W2_FPW == 4 && W2_SLOTS == 4 && WAIT >= 0 && WAIT <= 63, "the counts assume 4 DMA pieces per wave and chunk, 4 slots");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT) : "memory");
   __builtin_amdgcn_s_barrier();
-  // keep the stream three chunks ahead: stream position q + 3 = image (q + 3) mod NQ (a tile's chunk sequence
-  // repeats), into the slot chunk q - 1 just left.  Past the end of the launch the extra loads are harmless and keep
-  // the number of operations in flight what the waits assume.
-  w2_issue(gbase, (q + 3) % NQ, (q + 3) & (W2_SLOTS - 1), ring, w, lane);
+  if (!FIRST) w2_issue(gbase, (p + 3) % NQ, (p + 3) & (W2_SLOTS - 1), ring, w, lane);
+}
+__device__ __forceinline__ void w2_phase_end(const char* __restrict__ gbase, int p_next, int NQ, char* ring, int w, int lane) {
+  __builtin_amdgcn_s_barrier();
+  w2_issue(gbase, (p_next + 3) % NQ, (p_next + 3) & (W2_SLOTS - 1), ring, w, lane);
+}
+// a whole phase of n chunks for a wave that only feeds the ring (small batches: the half of the workgroup without a tile)
+__device__ __forceinline__ void w2_phase_loader_only(const char* __restrict__ gbase, int& p, int n, bool drain, int NQ, char* ring,
+                                                     int w, int lane) {
+  for (int c = 0; c < n; ++c) {
+    if (c == 0) {
+      if (drain)
+        w2_chunk<0, true>(gbase, p, NQ, ring, w, lane);
+      else
+        w2_chunk<8, true>(gbase, p, NQ, ring, w, lane);
+    } else {
+      w2_chunk<8, false>(gbase, p, NQ, ring, w, lane);
+    }
+    ++p;
+  }
+  w2_phase_end(gbase, p, NQ, ring, w, lane);
 }
 
 __device__ __forceinline__ bf16x8 w2_frag(const char* ring, int q, int s_l, int mo, int lane) {
@@ -134,10 +156,11 @@ __global__ __launch_bounds__(512, 2) void inr_siren_bf16_kernel(const NetDesc nd
   for (int i = tid; i < D * 256; i += 64 * NW) bias_lds[i] = a.packed[nd.w2_bias_off + i];
   for (int i = tid; i < 3 * E; i += 64 * NW) encB_lds[i] = a.encB[i];
   const int nq0 = w2_nq0(E), NQ = w2_nq(D, E);
-  // prime the ring: stream positions 0, 1, 2 (three in flight; every acquire adds position q + 3)
+  // prime the ring: stream positions 0 .. 3 (the first chunk of a phase requests nothing)
   w2_issue(gbase, 0, 0, ring, w, lane);
   w2_issue(gbase, 1 % NQ, 1, ring, w, lane);
   w2_issue(gbase, 2 % NQ, 2, ring, w, lane);
+  w2_issue(gbase, 3 % NQ, 3, ring, w, lane);
   __syncthreads();  // tables in LDS (the DMAs are waited for by the first acquire)
   float loss_acc = 0.f;
   int qs = 0;  // stream position (chunks consumed so far by this workgroup); chunk image = qs % NQ
@@ -151,13 +174,12 @@ __global__ __launch_bounds__(512, 2) void inr_siren_bf16_kernel(const NetDesc nd
     const int stile = tpw * wtile + (w >> 2);     // this wave's stash tile
     const bool tile_ok = (w >> 2) < tpw && stile < a.n_tiles;  // (odd tile counts: the last workgroup tile is half empty)
     if ((w >> 2) >= tpw) {  // small batches: this half of the workgroup has no tile -- it only feeds the ring
-      for (int q = 0; q < NQ; ++q) {
-        if (q == 0)
-          w2_acquire<2>(gbase, qs, NQ, ring, w, lane);
-        else
-          w2_acquire<0>(gbase, qs, NQ, ring, w, lane);
-        ++qs;
-      }
+      // the working half's phases: layer 0, hidden layers, last layer, dX of the last layer, dX of the hidden layers
+      w2_phase_loader_only(gbase, qs, nq0, true, NQ, ring, w, lane);
+      for (int l = 1; l < D - 1; ++l) w2_phase_loader_only(gbase, qs, 4, false, NQ, ring, w, lane);
+      w2_phase_loader_only(gbase, qs, 1, false, NQ, ring, w, lane);
+      w2_phase_loader_only(gbase, qs, 1, false, NQ, ring, w, lane);
+      for (int l = D - 2; l >= 1; --l) w2_phase_loader_only(gbase, qs, 4, false, NQ, ring, w, lane);
       continue;
     }
     const long long crow = (long long)stile * TL + wcol;
@@ -220,9 +242,9 @@ __global__ __launch_bounds__(512, 2) void inr_siren_bf16_kernel(const NetDesc nd
     for (int m = 0; m < NB; ++m) acc[m] = zero16();
     for (int ch = 0; ch < nq0; ++ch) {
       if (ch == 0)
-        w2_acquire<2>(gbase, qs, NQ, ring, w, lane);  // tile start: behind the previous tile's last epilogue / the x loads
+        w2_chunk<0, true>(gbase, qs, NQ, ring, w, lane);  // tile start: drain (the previous tile's last epilogue, the x loads)
       else
-        w2_acquire<0>(gbase, qs, NQ, ring, w, lane);
+        w2_chunk<8, false>(gbase, qs, NQ, ring, w, lane);
       bf16x8 b[4];
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
@@ -238,6 +260,7 @@ __global__ __launch_bounds__(512, 2) void inr_siren_bf16_kernel(const NetDesc nd
       w2_chunk_mma(acc, ring, qs, b, lane);
       ++qs;
     }
+    w2_phase_end(gbase, qs, NQ, ring, w, lane);
     INR_STAMP(si); ++si;
     fwd_epilogue(0);
     INR_STAMP(si); ++si;
@@ -247,27 +270,30 @@ __global__ __launch_bounds__(512, 2) void inr_siren_bf16_kernel(const NetDesc nd
       for (int m = 0; m < NB; ++m) acc[m] = zero16();
 #pragma unroll
       for (int ch = 0; ch < 4; ++ch) {
+        // the four chunks behind fwd_epilogue(l - 1)'s 64 stores
         if (ch == 0)
-          w2_acquire<1>(gbase, qs, NQ, ring, w, lane);  // behind fwd_epilogue(l - 1): 64 stores
+          w2_chunk<63, true>(gbase, qs, NQ, ring, w, lane);
         else
-          w2_acquire<0>(gbase, qs, NQ, ring, w, lane);
+          w2_chunk<63, false>(gbase, qs, NQ, ring, w, lane);
         const bf16x8 b[4] = {hB[4 * ch], hB[4 * ch + 1], hB[4 * ch + 2], hB[4 * ch + 3]};
         w2_chunk_mma(acc, ring, qs, b, lane);
         ++qs;
       }
+      w2_phase_end(gbase, qs, NQ, ring, w, lane);
       INR_STAMP(si); ++si;
       fwd_epilogue(l);
       INR_STAMP(si); ++si;
     }
     // ---- last layer: one row block (rows 0 .. out_f-1 live), its 16 K-steps in ONE chunk
     f32x16 accL = zero16();
-    w2_acquire<1>(gbase, qs, NQ, ring, w, lane);  // behind fwd_epilogue(D - 2): 64 stores
+    w2_chunk<63, true>(gbase, qs, NQ, ring, w, lane);  // first chunk behind fwd_epilogue(D - 2)'s 64 stores
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
       const bf16x8 A = *reinterpret_cast<const bf16x8*>(ring + (qs & (W2_SLOTS - 1)) * W2_CHUNK_BYTES + (t * 64 + lane) * 16);
       accL = mfma_bf16(A, hB[t], accL);
     }
     ++qs;
+    w2_phase_end(gbase, qs, NQ, ring, w, lane);
     INR_STAMP(si); ++si;
     float y[4], dy[4], g[4];
 #pragma unroll
@@ -297,10 +323,11 @@ __global__ __launch_bounds__(512, 2) void inr_siren_bf16_kernel(const NetDesc nd
       const bf16x8 b0 = pack8(v);
 #pragma unroll
       for (int m = 0; m < NB; ++m) acc[m] = zero16();
-      w2_acquire<2>(gbase, qs, NQ, ring, w, lane);  // behind the loss section (a few loads / stores): drain
+      w2_chunk<63, true>(gbase, qs, NQ, ring, w, lane);  // second chunk behind fwd_epilogue(D - 2)'s 64 stores
 #pragma unroll
       for (int m = 0; m < NB; ++m) acc[m] = mfma_bf16(w2_frag(ring, qs, 0, m, lane), b0, acc[m]);  // K-steps 1..3: zero weights
       ++qs;
+      w2_phase_end(gbase, qs, NQ, ring, w, lane);
     }
     INR_STAMP(si); ++si;
     for (int l = D - 2; l >= 0; --l) {
@@ -354,14 +381,16 @@ __global__ __launch_bounds__(512, 2) void inr_siren_bf16_kernel(const NetDesc nd
       for (int m = 0; m < NB; ++m) acc[m] = zero16();
 #pragma unroll
       for (int ch = 0; ch < 4; ++ch) {
+        // the four chunks behind the backward epilogue's 64 stores
         if (ch == 0)
-          w2_acquire<1>(gbase, qs, NQ, ring, w, lane);  // behind the backward epilogue: 64 loads (consumed) + 64 stores
+          w2_chunk<63, true>(gbase, qs, NQ, ring, w, lane);
         else
-          w2_acquire<0>(gbase, qs, NQ, ring, w, lane);
+          w2_chunk<63, false>(gbase, qs, NQ, ring, w, lane);
         const bf16x8 b[4] = {hB[4 * ch], hB[4 * ch + 1], hB[4 * ch + 2], hB[4 * ch + 3]};
         w2_chunk_mma(acc, ring, qs, b, lane);
         ++qs;
       }
+      w2_phase_end(gbase, qs, NQ, ring, w, lane);
       INR_STAMP(si); ++si;
     }
   }
