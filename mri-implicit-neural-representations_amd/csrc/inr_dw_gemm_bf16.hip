@@ -60,15 +60,13 @@ __device__ __forceinline__ void split_rows(const u32x4& a, const u32x4& b, u32x4
   odd[3] = __builtin_amdgcn_perm(b[3], b[2], 0x07060302u);
 }
 
-// sum of 8 bf16 (4 dwords) into acc.  (Written on the integer bits: with v_dot2_f32_bf16 against a pair of ones hipcc 7.2
-// selected the FIRST dword for all four dot products of an unrolled loop over the vector's elements -- the row sums came
-// out as 4 x the first coordinate pair.)
+// sum of 8 bf16 (4 dwords) into acc: v_dot2c_f32_bf16 against a pair of ones (fp32 accumulate, one instruction per
+// dword).  Written as inline assembly: through the builtin hipcc 7.2 selected the FIRST dword for all four dot products of
+// the unrolled loop -- the row sums came out as 4 x the first coordinate pair.
 __device__ __forceinline__ float sum8(const u32x4& v, float acc) {
+  const unsigned ones = 0x3f803f80u;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const unsigned d = v[i];
-    acc += __builtin_bit_cast(float, d << 16) + __builtin_bit_cast(float, d & 0xffff0000u);
-  }
+  for (int i = 0; i < 4; ++i) asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acc) : "v"(v[i]), "v"(ones));
   return acc;
 }
 
