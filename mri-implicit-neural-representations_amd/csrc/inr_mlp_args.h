@@ -26,6 +26,7 @@ struct MlpArgs {
   int dw_gemm;         // 1: leave dZ_l of the hidden-width layers in the stash for inr_dw_gemm.hip, skip their dW passes
   long long* dbg;      // diagnostic builds (-DINR_STAMPS) only: per-wave phase time stamps
   long long dbg_cap;   // entries behind dbg (a stamp past it is dropped)
+  int ll_lds;          // inr_mlp_kernel: the last layer's live A fragments (rows 0..3) sit in LDS (set by launch_mlp)
 };
 
 

@@ -195,6 +195,29 @@ __device__ __forceinline__ void acc_times_d_to_lds(const f32x16 (&acc)[NBM], flo
   const __amdgpu_buffer_rsrc_t rsA = uniform_rsrc(sv_dA, NBM * 32 * TL * 4);
   const __amdgpu_buffer_rsrc_t rsB = uniform_rsrc(PAIR ? sv_dB : sv_dA, NBM * 32 * TL * 4);
   const int voff = ((4 * half) * TL + wcol) * 4;  // one per-lane byte offset for all loads
+  if (!PAIR && NBM % 4 == 0) {
+    // 64 loads (four row blocks) in flight before the first use: a block at a time exposed one HBM latency per block
+    // (the phase stamps showed 20 k cycles here against 4 k for the plain image copies); all 16 * NBM at once is past
+    // what the register allocator places without spilling
+#pragma unroll
+    for (int m0 = 0; m0 < NBM; m0 += 4) {
+      float dq[4][16];
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          dq[m][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                   rsA, voff, (32 * (m0 + m) + (r & 3) + 8 * (r >> 2)) * TL * 4, 0));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          Rl[(32 * (m0 + m) + (r & 3) + 8 * (r >> 2)) * INR_LDS_LD] = acc[m0 + m][r] * dq[m][r];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    return;
+  }
 #pragma unroll
   for (int m = 0; m < NBM; ++m) {
     float dA[16], dB[16];
@@ -373,7 +396,7 @@ __device__ __forceinline__ void load_oq(float (&zo)[4], float (&zq)[4], const fl
   }
 }
 
-template <int NBOUT, int TL, int HACT, bool SAVE>
+template <int NBOUT, int TL, int HACT, bool SAVE, bool ALDS = false>
 __device__ __forceinline__ void fwd_group(f32x16 (&acc)[NBOUT], const f32x4 (&a_use)[NBOUT],
                                           f32x4 (&a_load)[NBOUT], const f32x4* p_next, float (&z_buf)[4],
                                           float (&zp_buf)[4], float (&zo_buf)[4], float (&zq_buf)[4],
@@ -387,7 +410,10 @@ __device__ __forceinline__ void fwd_group(f32x16 (&acc)[NBOUT], const f32x4 (&a_
   // z_buf holds the pre-activations of group s4+1 (fetched one group ago); they become h_load/d_load
   // during this group's MFMAs, and z_buf is refilled with group s4+2.
   constexpr bool G2D = HACT == ACT_GABOR2D;
-  load_afrag<NBOUT>(a_load, p_next);
+  if (ALDS)
+    a_load[0] = *p_next;  // one-block last layer: its live rows' fragments sit in LDS (see fwd_layer)
+  else
+    load_afrag<NBOUT>(a_load, p_next);
   float z_next[4], zp_next[4], zo_next[4], zq_next[4];
   load_z<HACT == ACT_GABOR || G2D>(z_next, zp_next, Rcol, s4_next2, half);
   load_oq<TL, G2D>(zo_next, zq_next, svl + 5 * hsz, hsz, s4_next2);
@@ -419,11 +445,18 @@ __device__ __forceinline__ void fwd_group(f32x16 (&acc)[NBOUT], const f32x4 (&a_
   }
 }
 
-template <int NB, int NBOUT, int TL, int HACT, bool SAVE, int NBT = NBOUT>
-__device__ __forceinline__ void fwd_layer(f32x16 (&acc)[NBOUT], const float* R, const float* __restrict__ wp,
+// ALDS (NBOUT == 1, the last layer): `wp` is the LDS copy of the fragments of output rows 0..3 -- float4
+// (s4 * 2 + half) * 4 + row, then one float4 of zeros that the lanes of rows 4..31 read.  With the fragments in L2 the
+// loop ran at one L2 + store-acknowledge latency per group: four MFMAs do not cover a load that waits, in the in-order
+// vmcnt, behind the eight stash stores issued before it.
+template <int NB, int NBOUT, int TL, int HACT, bool SAVE, int NBT = NBOUT, bool ALDS = false>
+__device__ __forceinline__ void fwd_layer(f32x16 (&acc)[NBOUT], const float* R, const float* wp,
                                           const ActParams& ap, float* __restrict__ sv, int wcol, int lane) {
+  static_assert(!ALDS || NBOUT == 1, "LDS fragments: one-block layers only");
   const int half = lane >> 5, col = lane & 31;
-  const f32x4* p = reinterpret_cast<const f32x4*>(wp) + lane;
+  constexpr int n4tot = NB * 4;
+  const f32x4* p = reinterpret_cast<const f32x4*>(wp) + (ALDS ? (col < 4 ? half * 4 + col : n4tot * 8) : lane);
+  const int gstride = ALDS ? (col < 4 ? 8 : 0) : NBT * 64;  // float4s between consecutive groups
   constexpr int n4 = NB * 4;  // K = 32*NB features -> 16*NB k-steps -> 4*NB groups of 4 (even)
   constexpr int hsz = NB * 32 * TL;
   constexpr bool G2D = HACT == ACT_GABOR2D;  // always called with SAVE: its orth inputs live in the stash
@@ -434,7 +467,10 @@ __device__ __forceinline__ void fwd_layer(f32x16 (&acc)[NBOUT], const float* R, 
   const int voff = (half * TL + wcol) * 4;
   f32x4 A0[NBOUT], A1[NBOUT];
   float Z[4], ZP[4], ZO[4], ZQ[4], H0[4], D0[4], E0[4], F0[4], G0[4], H1[4], D1[4], E1[4], F1[4], G1[4];
-  load_afrag<NBOUT>(A0, p);
+  if (ALDS)
+    A0[0] = *p;
+  else
+    load_afrag<NBOUT>(A0, p);
   load_z<PAIR>(Z, ZP, Rcol, 0, half);
   load_oq<TL, G2D>(ZO, ZQ, svl + 5 * hsz, hsz, 0);
   lazy_act<HACT>(Z, ZP, ZO, ZQ, ap, half, H0, D0, E0, F0, G0);
@@ -444,10 +480,10 @@ __device__ __forceinline__ void fwd_layer(f32x16 (&acc)[NBOUT], const float* R, 
   for (int s4 = 0; s4 < n4; s4 += 2) {
     const int n2 = (s4 + 2 < n4) ? (s4 + 2) : s4;
     const int n3 = (s4 + 3 < n4) ? (s4 + 3) : s4;
-    fwd_group<NBOUT, TL, HACT, SAVE>(acc, A0, A1, p + (size_t)(s4 + 1) * NBT * 64, Z, ZP, ZO, ZQ, Rcol, n2, s4, ap,
-                                     half, svl, hsz, rs, voff, H0, D0, E0, F0, G0, H1, D1, E1, F1, G1);
-    fwd_group<NBOUT, TL, HACT, SAVE>(acc, A1, A0, p + (size_t)n2 * NBT * 64, Z, ZP, ZO, ZQ, Rcol, n3, s4 + 1, ap,
-                                     half, svl, hsz, rs, voff, H1, D1, E1, F1, G1, H0, D0, E0, F0, G0);
+    fwd_group<NBOUT, TL, HACT, SAVE, ALDS>(acc, A0, A1, p + (size_t)(s4 + 1) * gstride, Z, ZP, ZO, ZQ, Rcol, n2, s4, ap,
+                                           half, svl, hsz, rs, voff, H0, D0, E0, F0, G0, H1, D1, E1, F1, G1);
+    fwd_group<NBOUT, TL, HACT, SAVE, ALDS>(acc, A1, A0, p + (size_t)n2 * gstride, Z, ZP, ZO, ZQ, Rcol, n3, s4 + 1, ap,
+                                           half, svl, hsz, rs, voff, H1, D1, E1, F1, G1, H0, D0, E0, F0, G0);
   }
 }
 
@@ -795,11 +831,21 @@ __global__ __launch_bounds__(NW * 64) void inr_mlp_kernel(const NetDesc nd, cons
   constexpr int RS = NB * 32 * INR_LDS_LD;  // floats per wave image
   float* R = lds + w * RS;
   float* encB_lds = lds + NW * RS;  // [E][3] encoder matrix (gauss mode)
+  // a.ll_lds: the last layer's fragments of output rows 0..3, [NB*4 groups][2 halves][4 rows] float4 + a float4 of zeros
+  float* ll_lds = encB_lds + (INMODE == IN_GAUSS ? ((3 * nd.E + 3) & ~3) : 0);
+  const int D = nd.D;
+  if (a.ll_lds && MODE != MODE_BWD) {
+    const f32x4* src = reinterpret_cast<const f32x4*>(a.packed + nd.L[D - 1].pf_off);
+    for (int c = tid; c <= NB * 4 * 8; c += NW * 64) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (c < NB * 4 * 8) v = src[(c >> 3) * 64 + ((c >> 2) & 1) * 32 + (c & 3)];
+      reinterpret_cast<f32x4*>(ll_lds)[c] = v;
+    }
+  }
   if (INMODE == IN_GAUSS) {
     for (int i = tid; i < 3 * nd.E; i += NW * 64) encB_lds[i] = a.encB[i];
-    __syncthreads();
   }
-  const int D = nd.D;
+  if (INMODE == IN_GAUSS || (a.ll_lds && MODE != MODE_BWD)) __syncthreads();
   constexpr int HSZ = NB * 32 * TL;  // floats per stashed tensor
   float* slab = (MODE != MODE_FWD) ? a.slabs + (size_t)blockIdx.x * nd.slab_floats : nullptr;
   float loss_acc = 0.f;
@@ -889,10 +935,16 @@ __global__ __launch_bounds__(NW * 64) void inr_mlp_kernel(const NetDesc nd, cons
       {
         const ActParams ap{nd.L[D - 2].omega, nd.L[D - 2].s0};
         float* sh = sv + (size_t)(NS * (D - 2)) * HSZ;
-        if (saving)
+        if (a.ll_lds) {
+          if (saving)
+            fwd_layer<NB, 1, TL, HACT, true, 1, true>(accL, R, ll_lds, ap, sh, wcol, lane);
+          else
+            fwd_layer<NB, 1, TL, HACT, false, 1, true>(accL, R, ll_lds, ap, nullptr, wcol, lane);
+        } else if (saving) {
           fwd_layer<NB, 1, TL, HACT, true>(accL, R, a.packed + LL.pf_off, ap, sh, wcol, lane);
-        else
+        } else {
           fwd_layer<NB, 1, TL, HACT, false>(accL, R, a.packed + LL.pf_off, ap, nullptr, wcol, lane);
+        }
       }
       float zl[4], y[4], dy[4], g[4];
       const bool ctanh = nd.last_act == ACT_CTANH;
@@ -1061,10 +1113,17 @@ __global__ __launch_bounds__(NW * 64) void inr_mlp_kernel(const NetDesc nd, cons
 
 // hipFuncSetAttribute + launch
 template <int NB, int NW, int INMODE, int HACT, int MODE>
-inline hipError_t launch_mlp(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int grid, hipStream_t st) {
-  const size_t lds_bytes = ((size_t)NW * NB * 32 * INR_LDS_LD + 3 * (size_t)nd.E) * sizeof(float);
+inline hipError_t launch_mlp(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a_in, int grid, hipStream_t st) {
+  MlpArgs a = a_in;
+  size_t lds_bytes = ((size_t)NW * NB * 32 * INR_LDS_LD + 3 * (size_t)nd.E) * sizeof(float);
   auto k = inr_mlp_kernel<NB, NW, INMODE, HACT, MODE>;
   if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
+  // the last layer's fragments in LDS when they fit (4 KB + 16 B behind the 16-byte aligned encoder matrix) and the
+  // layer really has <= 4 output rows
+  const size_t with_ll = ((size_t)NW * NB * 32 * INR_LDS_LD + (INMODE == IN_GAUSS ? ((3 * (size_t)nd.E + 3) & ~(size_t)3) : 0) +
+                          (size_t)(NB * 4 * 8 + 1) * 4) * sizeof(float);
+  a.ll_lds = (MODE != MODE_BWD && nd.L[nd.D - 1].M <= 4 && with_ll <= 160 * 1024) ? 1 : 0;
+  if (a.ll_lds) lds_bytes = with_ll;
 #ifdef INR_DWG_STATIC  // the kernel has no in-kernel dW passes for layers the GEMM can take: the caller must run it
   if (MODE != MODE_FWD && HACT != ACT_GABOR2D && !a.dw_gemm && (nd.D > 2 || INMODE == IN_GAUSS))
     return hipErrorInvalidValue;
