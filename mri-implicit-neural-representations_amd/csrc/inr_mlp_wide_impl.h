@@ -19,16 +19,43 @@ template <int TL, int RH, bool PAIR>
 __device__ __forceinline__ void rows_times(float* R, const float* __restrict__ dA, const float* __restrict__ dB, int r0,
                                            int wcol, int lane) {
   const int half = lane >> 5, col = lane & 31;
-  if (PAIR) {
-#pragma unroll 4
-    for (int r = r0 + 2 * half; r < r0 + RH; r += 4) {  // this lane-half's pairs
-      const float p = R[swz(r, col)], q = R[swz(r + 1, col)];
-      R[swz(r, col)] = fmaf(p, dA[r * TL + wcol], q * dB[r * TL + wcol]);
-      R[swz(r + 1, col)] = fmaf(p, dA[(r + 1) * TL + wcol], q * dB[(r + 1) * TL + wcol]);
+  // The Jacobian entries come from the stash (HBM / L2): with four rows in flight per lane the pass ran at one memory
+  // latency per four rows (phase stamps: 35 k cycles per layer at 192 rows per wave).  Batches of BT row steps are
+  // requested through buffer descriptors (row offset in an SGPR) before the first is used; nothing else is live here.
+  constexpr int STEP = PAIR ? 4 : 2;           // rows a lane advances per step (both halves together)
+  constexpr int NSTEP = RH / STEP;
+  constexpr int BMAX = PAIR ? 16 : 32;         // <= 64 loads in flight per lane
+  constexpr int BT = NSTEP % BMAX == 0 ? BMAX : (NSTEP % (BMAX * 3 / 4) == 0 ? BMAX * 3 / 4 : (NSTEP % (BMAX / 2) == 0 ? BMAX / 2 : 4));
+  static_assert(NSTEP % BT == 0, "row count per wave must be a multiple of 16");
+  const __amdgpu_buffer_rsrc_t rsA = uniform_rsrc(dA + (size_t)r0 * TL, RH * TL * 4);
+  const __amdgpu_buffer_rsrc_t rsB = uniform_rsrc((PAIR ? dB : dA) + (size_t)r0 * TL, RH * TL * 4);
+  const int voff = ((PAIR ? 2 * half : half) * TL + wcol) * 4;
+#pragma unroll 1
+  for (int b = 0; b < NSTEP; b += BT) {
+    float a0[BT], a1[BT], b0[BT], b1[BT];
+#pragma unroll
+    for (int i = 0; i < BT; ++i) {
+      const int so = (b + i) * STEP * TL * 4;
+      a0[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsA, voff, so, 0));
+      if (PAIR) {
+        b0[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsB, voff, so, 0));
+        a1[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsA, voff, so + TL * 4, 0));
+        b1[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsB, voff, so + TL * 4, 0));
+      }
     }
-  } else {
-#pragma unroll 8
-    for (int r = r0 + half; r < r0 + RH; r += 2) R[swz(r, col)] *= dA[r * TL + wcol];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < BT; ++i) {
+      const int r = r0 + (b + i) * STEP + (PAIR ? 2 * half : half);
+      if (PAIR) {
+        const float p = R[swz(r, col)], q = R[swz(r + 1, col)];
+        R[swz(r, col)] = fmaf(p, a0[i], q * b0[i]);
+        R[swz(r + 1, col)] = fmaf(p, a1[i], q * b1[i]);
+      } else {
+        R[swz(r, col)] *= a0[i];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -44,7 +71,10 @@ __device__ __forceinline__ void wire_epilogue(const f32x16 (&acc)[MT], const flo
                                               int lane) {
   const int half = lane >> 5, col = lane & 31;
   float* Rl = Rown + (4 * half) * INR_LDS_LD + col;
-  const int so = (4 * half) * TL + wcol;
+  const int voff = ((4 * half) * TL + wcol) * 4;  // per-lane byte offset; the row offset goes in an SGPR (stash_store)
+  const __amdgpu_buffer_rsrc_t rh = uniform_rsrc(save ? sv_h : (const float*)bias, MT * 32 * TL * 4);
+  const __amdgpu_buffer_rsrc_t ra = uniform_rsrc(save ? sv_dA : (const float*)bias, MT * 32 * TL * 4);
+  const __amdgpu_buffer_rsrc_t rb = uniform_rsrc(save ? sv_dB : (const float*)bias, MT * 32 * TL * 4);
   const float* bl = bias + 4 * half;
   const float s2 = s0 * s0;
 #pragma unroll
@@ -64,12 +94,12 @@ __device__ __forceinline__ void wire_epilogue(const f32x16 (&acc)[MT], const flo
         Rl[(row + 1) * INR_LDS_LD] = yi;
         if (save) {
           const float ka = -2.f * s2 * za, kb = -omega - 2.f * s2 * zb;
-          sv_h[so + row * TL] = yr;
-          sv_h[so + (row + 1) * TL] = yi;
-          sv_dA[so + row * TL] = fmaf(ka, yr, -omega * yi);  // d y_r / d a
-          sv_dB[so + row * TL] = fmaf(ka, yi, omega * yr);   // d y_i / d a
-          sv_dA[so + (row + 1) * TL] = kb * yr;              // d y_r / d b
-          sv_dB[so + (row + 1) * TL] = kb * yi;              // d y_i / d b
+          stash_store(rh, voff, row * TL * 4, yr);
+          stash_store(rh, voff, (row + 1) * TL * 4, yi);
+          stash_store(ra, voff, row * TL * 4, fmaf(ka, yr, -omega * yi));  // d y_r / d a
+          stash_store(rb, voff, row * TL * 4, fmaf(ka, yi, omega * yr));   // d y_i / d a
+          stash_store(ra, voff, (row + 1) * TL * 4, kb * yr);              // d y_r / d b
+          stash_store(rb, voff, (row + 1) * TL * 4, kb * yi);              // d y_i / d b
         }
       }
     }
@@ -132,6 +162,8 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
     float* sv_enc = sv_last + 4 * TL;
     float* sv_g = sv_last + 4 * TL;  // WIRE2D (never gauss): copy of a layer's output gradient [NB*32][TL]
     const bool stash = saving && hh == 0;  // one wave of the pair writes the (shared) lazy-activation stash
+    int si = 0;  // diagnostic builds: phase stamps 0, 1, 2, ... in program order (tools/stamps.py wire)
+    INR_STAMP(si); ++si;
 
     // ================================ forward =================================
     if (MODE != MODE_BWD) {
@@ -158,6 +190,7 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
           fwd_layer0_x<MT, NB>(acc, a.packed + L0.pf_off + aoff, a.x + (size_t)(valid ? crow : 0) * L0.K, valid, L0.K,
                                L0.Kpad8, lane);
         }
+        INR_STAMP(si); ++si;
         if (EAGER)
           wire_epilogue<MT, TL>(acc, a.packed + L0.pbias_off + m0 * 32, Rown, sv + (size_t)m0 * 32 * TL,
                                 sv + (size_t)1 * HSZ + (size_t)m0 * 32 * TL, sv + (size_t)2 * HSZ + (size_t)m0 * 32 * TL,
@@ -174,6 +207,7 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
                                     wcol, lane);
         }
       }
+      INR_STAMP(si); ++si;
       __syncthreads();  // z_0 (and orth_0) complete
       for (int l = 1; l < D - 1; ++l) {
         const LayerDesc& Ll = nd.L[l];
@@ -188,6 +222,7 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
           fwd_layer<NB, MT, TL, HACT, true, NB>(acc, R, a.packed + Ll.pf_off + aoff, ap, sh, wcol, lane);
         else
           fwd_layer<NB, MT, TL, HACT, false, NB>(acc, R, a.packed + Ll.pf_off + aoff, ap, G2D ? sh : nullptr, wcol, lane);  // WIRE2D reads orth terms from sh
+        INR_STAMP(si); ++si;
         __syncthreads();  // both waves of the pair have read z_{l-1}; h_{l-1} is in the stash
         if (EAGER) {
           float* so = sv + (size_t)(NS * l) * HSZ + (size_t)m0 * 32 * TL;
@@ -204,6 +239,7 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
           orth_epilogue<MT, TL, NB>(acc, a.packed + Ol.pbias_off + m0 * 32,
                                     sv + (size_t)(NS * l + 5) * HSZ + (size_t)m0 * 32 * TL, wcol, lane);
         }
+        INR_STAMP(si); ++si;
         __syncthreads();  // z_l (and orth_l) complete
       }
       float g4[4] = {0.f, 0.f, 0.f, 0.f}, dy[4] = {0.f, 0.f, 0.f, 0.f};
@@ -241,6 +277,7 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
           loss_acc += loss_row(ld, nd.out_f, y, t, g4);
         }
       }
+      INR_STAMP(si); ++si;
       __syncthreads();  // the last layer has read z_{D-2}: rows may be overwritten (dZ_last / the next tile's z_0)
       if (MODE == MODE_FUSED) {
         if (hh == 0) {
@@ -267,6 +304,7 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
           R[swz(acc_row(r, half), col)] = v;
         }
       }
+      INR_STAMP(si); ++si;
       __syncthreads();  // every group's dZ_last is in LDS
       {
         BSrcStash<TL> bs{sv + (size_t)(NS * (D - 2)) * HSZ};
@@ -274,10 +312,12 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
           dw_pass<1, TL, false, BSrcStash<TL>>(lds, RS, bs, n, slab + LL.gw_off, slab + LL.gb_off, LL.M, LL.K, first,
                                                n == 0, lane);
       }
+      INR_STAMP(si); ++si;
       f32x16 gacc[MT];
 #pragma unroll
       for (int m = 0; m < MT; ++m) gacc[m] = zero16();
       bwd_dx<MT, TL, false, false, NB>(gacc, R, a.packed + LL.pb_off + aoff, LL.Mpad8, nullptr, wcol, lane);
+      INR_STAMP(si); ++si;
       __syncthreads();  // all reads of dZ_last are done
       if (D == 2)
         acc_times_d_to_lds<MT, TL, PAIR>(gacc, Rown, sv + (size_t)1 * HSZ + (size_t)m0 * 32 * TL,
@@ -286,16 +326,20 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
         acc_to_lds<MT, false>(gacc, Rown, nullptr, lane);  // dH_{D-2} (own rows)
       for (int l = D - 2; l >= 1; --l) {
         const LayerDesc& Ll = nd.L[l];
+        INR_STAMP(si); ++si;
         __syncthreads();  // dH_l complete
         if (G2D) rows_copy<TL, RH, true>(R, sv_g, RH * hh, wcol, lane);  // needed again for the orth Linear
         rows_times<TL, RH, PAIR>(R, sv + (size_t)(NS * l + 1) * HSZ, sv + (size_t)(NS * l + 2) * HSZ, RH * hh, wcol,
                                  lane);  // own rows: dZ_l = dH_l * act'
+        INR_STAMP(si); ++si;
         __syncthreads();
 #pragma unroll
         for (int m = 0; m < MT; ++m) gacc[m] = zero16();
         bwd_dx<MT, TL, false, false, NB>(gacc, R, a.packed + Ll.pb_off + aoff, Ll.Mpad8, nullptr, wcol, lane);
+        INR_STAMP(si); ++si;
         // dW_l is left to the batch GEMM (inr_dw_gemm.hip): own rows of dZ_l over the act' slot they were formed from
         rows_copy<TL, RH, true>(R, sv + (size_t)(NS * l + 1) * HSZ, RH * hh, wcol, lane);
+        INR_STAMP(si); ++si;
         __syncthreads();  // dZ_l has been read by every wave's dX
         if (G2D) {  // second Linear of the layer: dZ_orth = J_orth dH_l, dH_{l-1} += V_l^T dZ_orth, dV_l
           const LayerDesc& Ol = nd.L[nd.orth0 + l];
@@ -314,6 +358,7 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
       }
       {
         const LayerDesc& L0 = nd.L[0];
+        INR_STAMP(si); ++si;
         __syncthreads();  // dZ_0 complete
         if (INMODE == IN_GAUSS) {
           rows_copy<TL, RH, true>(R, sv + (size_t)1 * HSZ, RH * hh, wcol, lane);  // dZ_0 (own rows), for the GEMM
@@ -341,6 +386,7 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
         }
         __syncthreads();
       }
+      INR_STAMP(si); ++si;
       first = false;
     }
   }

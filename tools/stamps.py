@@ -1,5 +1,5 @@
 """Diagnostic: per-phase cycle shares of a fused kernel (needs `make -C csrc dbg`).
-Run on the GPU box:  python tools/stamps.py [B] [f32|bf16|mfn]
+Run on the GPU box:  python tools/stamps.py [B] [f32|bf16|mfn|wire]
 
 The stamp buffer holds 64 slots per WAVE of the launch: every fused kernel runs 4 waves per workgroup whatever
 its tile (128-coordinate tiles: one wave per 32 coordinates; 64-coordinate tiles: two waves per coordinate
@@ -37,6 +37,14 @@ if PREC == "mfn":  # BASELINE config 4: MultiscaleKFourier 8x512, LSL + consiste
 
     def step():
         eng.train_step(coords, enc.B.contiguous(), gt, spec, dist=dist, scale=0.5, cons=cons)
+elif PREC == "wire":  # BASELINE config 3: WIRE depth 4 / width 256 (181 complex features), HDR
+    net = dict(network_input_size=3, network_output_size=2, network_depth=4, network_width=256, first_omega_0=30,
+               hidden_omega_0=30, scale=15)
+    model = M.WIRE(net).to(dev)
+    eng = model._engine()
+
+    def step():
+        eng.train_step(coords, None, gt, M.LossSpec(L.LOSS_HDR), hdr_A=0.3)
 else:
     net = dict(network_input_size=512, network_output_size=2, network_depth=5, network_width=256, last_tanh=True)
     model = M.SIREN(net).to(dev)
@@ -66,6 +74,18 @@ if PREC == "mfn":
     names[50] = "stage 0 g_u -> stash"
     order.append(50)
     last = 50
+elif PREC == "wire":  # inr_mlp_wide_kernel: stamps 0, 1, 2, ... in program order
+    NH = 4  # hidden complex layers of config 3 (network_depth)
+    labels = ["start", "L0 GEMM", "L0 epilogue"]
+    for l in range(1, NH + 1):
+        labels += [f"sync + L{l} GEMM", f"sync + L{l} epilogue"]
+    labels += ["sync + last layer + loss (wave 0 of a pair)", "sync + dZ_last -> image", "sync + dW last", "dX last"]
+    for l in range(NH, 0, -1):
+        labels += [f"sync + dH_{l} -> image", f"sync + dZ_{l} = J dH_{l}", f"sync + dX L{l}", f"dZ_{l} -> stash"]
+    labels += ["sync + dZ_0 = J dH_0 -> image", "sync + dW_0 passes"]
+    names = dict(enumerate(labels))
+    order = list(range(len(labels)))
+    last = len(labels) - 1
 else:
     names = {0: "start", 1: "fwd L0", 2: "fwd L1", 3: "fwd L2", 4: "fwd L3", 10: "fwd last+loss", 11: "sync", 12: "dW last",
              13: "dX last+store", 26: "dX L3", 29: "dZ3 -> stash", 22: "dX L2", 25: "dZ2 -> stash", 18: "dX L1",
