@@ -218,27 +218,34 @@ __device__ __forceinline__ void acc_times_d_to_lds(const f32x16 (&acc)[NBM], flo
     }
     return;
   }
+  // (PAIR, or a block count that is not a multiple of four) two row blocks = 64 loads at a time when possible
+  constexpr int MB = (PAIR && NBM % 2 == 0) ? 2 : 1;
 #pragma unroll
-  for (int m = 0; m < NBM; ++m) {
-    float dA[16], dB[16];
+  for (int m0 = 0; m0 < NBM; m0 += MB) {
+    float dA[MB][16], dB[MB][16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int soff = (32 * m + (r & 3) + 8 * (r >> 2)) * TL * 4;
-      dA[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsA, voff, soff, 0));
-      dB[r] = PAIR ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsB, voff, soff, 0)) : 0.f;
-    }
-    __builtin_amdgcn_sched_barrier(0);  // all loads of the block in flight before the first use
+    for (int mm = 0; mm < MB; ++mm)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float v;
-      if (PAIR) {
-        const float pp = acc[m][r & ~1], qq = acc[m][r | 1];
-        v = fmaf(pp, dA[r], qq * dB[r]);
-      } else {
-        v = acc[m][r] * dA[r];
+      for (int r = 0; r < 16; ++r) {
+        const int soff = (32 * (m0 + mm) + (r & 3) + 8 * (r >> 2)) * TL * 4;
+        dA[mm][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsA, voff, soff, 0));
+        dB[mm][r] = PAIR ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsB, voff, soff, 0)) : 0.f;
       }
-      Rl[(32 * m + (r & 3) + 8 * (r >> 2)) * INR_LDS_LD] = v;
-    }
+    __builtin_amdgcn_sched_barrier(0);  // all loads of the blocks in flight before the first use
+#pragma unroll
+    for (int mm = 0; mm < MB; ++mm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + mm;
+        float v;
+        if (PAIR) {
+          const float pp = acc[m][r & ~1], qq = acc[m][r | 1];
+          v = fmaf(pp, dA[mm][r], qq * dB[mm][r]);
+        } else {
+          v = acc[m][r] * dA[mm][r];
+        }
+        Rl[(32 * m + (r & 3) + 8 * (r >> 2)) * INR_LDS_LD] = v;
+      }
     __builtin_amdgcn_sched_barrier(0);
   }
 }
