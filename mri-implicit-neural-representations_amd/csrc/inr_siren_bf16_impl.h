@@ -81,9 +81,9 @@ __device__ __forceinline__ void w2_issue(const char* __restrict__ gbase, int img
 // The vector-memory counter retires IN ORDER, so a DMA issued behind those stores cannot be waited for without
 // draining them.  Hence every DMA a phase needs is issued BEFORE the epilogue in front of it:
 //   * chunk stream position p lives in slot p & 3; four chunks are in flight or in use at any time;
-//   * w2_chunk<WAIT, FIRST>(p): wait for this wave's pieces of chunk p, barrier (all pieces landed; everyone is done
-//     with chunk p - 1), then -- except for the first chunk of a phase, whose predecessor's slot was refilled by
-//     w2_phase_end -- request chunk p + 3 into the slot chunk p - 1 just left;
+//   * w2_chunk<WAIT>(): wait for this wave's pieces of chunk p, barrier (all pieces landed; everyone is done with
+//     chunk p - 1); then -- except for the first chunk of a phase, whose predecessor's slot was refilled by
+//     w2_phase_end -- w2_request(p): chunk p + 3 into the slot chunk p - 1 just left;
 //   * w2_phase_end(p_next): barrier (everyone is done with the phase's last chunk p_next - 1), request chunk
 //     p_next + 3 into its slot: the one request that would otherwise sit behind the epilogue's stores.
 // WAIT is the s_waitcnt vmcnt operand: "at most WAIT operations outstanding" covers chunk p when at least WAIT
@@ -92,12 +92,17 @@ __device__ __forceinline__ void w2_issue(const char* __restrict__ gbase, int img
 // few of those stores, a GEMM phase old); otherwise only the requests of chunks p + 1, p + 2 are guaranteed: 8.
 // Stream position p holds chunk image p mod NQ (a tile's chunk sequence repeats); past the end of the launch the extra
 // requests are harmless and keep the number of operations in flight what the waits assume.
-template <int WAIT, bool FIRST>
-__device__ __forceinline__ void w2_chunk(const char* __restrict__ gbase, int p, int NQ, char* ring, int w, int lane) {
+// The request of chunk p + 3 is issued by the caller a K-step into chunk p's MFMAs (w2_chunk_mma<true>), not here: four
+// LDS-DMA instructions take a few hundred cycles to issue, and right behind the barrier both waves of a SIMD would
+// spend them with the matrix pipe empty.
+template <int WAIT>
+__device__ __forceinline__ void w2_chunk() {
   static_assert(W2_FPW == 4 && W2_SLOTS == 4 && WAIT >= 0 && WAIT <= 63, "the counts assume 4 DMA pieces per wave and chunk, 4 slots");
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT) : "memory");
   __builtin_amdgcn_s_barrier();
-  if (!FIRST) w2_issue(gbase, (p + 3) % NQ, (p + 3) & (W2_SLOTS - 1), ring, w, lane);
+}
+__device__ __forceinline__ void w2_request(const char* __restrict__ gbase, int p, int NQ, char* ring, int w, int lane) {
+  w2_issue(gbase, (p + 3) % NQ, (p + 3) & (W2_SLOTS - 1), ring, w, lane);
 }
 __device__ __forceinline__ void w2_phase_end(const char* __restrict__ gbase, int p_next, int NQ, char* ring, int w, int lane) {
   __builtin_amdgcn_s_barrier();
@@ -109,11 +114,12 @@ __device__ __forceinline__ void w2_phase_loader_only(const char* __restrict__ gb
   for (int c = 0; c < n; ++c) {
     if (c == 0) {
       if (drain)
-        w2_chunk<0, true>(gbase, p, NQ, ring, w, lane);
+        w2_chunk<0>();
       else
-        w2_chunk<8, true>(gbase, p, NQ, ring, w, lane);
+        w2_chunk<8>();
     } else {
-      w2_chunk<8, false>(gbase, p, NQ, ring, w, lane);
+      w2_chunk<8>();
+      w2_request(gbase, p, NQ, ring, w, lane);
     }
     ++p;
   }
@@ -125,7 +131,10 @@ __device__ __forceinline__ bf16x8 w2_frag(const char* ring, int q, int s_l, int 
 }
 
 // one chunk = four K = 16 steps against B fragments b[0..3], 8 row blocks (the partner wave hides the LDS latency)
-__device__ __forceinline__ void w2_chunk_mma(f32x16 (&acc)[8], const char* ring, int q, const bf16x8 (&b)[4], int lane) {
+// REQUEST: chunk q is not the first of its phase -- the slot chunk q - 1 left takes chunk q + 3, behind the first K-step
+template <bool REQUEST>
+__device__ __forceinline__ void w2_chunk_mma(f32x16 (&acc)[8], char* ring, int q, const bf16x8 (&b)[4], int lane,
+                                             const char* __restrict__ gbase, int NQ, int w) {
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     bf16x8 A[8];
@@ -133,6 +142,7 @@ __device__ __forceinline__ void w2_chunk_mma(f32x16 (&acc)[8], const char* ring,
     for (int m = 0; m < 8; ++m) A[m] = w2_frag(ring, q, s, m, lane);
 #pragma unroll
     for (int m = 0; m < 8; ++m) acc[m] = mfma_bf16(A[m], b[s], acc[m]);
+    if (REQUEST && s == 0) w2_request(gbase, q, NQ, ring, w, lane);
   }
 }
 
@@ -242,9 +252,9 @@ __global__ __launch_bounds__(512, 2) void inr_siren_bf16_kernel(const NetDesc nd
     for (int m = 0; m < NB; ++m) acc[m] = zero16();
     for (int ch = 0; ch < nq0; ++ch) {
       if (ch == 0)
-        w2_chunk<0, true>(gbase, qs, NQ, ring, w, lane);  // tile start: drain (the previous tile's last epilogue, the x loads)
+        w2_chunk<0>();  // tile start: drain (the previous tile's last epilogue, the x loads)
       else
-        w2_chunk<8, false>(gbase, qs, NQ, ring, w, lane);
+        w2_chunk<8>();
       bf16x8 b[4];
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
@@ -257,7 +267,10 @@ __global__ __launch_bounds__(512, 2) void inr_siren_bf16_kernel(const NetDesc nd
         }
         b[s] = pack8(f);
       }
-      w2_chunk_mma(acc, ring, qs, b, lane);
+      if (ch == 0)
+        w2_chunk_mma<false>(acc, ring, qs, b, lane, gbase, NQ, w);
+      else
+        w2_chunk_mma<true>(acc, ring, qs, b, lane, gbase, NQ, w);
       ++qs;
     }
     w2_phase_end(gbase, qs, NQ, ring, w, lane);
@@ -271,12 +284,12 @@ __global__ __launch_bounds__(512, 2) void inr_siren_bf16_kernel(const NetDesc nd
 #pragma unroll
       for (int ch = 0; ch < 4; ++ch) {
         // the four chunks behind fwd_epilogue(l - 1)'s 64 stores
-        if (ch == 0)
-          w2_chunk<63, true>(gbase, qs, NQ, ring, w, lane);
-        else
-          w2_chunk<63, false>(gbase, qs, NQ, ring, w, lane);
+        w2_chunk<63>();
         const bf16x8 b[4] = {hB[4 * ch], hB[4 * ch + 1], hB[4 * ch + 2], hB[4 * ch + 3]};
-        w2_chunk_mma(acc, ring, qs, b, lane);
+        if (ch == 0)
+          w2_chunk_mma<false>(acc, ring, qs, b, lane, gbase, NQ, w);
+        else
+          w2_chunk_mma<true>(acc, ring, qs, b, lane, gbase, NQ, w);
         ++qs;
       }
       w2_phase_end(gbase, qs, NQ, ring, w, lane);
@@ -286,7 +299,7 @@ __global__ __launch_bounds__(512, 2) void inr_siren_bf16_kernel(const NetDesc nd
     }
     // ---- last layer: one row block (rows 0 .. out_f-1 live), its 16 K-steps in ONE chunk
     f32x16 accL = zero16();
-    w2_chunk<63, true>(gbase, qs, NQ, ring, w, lane);  // first chunk behind fwd_epilogue(D - 2)'s 64 stores
+    w2_chunk<63>();  // first chunk behind fwd_epilogue(D - 2)'s 64 stores
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
       const bf16x8 A = *reinterpret_cast<const bf16x8*>(ring + (qs & (W2_SLOTS - 1)) * W2_CHUNK_BYTES + (t * 64 + lane) * 16);
@@ -323,7 +336,7 @@ __global__ __launch_bounds__(512, 2) void inr_siren_bf16_kernel(const NetDesc nd
       const bf16x8 b0 = pack8(v);
 #pragma unroll
       for (int m = 0; m < NB; ++m) acc[m] = zero16();
-      w2_chunk<63, true>(gbase, qs, NQ, ring, w, lane);  // second chunk behind fwd_epilogue(D - 2)'s 64 stores
+      w2_chunk<63>();  // second chunk behind fwd_epilogue(D - 2)'s 64 stores
 #pragma unroll
       for (int m = 0; m < NB; ++m) acc[m] = mfma_bf16(w2_frag(ring, qs, 0, m, lane), b0, acc[m]);  // K-steps 1..3: zero weights
       ++qs;
@@ -382,12 +395,12 @@ __global__ __launch_bounds__(512, 2) void inr_siren_bf16_kernel(const NetDesc nd
 #pragma unroll
       for (int ch = 0; ch < 4; ++ch) {
         // the four chunks behind the backward epilogue's 64 stores
-        if (ch == 0)
-          w2_chunk<63, true>(gbase, qs, NQ, ring, w, lane);
-        else
-          w2_chunk<63, false>(gbase, qs, NQ, ring, w, lane);
+        w2_chunk<63>();
         const bf16x8 b[4] = {hB[4 * ch], hB[4 * ch + 1], hB[4 * ch + 2], hB[4 * ch + 3]};
-        w2_chunk_mma(acc, ring, qs, b, lane);
+        if (ch == 0)
+          w2_chunk_mma<false>(acc, ring, qs, b, lane, gbase, NQ, w);
+        else
+          w2_chunk_mma<true>(acc, ring, qs, b, lane, gbase, NQ, w);
         ++qs;
       }
       w2_phase_end(gbase, qs, NQ, ring, w, lane);
