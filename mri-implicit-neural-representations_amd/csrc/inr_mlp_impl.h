@@ -271,9 +271,17 @@ __device__ __forceinline__ float gauss_feature(const float* encB_lds, int s, flo
   // drag a vmcnt(0) behind it and drain the A-fragment prefetch every k-step
   const float b0 = encB_lds[3 * s + 0], b1 = encB_lds[3 * s + 1], b2 = encB_lds[3 * s + 2];
   const float ph = fmaf(xs2, b2, fmaf(xs1, b1, xs0 * b0));  // (2*pi*x) @ B^T, K = 3 (networks.py:31)
+#ifndef INR_SINCOS_POLY
+  // one transcendental: the reduced argument in revolutions (sincos_cw's reduction), + 1/4 turn for the cosine half
+  const float k = rintf(ph * 0.15915494309189535f);
+  float r = fmaf(k, -6.2831854820251465f, ph);
+  r = fmaf(k, 1.7484555e-7f, r);
+  return __builtin_amdgcn_sinf(fmaf(r, 0.15915494309189535f, half ? 0.25f : 0.f));
+#else
   float sn, cs;
   sincos_cw(ph, sn, cs);
   return half ? cs : sn;
+#endif
 }
 
 template <int NB, int TL, bool SAVE>
