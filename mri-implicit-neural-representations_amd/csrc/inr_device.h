@@ -128,11 +128,14 @@ __device__ __forceinline__ int swz(int feat, int col) { return feat * INR_LDS_LD
 // -DINR_SINCOS_POLY: three-constant Cody-Waite by pi/2 + cephes minimax polynomials on [-pi/4, pi/4] (max abs
 // error 9e-8, mean 1.6e-8): kept for A/B runs (make poly).
 #ifndef INR_SINCOS_POLY
+// Reduction in REVOLUTIONS (what v_sin / v_cos take), two-constant 1/(2 pi): k = rint(x * c_hi); x * c_hi - k is exact
+// inside the FMA up to its one rounding at magnitude <= 1/2 (3e-8), then + x * c_lo (c_hi + c_lo = 1/(2 pi) to 1e-16).
+// Four VALU instructions; round 2's first form reduced in radians and multiplied afterwards (five).
 __device__ __forceinline__ void sincos_cw(float x, float& sn, float& cs) {
-  const float k = rintf(x * 0.15915494309189535f);
-  float r = fmaf(k, -6.2831854820251465f, x);  // k * float(2 pi) is exact inside the FMA for |k| < 2^24 / 2pi ...
-  r = fmaf(k, 1.7484555e-7f, r);               // ... + k * (float(2 pi) - 2 pi)
-  const float rev = r * 0.15915494309189535f;
+  constexpr float c_hi = 0.15915494309189535f;
+  constexpr float c_lo = (float)(0.15915494309189533576888 - (double)c_hi);
+  const float k = rintf(x * c_hi);
+  const float rev = fmaf(x, c_lo, fmaf(x, c_hi, -k));
   sn = __builtin_amdgcn_sinf(rev);
   cs = __builtin_amdgcn_cosf(rev);
 }
