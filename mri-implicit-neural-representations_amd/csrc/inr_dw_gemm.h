@@ -21,6 +21,7 @@ struct DwGemmArgs {
   int n_tiles, n_chunks, tiles_per_chunk;
   int TL;              // coordinates per tile: 64 or 128
   int WB;              // 32-row blocks per wave-tile side: 4 (workgroup tile 256 x 256) or 3 (192 x 192)
+  int WBM;             // 0: square tiles; 2 (with WB = 4, TL = 128): 128-row x 256-column workgroup tiles for short chunks
   int n_items;
   int units, blocks_per_chunk;  // set by the launcher
   DwGemmItem it[INR_DWG_MAX_ITEMS];

@@ -25,16 +25,20 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int DWG_LD = 36;  // LDS row pitch (floats): 16-byte reads of 8 consecutive rows hit 32 distinct banks
 // WB: 32-row blocks per wave tile side (4: 128 x 128 per wave, 256 x 256 per workgroup; 3: 96 / 192 for the 384-row
 // WIRE shape).  A stage holds the G tile [64 WB][32] and the H tile [64 WB][32].
-template <int WB>
-constexpr int dwg_stage() { return 2 * 64 * WB * DWG_LD; }
+// WBM x WB: 32-row blocks per wave tile (rows x columns of dW); the workgroup tile is (64 WBM) x (64 WB).  WBM < WB
+// (128 x 256) is for SHORT chunks: at 25 000 rows a 256 x 256 workgroup sees only K = 512 coordinates, and the 245
+// workgroups' 256 KB of results -- all stored at the same moment, with nothing left to overlap -- were a sixth of the
+// launch; half-height tiles over twice the K halve the slab stream (and what reduce_slabs reads) for one more pass over h.
+template <int WBM, int WB>
+constexpr int dwg_stage() { return 64 * (WBM + WB) * DWG_LD; }
 
-template <int WB, bool BIAS>
-__device__ __forceinline__ void dwg_mma(f32x16 (&acc)[WB][WB], float (&bsum)[WB], const f32x4 (&A)[WB],
+template <int WBM, int WB, bool BIAS>
+__device__ __forceinline__ void dwg_mma(f32x16 (&acc)[WBM][WB], float (&bsum)[WBM], const f32x4 (&A)[WBM],
                                         const f32x4 (&B)[WB]) {
 #pragma unroll
   for (int e = 0; e < 4; ++e)
 #pragma unroll
-    for (int i = 0; i < WB; ++i) {
+    for (int i = 0; i < WBM; ++i) {
       if (BIAS) bsum[i] += A[i][e];
 #pragma unroll
       for (int j = 0; j < WB; ++j)
@@ -58,20 +62,20 @@ __device__ __forceinline__ void dwg_stash(float* buf, const f32x4 (&v)[NF], int 
   for (int k = 0; k < NF; ++k) *reinterpret_cast<f32x4*>(p + k * 32 * DWG_LD) = v[k];
 }
 
-// Workgroup = a (64 WB) x (64 WB) block of one item's dW over one chunk of tiles; waves 2 x 2, (32 WB)^2 each.
-template <int TL, int WB, bool BIAS>
+// Workgroup = a (64 WBM) x (64 WB) block of one item's dW over one chunk of tiles; waves 2 x 2, (32 WBM) x (32 WB) each.
+template <int TL, int WBM, int WB, bool BIAS>
 __device__ __forceinline__ void dwg_body(const DwGemmArgs& a, const DwGemmItem& it, int kc, int mb0, int nb0,
                                          float* lds) {
-  constexpr int NF = 4 * WB;         // 16-byte fetches per thread and stage
-  constexpr int TR = 64 * WB;        // rows of one operand tile
-  constexpr int DWG_STAGE = dwg_stage<WB>();
+  constexpr int NF = 2 * (WBM + WB);  // 16-byte fetches per thread and stage
+  constexpr int TR = 64 * WBM;        // rows of the G (dZ) tile; the H tile has 64 WB
+  constexpr int DWG_STAGE = dwg_stage<WBM, WB>();
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int half = lane >> 5, li = lane & 31;
   const int wm = w >> 1, wn = w & 1;
-  f32x16 acc[WB][WB];
-  float bsum[WB];
+  f32x16 acc[WBM][WB];
+  float bsum[WBM];
 #pragma unroll
-  for (int i = 0; i < WB; ++i) {
+  for (int i = 0; i < WBM; ++i) {
     bsum[i] = 0.f;
 #pragma unroll
     for (int j = 0; j < WB; ++j)
@@ -94,7 +98,7 @@ __device__ __forceinline__ void dwg_body(const DwGemmArgs& a, const DwGemmItem& 
   int n_mine = a.n_tiles - t0;
   if (n_mine > a.tiles_per_chunk) n_mine = a.tiles_per_chunk;
   const int n_steps = (n_mine > 0 ? n_mine : 0) * KS;
-  const float* As = lds + (wm * 32 * WB + li) * DWG_LD + 4 * half;
+  const float* As = lds + (wm * 32 * WBM + li) * DWG_LD + 4 * half;
   const float* Bs = lds + (TR + wn * 32 * WB + li) * DWG_LD + 4 * half;
   f32x4 v[NF];
   if (n_steps > 0) {  // (an empty chunk still writes its zeros)
@@ -111,20 +115,20 @@ __device__ __forceinline__ void dwg_body(const DwGemmArgs& a, const DwGemmItem& 
     const float* Bb = Bs + (s & 1) * DWG_STAGE;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      f32x4 A[WB], B[WB];
+      f32x4 A[WBM], B[WB];
 #pragma unroll
-      for (int i = 0; i < WB; ++i) A[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * DWG_LD + 8 * q);
+      for (int i = 0; i < WBM; ++i) A[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * DWG_LD + 8 * q);
 #pragma unroll
       for (int j = 0; j < WB; ++j) B[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * DWG_LD + 8 * q);
-      dwg_mma<WB, BIAS>(acc, bsum, A, B);
+      dwg_mma<WBM, WB, BIAS>(acc, bsum, A, B);
     }
     if (sn < n_steps) dwg_stash(lds + (sn & 1) * DWG_STAGE, v, t);
     __syncthreads();
   }
   float* slab = a.slabs + (size_t)kc * a.slab_floats;
-  const int mb = mb0 + WB * wm, nb = nb0 + WB * wn;
+  const int mb = mb0 + WBM * wm, nb = nb0 + WB * wn;
 #pragma unroll
-  for (int i = 0; i < WB; ++i) {
+  for (int i = 0; i < WBM; ++i) {
     if (mb + i >= it.Mblk) continue;
 #pragma unroll
     for (int j = 0; j < WB; ++j) {
@@ -144,7 +148,7 @@ __device__ __forceinline__ void dwg_body(const DwGemmArgs& a, const DwGemmItem& 
   }
 }
 
-template <int TL, int WB>
+template <int TL, int WBM, int WB>
 __global__ __launch_bounds__(256) void dw_gemm_kernel(const DwGemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int kc = blockIdx.x / a.blocks_per_chunk;
@@ -155,17 +159,17 @@ __global__ __launch_bounds__(256) void dw_gemm_kernel(const DwGemmArgs a) {
   const int u = unit - it.unit0;
   const int mi = u / it.nt, ni = u % it.nt;
   if (ni == 0)
-    dwg_body<TL, WB, true>(a, it, kc, 2 * WB * mi, 0, lds);
+    dwg_body<TL, WBM, WB, true>(a, it, kc, 2 * WBM * mi, 0, lds);
   else
-    dwg_body<TL, WB, false>(a, it, kc, 2 * WB * mi, 2 * WB * ni, lds);
+    dwg_body<TL, WBM, WB, false>(a, it, kc, 2 * WBM * mi, 2 * WB * ni, lds);
 }
 
-template <int TL, int WB>
+template <int TL, int WBM, int WB>
 static hipError_t launch_tl(const DwGemmArgs& a, dim3 grid, hipStream_t st) {
-  constexpr size_t lds_bytes = (size_t)2 * dwg_stage<WB>() * sizeof(float);  // two stages (WB = 4: 147 KB)
-  auto k = dw_gemm_kernel<TL, WB>;
+  constexpr size_t lds_bytes = (size_t)2 * dwg_stage<WBM, WB>() * sizeof(float);  // two stages (4 x 4: 147 KB)
+  auto k = dw_gemm_kernel<TL, WBM, WB>;
   {
-    hipError_t e = allow_full_lds<dw_gemm_kernel<TL, WB>>();
+    hipError_t e = allow_full_lds<dw_gemm_kernel<TL, WBM, WB>>();
     if (e != hipSuccess) return e;
   }
   hipLaunchKernelGGL(k, grid, dim3(256), lds_bytes, st, a);
@@ -178,9 +182,11 @@ hipError_t launch_dw_gemm(DwGemmArgs& a, hipStream_t st) {
   a.blocks_per_chunk = dw_gemm_units(a);
   a.units = a.blocks_per_chunk;
   const dim3 grid((unsigned)(a.n_chunks * a.blocks_per_chunk));
-  if (a.TL == 128 && a.WB == 4) return launch_tl<128, 4>(a, grid, st);
-  if (a.TL == 64 && a.WB == 4) return launch_tl<64, 4>(a, grid, st);
-  if (a.TL == 64 && a.WB == 3) return launch_tl<64, 3>(a, grid, st);
+  const int wbm = a.WBM > 0 ? a.WBM : a.WB;
+  if (a.TL == 128 && a.WB == 4 && wbm == 4) return launch_tl<128, 4, 4>(a, grid, st);
+  if (a.TL == 128 && a.WB == 4 && wbm == 2) return launch_tl<128, 2, 4>(a, grid, st);
+  if (a.TL == 64 && a.WB == 4 && wbm == 4) return launch_tl<64, 4, 4>(a, grid, st);
+  if (a.TL == 64 && a.WB == 3 && wbm == 3) return launch_tl<64, 3, 3>(a, grid, st);
   return hipErrorInvalidValue;
 }
 
@@ -189,7 +195,8 @@ int dw_gemm_units(DwGemmArgs& a) {
   int units = 0;
   for (int k = 0; k < a.n_items; ++k) {
     DwGemmItem& it = a.it[k];
-    it.mt = (it.Mblk + 2 * a.WB - 1) / (2 * a.WB);
+    const int wbm = a.WBM > 0 ? a.WBM : a.WB;
+    it.mt = (it.Mblk + 2 * wbm - 1) / (2 * wbm);
     it.nt = (it.Kblk + 2 * a.WB - 1) / (2 * a.WB);
     it.unit0 = units;
     units += it.mt * it.nt;
