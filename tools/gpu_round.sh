@@ -17,6 +17,7 @@ if [ -f mri-implicit-neural-representations_amd/lib/libinr_mi355x_dbg.so ]; then
   timeout -k 10 120 python tools/stamps.py 25000 bf16 > gpurun_out/${TAG}_stamps_bf16.log 2>&1; echo "stamps bf16 rc=$?"
   timeout -k 10 120 python tools/stamps.py 65536 bf16 > gpurun_out/${TAG}_stamps_bf16_65536.log 2>&1
   timeout -k 10 120 python tools/stamps.py 65536 f32 > gpurun_out/${TAG}_stamps_f32_65536.log 2>&1
+  timeout -k 10 120 python tools/stamps.py 25000 wire > gpurun_out/${TAG}_stamps_wire.log 2>&1
 fi
 python - <<'PY'
 import json,glob
