@@ -93,7 +93,9 @@ enum inr_loss {
   INR_LOSS_TANH = 2,    /* TanhL2Loss                 metrics/losses.py:130-139 */
   INR_LOSS_LOGSPACE = 3,/* LogSpaceLoss               metrics/losses.py:214-223 */
   INR_LOSS_HDR = 4,     /* HDRLoss_FF (separable form) metrics/losses.py:236-264 */
-  INR_LOSS_MSLE_HALF = 5 /* 0.5 * MSLELoss()           metrics/losses.py:18-27; train.py:84,182 */
+  INR_LOSS_MSLE_HALF = 5, /* 0.5 * MSLELoss()          metrics/losses.py:18-27; train.py:84,182 */
+  INR_LOSS_CENTER = 6    /* CenterLoss ('LSL' of train.py:87-88), pointwise part: metrics/losses.py:141-173,201;
+                            its random-pair term is inr_center_pairs_grad */
 };
 
 typedef struct inr_net_desc {
@@ -225,6 +227,15 @@ int inr_loss_grad_multi(const inr_loss_desc* loss, const float* outs, const floa
  * (same layout as inr_loss_grad, which is normally called first on the same buffers). */
 int inr_tv_grad(const float* out, int64_t R, int64_t R_own, int64_t W, int64_t H, float weight,
                 float* loss_out, float* dout, void* stream);
+
+/* Replaces the random-pair ("centre") term of CenterLoss.forward (metrics/losses.py:175-199; 'LSL' of train.py:87-88,
+ * called at train.py:178-180) for ONE radial band: the caller draws the n row pairs (idx_a[p] from the inner mask, idx_b[p]
+ * from the ring outside it) with torch.randperm exactly as the reference does (losses.py:193-194) and passes global row
+ * indices into out / gt [B,2];  r_p = (|gt_a| - |gt_b|) - (|out_a| - |out_b|).  ADDS  weight * mean_p r_p^2  to loss_out[0]
+ * (loss_out[1..64] is scratch, same layout as inr_loss_grad) and its gradient to dout [B,2].  Call after inr_loss_grad with
+ * INR_LOSS_CENTER on the same buffers (weight = 0.1 per band, losses.py:201), before inr_backward. */
+int inr_center_pairs_grad(const float* out, const float* gt, const int64_t* idx_a, const int64_t* idx_b, int64_t n,
+                          int64_t B, float weight, float* loss_out, float* dout, void* stream);
 
 /* Fused tier-2 step, stages 1-3 of train.py:163-189 in one launch: encode -> forward -> pointwise
  * loss -> backward, then the fixed-order slab reduction.  Leaves grads [P] and loss_out[0];

@@ -775,7 +775,7 @@ int inr_loss_grad(const inr_loss_desc* loss, const float* out, const float* gt, 
                   const uint8_t* mask, int64_t B, float* loss_out, float* dout, void* stream) {
   if (loss == nullptr || out == nullptr || gt == nullptr || loss_out == nullptr || dout == nullptr)
     return fail(INR_ERR_INVALID, "inr_loss_grad: null argument");
-  if (loss->kind < INR_LOSS_L2_HALF || loss->kind > INR_LOSS_MSLE_HALF)
+  if (loss->kind < INR_LOSS_L2_HALF || loss->kind > INR_LOSS_CENTER)
     return fail(INR_ERR_INVALID, "inr_loss_grad: loss kind %d", loss->kind);
   if (B <= 0) return fail(INR_ERR_INVALID, "inr_loss_grad: B = %lld", (long long)B);
   LossDesc ld;
@@ -789,7 +789,7 @@ int inr_loss_grad_multi(const inr_loss_desc* loss, const float* outs, const floa
                         const uint8_t* mask, int32_t n_heads, int64_t B, float* loss_out, float* douts, void* stream) {
   if (loss == nullptr || outs == nullptr || gt == nullptr || loss_out == nullptr || douts == nullptr)
     return fail(INR_ERR_INVALID, "inr_loss_grad_multi: null argument");
-  if (loss->kind < INR_LOSS_L2_HALF || loss->kind > INR_LOSS_MSLE_HALF)
+  if (loss->kind < INR_LOSS_L2_HALF || loss->kind > INR_LOSS_CENTER)
     return fail(INR_ERR_INVALID, "inr_loss_grad_multi: loss kind %d", loss->kind);
   if (n_heads < 1 || n_heads > INR_MAX_HEADS || B <= 0)
     return fail(INR_ERR_INVALID, "inr_loss_grad_multi: n_heads %d, B %lld", n_heads, (long long)B);
@@ -815,6 +815,17 @@ int inr_tv_grad(const float* out, int64_t R, int64_t R_own, int64_t W, int64_t H
   return INR_OK;
 }
 
+int inr_center_pairs_grad(const float* out, const float* gt, const int64_t* idx_a, const int64_t* idx_b, int64_t n,
+                          int64_t B, float weight, float* loss_out, float* dout, void* stream) {
+  if (out == nullptr || gt == nullptr || idx_a == nullptr || idx_b == nullptr || loss_out == nullptr || dout == nullptr)
+    return fail(INR_ERR_INVALID, "inr_center_pairs_grad: null argument");
+  if (n <= 0 || B <= 0) return fail(INR_ERR_INVALID, "inr_center_pairs_grad: n %lld B %lld", (long long)n, (long long)B);
+  hipError_t e = inr::launch_center_pairs(out, gt, (const long long*)idx_a, (const long long*)idx_b, n, B,
+                                          (float)((double)weight / (double)n), loss_out, dout, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "inr_center_pairs_grad");
+  return INR_OK;
+}
+
 int inr_train_step(const inr_plan* plan, const inr_loss_desc* loss, const float* params, const float* packed,
                    const float* x, const float* enc_B, const float* gt, const uint8_t* mask, int64_t B,
                    const inr_workspace* ws, float* grads, float* loss_out, void* stream) {
@@ -824,7 +835,7 @@ int inr_train_step(const inr_plan* plan, const inr_loss_desc* loss, const float*
   if (plan->nd.mfn_n > 0)
     return fail(INR_ERR_INVALID, "inr_train_step: multiplicative-filter plans use inr_train_step_multi");
   if (plan->nd.input == IN_GAUSS && enc_B == nullptr) return fail(INR_ERR_INVALID, "inr_train_step: enc_B is null");
-  if (loss->kind < INR_LOSS_L2_HALF || loss->kind > INR_LOSS_MSLE_HALF)
+  if (loss->kind < INR_LOSS_L2_HALF || loss->kind > INR_LOSS_CENTER)
     return fail(INR_ERR_INVALID, "inr_train_step: loss kind %d", loss->kind);
   if (loss->kind >= INR_LOSS_LOGSPACE && plan->nd.out_f != 2)
     return fail(INR_ERR_INVALID, "inr_train_step: complex-row losses need out_features == 2");
@@ -959,7 +970,7 @@ int inr_train_step_multi(const inr_plan* plan, const inr_loss_desc* loss, const 
     return fail(INR_ERR_INVALID, "inr_train_step_multi: null argument");
   if (plan->nd.input == IN_GAUSS && enc_B == nullptr) return fail(INR_ERR_INVALID, "inr_train_step_multi: enc_B is null");
   if (plan->nd.mfn_n == 0) return fail(INR_ERR_INVALID, "inr_train_step_multi: not a multiplicative-filter plan");
-  if (loss->kind < INR_LOSS_L2_HALF || loss->kind > INR_LOSS_MSLE_HALF)
+  if (loss->kind < INR_LOSS_L2_HALF || loss->kind > INR_LOSS_CENTER)
     return fail(INR_ERR_INVALID, "inr_train_step_multi: loss kind %d", loss->kind);
   if ((loss->cons_w != 0.f || plan->nd.bounded) && dist == nullptr)
     return fail(INR_ERR_INVALID, "inr_train_step_multi: the consistency term / bounded linears need dist");

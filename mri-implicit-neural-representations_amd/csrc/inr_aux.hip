@@ -658,4 +658,52 @@ hipError_t launch_tv_grad(const float* out, long long R, long long R_own, long l
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// CenterLoss, random-pair term of one band (metrics/losses.py:175-199): for pairs p < n of rows (a_p, b_p) -- drawn by the
+// caller with torch.randperm exactly as the reference draws them -- r_p = (|t_a| - |t_b|) - (|y_a| - |y_b|), the band adds
+// w * sum_p r_p^2 (w = 0.1 / n) to the loss and  -2 w r_p y_a / |y_a|  to dout[a_p],  +2 w r_p y_b / |y_b|  to dout[b_p].
+// The a rows of a band are distinct, so are the b rows, and no row is in both (they come from disjoint radial masks): plain
+// read-modify-write, no atomics; bands are separate launches on one stream.  Rows outside [0, B) are ignored.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void center_pairs_kernel(const float* __restrict__ out, const float* __restrict__ gt,
+                                                           const long long* __restrict__ ia, const long long* __restrict__ ib,
+                                                           long long n, long long B, float w, float* __restrict__ loss_out,
+                                                           float* __restrict__ dout) {
+  __shared__ float red[256];
+  const long long per = (n + LOSS_BLOCKS - 1) / LOSS_BLOCKS;
+  const long long lo = (long long)blockIdx.x * per;
+  const long long hi = lo + per < n ? lo + per : n;
+  float acc = 0.f;
+  for (long long p = lo + threadIdx.x; p < hi; p += 256) {
+    const long long a = ia[p], b = ib[p];
+    if (a < 0 || a >= B || b < 0 || b >= B) continue;
+    const float yar = out[2 * a], yai = out[2 * a + 1], ybr = out[2 * b], ybi = out[2 * b + 1];
+    const float na = sqrtf(yar * yar + yai * yai), nb = sqrtf(ybr * ybr + ybi * ybi);
+    const float ta = sqrtf(gt[2 * a] * gt[2 * a] + gt[2 * a + 1] * gt[2 * a + 1]);
+    const float tb = sqrtf(gt[2 * b] * gt[2 * b] + gt[2 * b + 1] * gt[2 * b + 1]);
+    const float r = (ta - tb) - (na - nb);
+    acc += w * r * r;
+    const float ca = na > 0.f ? -2.f * w * r / na : 0.f;  // d|y|/dy = y / |y| (0 at the origin, as torch.abs)
+    const float cb = nb > 0.f ? 2.f * w * r / nb : 0.f;
+    dout[2 * a] += ca * yar;
+    dout[2 * a + 1] += ca * yai;
+    dout[2 * b] += cb * ybr;
+    dout[2 * b + 1] += cb * ybi;
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s >= 1; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss_out[1 + blockIdx.x] = red[0];
+}
+
+hipError_t launch_center_pairs(const float* out, const float* gt, const long long* ia, const long long* ib, long long n,
+                               long long B, float w, float* loss_out, float* dout, hipStream_t st) {
+  hipLaunchKernelGGL(center_pairs_kernel, dim3(LOSS_BLOCKS), dim3(256), 0, st, out, gt, ia, ib, n, B, w, loss_out, dout);
+  hipLaunchKernelGGL(loss_fold_add_kernel, dim3(1), dim3(1), 0, st, loss_out);
+  return hipGetLastError();
+}
+
 }  // namespace inr

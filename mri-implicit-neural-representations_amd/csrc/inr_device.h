@@ -40,6 +40,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define LOSS_LOGSPACE 3
 #define LOSS_HDR 4
 #define LOSS_MSLE_HALF 5
+#define LOSS_CENTER 6
 
 struct LayerDesc {
   int K, M;          // in / out features of the (virtual) real matrix the kernel multiplies
@@ -216,6 +217,18 @@ __device__ __forceinline__ float loss_row(const LossDesc& ld, int out_f, const f
       loss += 0.5f * e * e * s;
       g[o] = e / ay * s;
     }
+  } else if (ld.kind == LOSS_CENTER) {
+    // CenterLoss, pointwise part (losses.py:157-173,201): 0.1 error_loss.mean() + 0.9 (abs_loss.mean() + reg.mean()) with
+    // error_loss == abs_loss == (|y - t| / (|y|_detached + eps))^2 and reg the same [B,B] broadcast as HDRLoss_FF's
+    // (separable: factor * A * |y|^2 / den^2).  The random-pair term is inr_center_pairs_grad.
+    const float er = y[0] - t[0], ei = y[1] - t[1];
+    const float ya2 = y[0] * y[0] + y[1] * y[1];
+    const float den = sqrtf(ya2) + ld.eps;
+    const float q = inv / (den * den);
+    const float rq = 0.9f * ld.factor * ld.hdr_A * q;
+    loss = (er * er + ei * ei) * q + rq * ya2;
+    g[0] = 2.f * er * q + 2.f * rq * y[0];
+    g[1] = 2.f * ei * q + 2.f * rq * y[1];
   } else {  // LOSS_HDR: HDRLoss_FF, separable form (losses.py:236-264)
     const float er = y[0] - t[0], ei = y[1] - t[1];
     const float ya2 = y[0] * y[0] + y[1] * y[1];

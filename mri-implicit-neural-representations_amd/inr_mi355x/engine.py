@@ -21,19 +21,21 @@ class LossSpec:
     eps: float = 1e-3
     sigma: float = 2.0
     factor: float = 0.5
+    min_sample: int = 3000  # CenterLoss: pairs per radial band (loss_opts['min_sample'], losses.py:150)
 
     @staticmethod
     def from_config(config: dict) -> "LossSpec":
         name = config["loss"]
         opts = config.get("loss_opts", {}) or {}
         kinds = {"L2": L.LOSS_L2_HALF, "L1": L.LOSS_L1_HALF, "tanh": L.LOSS_TANH, "HDR": L.LOSS_HDR,
-                 "LogSpace": L.LOSS_LOGSPACE, "MSLE": L.LOSS_MSLE_HALF}  # train.py:82-96 ('LSL' there is the
-        # non-deterministic CenterLoss, 'T' / 'FFL' are broken at their call sites: SURVEY A.4 #7, #8)
+                 "LogSpace": L.LOSS_LOGSPACE, "MSLE": L.LOSS_MSLE_HALF, "LSL": L.LOSS_CENTER}  # train.py:82-96 ('LSL'
+        # there is CenterLoss -- its pairs come from torch.randperm on the CPU generator, as here; 'T' / 'FFL' are broken
+        # at their call sites: SURVEY A.4 #7, #8)
         if name not in kinds:
             # the reference evaluates `NotImplementedError` without raising (train.py:98); we raise
             raise NotImplementedError(f"loss {name!r} has no MI355X kernel (supported: {sorted(kinds)})")
         return LossSpec(kinds[name], float(opts.get("hdr_eps", 1e-3)), float(opts.get("hdr_ff_sigma", 2.0)),
-                        float(opts.get("hdr_ff_factor", 0.5)))
+                        float(opts.get("hdr_ff_factor", 0.5)), int(opts.get("min_sample", 3000)))
 
 
 def _shape(t: Optional[torch.Tensor], name: str, *shape) -> None:
@@ -224,6 +226,21 @@ class MLPEngine:
         assert R * W == out.shape[0] and out.shape[1] == 2 and dout.shape == out.shape
         L.check(self.lib.inr_tv_grad(_ptr(out, "out"), R, rows_own, W, H, C.c_float(weight),
                                      _ptr(self._loss, "loss"), _ptr(dout, "dout"), self._stream()))
+        return self._loss[0]
+
+    def center_pairs_grad(self, out: torch.Tensor, gt: torch.Tensor, dout: torch.Tensor, idx_a: torch.Tensor,
+                          idx_b: torch.Tensor, weight: float = 0.1):
+        """One radial band of CenterLoss's random-pair term (losses.py:175-199; see inr_center_pairs_grad): idx_a / idx_b
+        are int64 row indices into out / gt [B,2].  Adds weight * mean_p r_p^2 to the loss scalar of the preceding
+        loss_grad call and its gradient to dout.  Returns the loss scalar (device)."""
+        B, n = out.shape[0], idx_a.shape[0]
+        _shape(out, "out", B, 2)
+        _shape(gt, "gt", B, 2)
+        _shape(dout, "dout", B, 2)
+        _shape(idx_b, "idx_b", n)
+        L.check(self.lib.inr_center_pairs_grad(_ptr(out, "out"), _ptr(gt, "gt"), _ptr(idx_a, "idx_a", torch.int64),
+                                               _ptr(idx_b, "idx_b", torch.int64), n, B, C.c_float(weight),
+                                               _ptr(self._loss, "loss"), _ptr(dout, "dout"), self._stream()))
         return self._loss[0]
 
     def train_step(self, x: torch.Tensor, enc_B: Optional[torch.Tensor], gt: torch.Tensor, spec: LossSpec,

@@ -90,6 +90,25 @@ def allreduce_step_outputs(grads: torch.Tensor, loss: torch.Tensor, world: int, 
     return loss
 
 
+def center_pair_rows(kcoords: torch.Tensor, min_sample: int, n_bands: int = 2):
+    """The row pairs of CenterLoss's N_BANDS radial bands (losses.py:176-194), as the reference draws them: band k
+    compares dist^2 = ky^2 + kx^2 with the RATIOS (k-1)/N (0.1 for the first band) and k/N; n = min(min_sample, |inner|,
+    |ring|); torch.randperm on the default CPU generator, inner set first.  Yields (rows_a, rows_b) int64 on kcoords'
+    device; bands with an empty side are skipped."""
+    d2 = kcoords[:, 1] ** 2 + kcoords[:, 2] ** 2
+    for band in range(1, n_bands + 1):
+        r1 = (band - 1) / n_bands or 0.1
+        m1 = d2 <= r1
+        m2 = (d2 <= band / n_bands) & ~m1
+        rows1, rows2 = torch.nonzero(m1)[:, 0], torch.nonzero(m2)[:, 0]
+        n = min(min_sample, rows1.numel(), rows2.numel())
+        if n == 0:
+            continue
+        a = torch.randperm(rows1.numel())[:n].to(kcoords.device)
+        b = torch.randperm(rows2.numel())[:n].to(kcoords.device)
+        yield rows1[a].contiguous(), rows2[b].contiguous()
+
+
 class INRTrainer:
     def __init__(self, config: dict, image: torch.Tensor, coords: torch.Tensor, shape, device,
                  seed: int = 0, mask: Optional[torch.Tensor] = None, rank: int = 0, world: int = 1,
@@ -159,6 +178,13 @@ class INRTrainer:
             raise ValueError("use_tv needs per_coil batches: tv_loss views the batch as one [H,W,2] coil (train.py:175)")
         if self.use_tv and self.is_mfn:
             raise NotImplementedError("use_tv with the multiplicative filter networks")
+        if self.loss.kind == L.LOSS_CENTER:
+            if self.mask is not None:
+                # the reference indexes the MASKED predictions with radial masks of the UNMASKED coordinates
+                # (train.py:176-179, losses.py:188-189): an IndexError there
+                raise NotImplementedError("loss 'LSL' (CenterLoss) with an undersampling mask")
+            if self.is_mfn or world > 1 or self.per_coil:
+                raise NotImplementedError("loss 'LSL' (CenterLoss): single-rank SIREN / FFN / WIRE fits on plain batches")
         self.steps_per_epoch = math.ceil(self.n / self.bs)
         self.global_step = 0
         self._hdr_A = {}
@@ -175,7 +201,7 @@ class INRTrainer:
 
     def _batch_hdr_A(self, it: int, lo: int, hi: int) -> float:
         """A = mean_i((1-f_i)^2) over ALL batch coordinates (losses.py:241-242,258; SURVEY A.4 #17)."""
-        if self.loss.kind != L.LOSS_HDR:
+        if self.loss.kind not in (L.LOSS_HDR, L.LOSS_CENTER):
             return 0.0
         if it not in self._hdr_A:
             kc = self.coords[lo:hi]
@@ -192,6 +218,8 @@ class INRTrainer:
         A = self._batch_hdr_A(it, lo, hi)
         if self.use_tv:
             loss = self._tv_step(lo, count, A)
+        elif self.loss.kind == L.LOSS_CENTER:
+            loss = self._center_step(lo, hi, A)
         else:
             slo, shi = shard_rows(lo, hi, self.rank, self.world)
             if shi == slo:  # a short last batch can leave a rank without rows: it contributes zeros to the sum
@@ -216,6 +244,19 @@ class INRTrainer:
     def _fused(self, slo, shi, count, m, A):
         return self.engine.train_step(self._inputs(slo, shi), self.enc_B, self.image[slo:shi], self.loss,
                                       count=count, mask=m, hdr_A=A)
+
+    def _center_step(self, lo: int, hi: int, A: float) -> torch.Tensor:
+        """CenterLoss ('LSL', train.py:87-88,178-180; losses.py:141-201): forward -> pointwise part -> the random-pair
+        term of the two radial bands -> backward.  The pairs are drawn with torch.randperm on the CPU generator in the
+        reference's order (band 1: inner, ring; band 2: inner, ring), from masks on dist^2 = ky^2 + kx^2 compared with the
+        band RATIOS (losses.py:153-154,180-187).  Single rank, whole batches (pairs span the batch)."""
+        x, gt = self._inputs(lo, hi), self.image[lo:hi]
+        out = self.engine.forward(x, self.enc_B, save=True)
+        loss, dout = self.engine.loss_grad(self.loss, out, gt, hi - lo, hdr_A=A)
+        for rows_a, rows_b in center_pair_rows(self.coords[lo:hi], self.loss.min_sample):
+            loss = self.engine.center_pairs_grad(out, gt, dout, rows_a, rows_b, 0.1)
+        self.engine.backward(x, self.enc_B, dout)
+        return loss
 
     def _tv_step(self, lo: int, count: int, A: float) -> torch.Tensor:
         """Per-coil step with total variation (train.py:163-189 with use_tv): forward (stashing) ->

@@ -30,7 +30,7 @@ __all__ = [
     "init_fourier", "fourier_forward", "init_gabor", "gabor_forward", "kgabor_forward",
     "init_multiscale", "multiscale_forward", "init_bounded", "bounded_forward",
     "init_model", "model_forward", "trainable_keys",
-    "loss_l2_half", "loss_l1_half", "loss_hdr", "loss_tanh", "loss_logspace", "loss_msle",
+    "loss_l2_half", "loss_l1_half", "loss_hdr", "loss_center", "loss_tanh", "loss_logspace", "loss_msle",
     "loss_consistency", "loss_tv", "reg_l1", "reg_l2", "make_loss",
     "adam_init", "adam_step", "lr_factor",
     "complex_abs", "rss", "fft2c", "ifft2c", "psnr",
@@ -516,6 +516,43 @@ def loss_hdr(out: Tensor, gt: Tensor, kcoords: Tensor, opts: dict) -> Tuple[Tens
     return loss.mean() + reg, reg
 
 
+def loss_center(out: Tensor, gt: Tensor, kcoords: Tensor, opts: dict) -> Tuple[Tensor, int]:
+    """CenterLoss.forward (losses.py:141-201; 'LSL' of train.py:87-88).  Pointwise part: 0.1 error_loss.mean() +
+    0.9 (abs_loss.mean() + reg.mean()) with error_loss == abs_loss == (|y - t| / (|y|_detached + eps))^2 (:160-169) and
+    reg the same [B,1] x [B] -> [B,B] broadcast as HDRLoss_FF (:170-171; separable form as in loss_hdr).  Pair term
+    (:173-199): N_BANDS = 2 radial bands on dist^2 = ky^2 + kx^2 compared with the band RATIOS (0.1 | 0.5, then 0.5 | 1.0);
+    n = min(min_sample, |inner|, |ring|) pairs per band drawn with torch.randperm on the default (CPU) generator, inner
+    first; 0.1 * sum_bands mean((diff_gt - diff_pred)^2)."""
+    sigma, eps, factor = float(opts["hdr_ff_sigma"]), float(opts["hdr_eps"]), float(opts["hdr_ff_factor"])
+    min_sample = int(opts["min_sample"])
+    d2 = kcoords[..., 1] ** 2 + kcoords[..., 2] ** 2
+    f = torch.exp(-d2 / (2 * sigma ** 2))
+    y = torch.view_as_complex(out.contiguous())
+    t = torch.view_as_complex(gt.contiguous())
+    den = y.detach().abs() + eps
+    rel = ((y - t).abs() / den) ** 2
+    reg = factor * torch.mean((1.0 - f) ** 2) * torch.mean((y.abs() / den) ** 2)
+    ya, ta = y.abs(), t.abs()
+    center = torch.zeros((), dtype=out.dtype, device=out.device)
+    n_bands = 2
+    for band in range(1, n_bands + 1):
+        r1 = (band - 1) / n_bands
+        if r1 == 0:
+            r1 = 0.1
+        m1 = d2 <= r1
+        m2 = (d2 <= band / n_bands) & ~m1
+        y1, y2 = ya[m1], ya[m2]
+        n = min(min_sample, min(len(y1), len(y2)))
+        if n == 0:
+            continue
+        a = torch.randperm(y1.size(0))[:n]
+        b = torch.randperm(y2.size(0))[:n]
+        diff_pred = y1[a] - y2[b]
+        diff_gt = ta[m1][a] - ta[m2][b]
+        center = center + ((diff_gt - diff_pred) ** 2).mean()
+    return 0.1 * rel.mean() + 0.9 * (rel.mean() + reg) + 0.1 * center, 0
+
+
 def loss_tanh(out: Tensor, gt: Tensor) -> Tuple[Tensor, float]:
     """TanhL2Loss.forward, with_mag=False (losses.py:130-139)."""
     return torch.mean((torch.tanh(out) - torch.tanh(gt)) ** 2), 0
@@ -578,6 +615,8 @@ def make_loss(config: dict):
         return lambda o, g, k: loss_hdr(o, g, k, opts)[0]
     if kind == "tanh":
         return lambda o, g, k: loss_tanh(o, g)[0]
+    if kind == "LSL":
+        return lambda o, g, k: loss_center(o, g, k, opts)[0]
     raise NotImplementedError(kind)
 
 

@@ -262,7 +262,9 @@ def test_trajectory_golden(dev):
     arrs = _load("trajectory.npz")
     meta = json.load(open(os.path.join(GOLD, "trajectory_meta.json")))
     coords, image = _t(arrs["coords"]), _t(arrs["image"])
-    for tag in ("SIREN_L2", "SIREN_L2_reg", "SIREN_regL2"):  # plain | + Regularization_L1 + weight decay | + Regularization_L2
+    # plain | + Regularization_L1 + weight decay | + Regularization_L2 | CenterLoss ('LSL': forward -> pointwise part ->
+    # two bands of torch.randperm pairs -> backward; the trainer draws from the generator its constructor seeded)
+    for tag in ("SIREN_L2", "SIREN_L2_reg", "SIREN_regL2", "SIREN_LSL"):
         cfg = meta["cases"][tag]
         tr = INRTrainer(cfg, image, coords, tuple(meta["shape"]), dev, seed=meta["seed"])
         got = [s[1] for s in tr.fit(meta["steps"], log_every=1)]
@@ -274,6 +276,35 @@ def test_trajectory_golden(dev):
         for k, v in tr.model.state_dict().items():
             torch.testing.assert_close(v.cpu(), _t(arrs[f"{tag}/final_sd/{k}"]), rtol=1e-4, atol=2e-6,
                                        msg=lambda m: f"{tag} {k}: {m}")
+
+
+def test_center_loss_vs_reference_vectors(dev):
+    """CenterLoss through inr_loss_grad(INR_LOSS_CENTER) + inr_center_pairs_grad against value and gradient of the
+    reference class (tests/golden/center.npz, pairs from torch.randperm under the fixture's seed)."""
+    import inr_mi355x as M
+    from inr_mi355x import _lib as L
+    from inr_mi355x.train import center_pair_rows
+    arrs = _load("center.npz")
+    out, gt, kc = (_t(arrs[k]).to(dev).contiguous() for k in ("out", "gt", "kcoords"))
+    net = dict(network_input_size=3, network_output_size=2, network_depth=2, network_width=32)
+    eng = M.SIREN(net).to(dev)._engine()  # (any engine: the loss entry points only use its scalar buffer and stream)
+    f = torch.exp(-(kc[:, 1] ** 2 + kc[:, 2] ** 2) / (2 * 2.0 ** 2))
+    A = float(torch.mean((1 - f) ** 2))
+    for tag, ms in (("ms50", 50), ("ms3000", 3000)):
+        spec = M.LossSpec(L.LOSS_CENTER, 1e-3, 2.0, 0.5, ms)
+        loss, dout = eng.loss_grad(spec, out, gt, out.shape[0], hdr_A=A)
+        torch.manual_seed(int(arrs["seed"]))
+        n_bands = 0
+        for rows_a, rows_b in center_pair_rows(kc, ms):
+            loss = eng.center_pairs_grad(out, gt, dout, rows_a, rows_b, 0.1)
+            n_bands += 1
+        assert n_bands == 2
+        torch.testing.assert_close(loss.cpu().reshape(1), _t(arrs[tag + "/loss"]), rtol=1e-5, atol=0)
+        torch.testing.assert_close(dout.cpu(), _t(arrs[tag + "/grad"]), rtol=1e-4, atol=1e-8)
+    # malformed calls are refused, rows outside the batch ignored
+    bad = torch.tensor([0, 10 ** 9], device=dev)
+    eng.center_pairs_grad(out, gt, dout, bad, bad.flip(0).contiguous(), 0.1)
+    torch.cuda.synchronize()
 
 
 def test_eval_chain_and_psnr(dev):

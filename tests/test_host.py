@@ -48,7 +48,9 @@ def test_plan_validation_and_sizes():
     slots, slabs = C.c_int64(), C.c_int64()
     assert sz.step_save_by_tile == 1
     assert lib.inr_plan_workspace(plan, 25000, C.byref(slots), C.byref(slabs)) == 0
-    assert (slots.value, slabs.value) == (196, 196 + 49)  # 5 workgroup tiles per chunk -> 51 chunks of 4 tiles wanted -> 49
+    # 256 x 256 tiles: 5 per chunk -> 51 chunks of 4 tiles = K 512 each: short, so 128 x 256 tiles (10 per chunk) over
+    # twice the K: 25 chunks of 8 tiles
+    assert (slots.value, slabs.value) == (196, 196 + 25)
     assert lib.inr_plan_workspace(plan, 65536, C.byref(slots), C.byref(slabs)) == 0
     assert slots.value == 512 and 256 < slabs.value <= 256 + 52
     assert lib.inr_plan_workspace(plan, 100, C.byref(slots), C.byref(slabs)) == 0

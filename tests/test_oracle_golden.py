@@ -202,6 +202,20 @@ def test_losses_golden(golden_dir):
         torch.testing.assert_close(grs[1], _t(arrs[tag + "/grad1"]), rtol=1e-6, atol=0)
 
 
+def test_center_loss_golden(golden_dir):
+    """CenterLoss ('LSL' of train.py:87-88): value and gradient, pairs drawn by torch.randperm under the fixture's seed."""
+    arrs = _load(golden_dir, "center.npz")
+    gt, kc = _t(arrs["gt"]), _t(arrs["kcoords"])
+    for tag, ms in (("ms50", 50), ("ms3000", 3000)):
+        opts = dict(hdr_eps=1e-3, hdr_ff_sigma=2, hdr_ff_factor=0.5, min_sample=ms)
+        out = _t(arrs["out"]).clone().requires_grad_(True)
+        torch.manual_seed(int(arrs["seed"]))
+        loss, _ = O.loss_center(out, gt, kc, opts)
+        (g,) = torch.autograd.grad(loss, out)
+        torch.testing.assert_close(loss.detach().reshape(1), _t(arrs[tag + "/loss"]), rtol=1e-5, atol=0)
+        torch.testing.assert_close(g, _t(arrs[tag + "/grad"]), rtol=1e-4, atol=1e-8)
+
+
 def test_trajectories_golden(golden_dir):
     """The oracle's restatement of the train.py loop tracks the reference-driven trajectory."""
     arrs = _load(golden_dir, "trajectory.npz")

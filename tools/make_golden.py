@@ -31,7 +31,7 @@ from models.mfn import (FourierNet, GaborNet, KGaborNet, MultiscaleKFourier,  # 
                         MultiscaleBoundedFourier)
 from models.wire2d import WIRE2D  # noqa: E402
 from models.regularization import Regularization_L1, Regularization_L2  # noqa: E402
-from metrics.losses import (HDRLoss_FF, TanhL2Loss, LogSpaceLoss, ConsistencyLoss,  # noqa: E402
+from metrics.losses import (HDRLoss_FF, TanhL2Loss, LogSpaceLoss, ConsistencyLoss, CenterLoss,  # noqa: E402
                             tv_loss, MSLELoss)
 
 torch.set_num_threads(1)  # deterministic reduction order
@@ -303,6 +303,12 @@ def trajectory():
                          net=dict(network_input_size=3, network_output_size=2, network_depth=2, network_width=46,
                                   first_omega_0=30, hidden_omega_0=30, scale=15),
                          encoder=dict(embedding="none", scale=0, embedding_size=0, coordinates_size=3)),
+        "SIREN_LSL": dict(model="SIREN", loss="LSL", lr=1e-4, batch_size=480, max_epoch=3, weight_decay=0.0,
+                          beta1=0.9, beta2=0.999,
+                          loss_opts=dict(hdr_eps=3e-3, hdr_ff_sigma=2, hdr_ff_factor=0.5, min_sample=40),
+                          net=dict(network_input_size=16, network_output_size=2, network_depth=3, network_width=32,
+                                   last_tanh=True),
+                          encoder=dict(embedding="gauss", scale=2, embedding_size=8, coordinates_size=3)),
         "Fourier_tanh": dict(model="Fourier", loss="tanh", lr=1e-3, batch_size=480, max_epoch=4, weight_decay=0.0,
                              beta1=0.9, beta2=0.999,
                              net=dict(network_input_size=16, network_output_size=2, network_depth=3, network_width=32),
@@ -323,6 +329,8 @@ def trajectory():
             loss_fn = HDRLoss_FF(cfg["loss_opts"])
         elif cfg["loss"] == "tanh":
             loss_fn = TanhL2Loss()
+        elif cfg["loss"] == "LSL":  # CenterLoss: its torch.randperm draws continue the generator seeded above
+            loss_fn = CenterLoss(cfg["loss_opts"])
         reg = None
         if cfg.get("regularization", {}).get("type") == "L1":
             reg = Regularization_L1(reg_strength=cfg["regularization"]["strenght"])
@@ -343,7 +351,7 @@ def trajectory():
                 # copy, i.e. the only arithmetic the combination can mean.
                 out = out.contiguous()
                 optim.zero_grad()
-                if cfg["loss"] in ("HDR", "tanh"):
+                if cfg["loss"] in ("HDR", "tanh", "LSL"):
                     loss, _ = loss_fn(out, gt, kc)
                 else:
                     loss = 0.5 * loss_fn(out, gt)
@@ -367,6 +375,24 @@ def trajectory():
     np.savez_compressed(os.path.join(OUT, "trajectory.npz"), **arrs)
     with open(os.path.join(OUT, "trajectory_meta.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)
+
+
+def center_vectors():
+    """CenterLoss.forward (losses.py:141-201) value and gradient; the pairs are whatever torch.randperm draws after
+    torch.manual_seed(SEED) -- the oracle and the engine's host side draw the same way."""
+    g = torch.Generator().manual_seed(77)
+    B, SEED = 800, 4321
+    out = (torch.randn(B, 2, generator=g) * 0.2).requires_grad_(True)
+    gt = torch.randn(B, 2, generator=g) * 0.2
+    kc = torch.rand(B, 3, generator=g) * 2 - 1
+    arrs = {"out": npy(out), "gt": npy(gt), "kcoords": npy(kc), "seed": np.array(SEED)}
+    for tag, ms in (("ms50", 50), ("ms3000", 3000)):
+        opts = dict(hdr_eps=1e-3, hdr_ff_sigma=2, hdr_ff_factor=0.5, min_sample=ms)
+        torch.manual_seed(SEED)
+        loss, _ = CenterLoss(opts)(out, gt, kc)
+        (gr,) = torch.autograd.grad(loss, out)
+        arrs[tag + "/loss"], arrs[tag + "/grad"] = npy(loss), npy(gr)
+    np.savez_compressed(os.path.join(OUT, "center.npz"), **arrs)
 
 
 def multiscale_trajectory():
@@ -566,7 +592,8 @@ def clustering_vectors():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     parts = dict(clustering=clustering_vectors, undersampling=undersampling_vectors, init=init_hashes,
-                 models=model_vectors, losses=loss_vectors, trajectory=trajectory, multiscale=multiscale_trajectory)
+                 models=model_vectors, losses=loss_vectors, center=center_vectors, trajectory=trajectory,
+                 multiscale=multiscale_trajectory)
     for name in (sys.argv[1:] or list(parts)):  # python tools/make_golden.py [part ...]; default: everything
         parts[name]()
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
