@@ -15,9 +15,15 @@ namespace inr {
 
 // owner-rows pass dZ = dH * act'(z) on image rows [r0, r0 + RH) of this wave's coordinate column.
 // PAIR (WIRE): rows (2i, 2i+1) hold (p, q) = dL/d(y_r, y_i); dZ[row] = p * dA[row] + q * dB[row]
-template <int TL, int RH, bool PAIR>
+// JAC (WIRE, eager activation): the stash holds y (dA argument) and the pre-activations z = a + j b (dB argument) of
+// every complex feature, and the four Jacobian entries of the Gabor wavelet are formed here from them -- the same
+// expressions, in the same order, that round 1 evaluated in the forward epilogue and stashed (six stores per feature
+// instead of four: the epilogues run at the CU's share of the HBM write rate).
+template <int TL, int RH, bool PAIR, bool JAC = false>
 __device__ __forceinline__ void rows_times(float* R, const float* __restrict__ dA, const float* __restrict__ dB, int r0,
-                                           int wcol, int lane) {
+                                           int wcol, int lane, float omega = 0.f, float s0 = 0.f) {
+  static_assert(!JAC || PAIR, "the Jacobian form is the complex one");
+  const float s2 = s0 * s0;
   const int half = lane >> 5, col = lane & 31;
   // The Jacobian entries come from the stash (HBM / L2): with four rows in flight per lane the pass ran at one memory
   // latency per four rows (phase stamps: 35 k cycles per layer at 192 rows per wave).  Batches of BT row steps are
@@ -47,7 +53,13 @@ __device__ __forceinline__ void rows_times(float* R, const float* __restrict__ d
 #pragma unroll
     for (int i = 0; i < BT; ++i) {
       const int r = r0 + (b + i) * STEP + (PAIR ? 2 * half : half);
-      if (PAIR) {
+      if (JAC) {
+        const float p = R[swz(r, col)], q = R[swz(r + 1, col)];
+        const float yr = a0[i], yi = a1[i], za = b0[i], zb = b1[i];
+        const float ka = -2.f * s2 * za, kb = -omega - 2.f * s2 * zb;
+        R[swz(r, col)] = fmaf(p, fmaf(ka, yr, -omega * yi), q * fmaf(ka, yi, omega * yr));
+        R[swz(r + 1, col)] = fmaf(p, kb * yr, q * (kb * yi));
+      } else if (PAIR) {
         const float p = R[swz(r, col)], q = R[swz(r + 1, col)];
         R[swz(r, col)] = fmaf(p, a0[i], q * b0[i]);
         R[swz(r + 1, col)] = fmaf(p, a1[i], q * b1[i]);
@@ -59,22 +71,62 @@ __device__ __forceinline__ void rows_times(float* R, const float* __restrict__ d
   }
 }
 
+// First layer of the eager WIRE path: dZ_0 = J_0 dH_0 formed while the dX accumulators are stored to the image (own rows),
+// J_0 from the stashed (y_0, z_0) as in rows_times<.., JAC>.  Registers (2p, 2p+1) of a lane are the (Re, Im) rows of a pair.
+template <int NBM, int TL>
+__device__ __forceinline__ void acc_times_jac_to_lds(const f32x16 (&acc)[NBM], float* R, const float* __restrict__ sv_y,
+                                                     const float* __restrict__ sv_z, float omega, float s0, int wcol,
+                                                     int lane) {
+  const int half = lane >> 5, col = lane & 31;
+  float* Rl = R + (4 * half) * INR_LDS_LD + col;
+  const __amdgpu_buffer_rsrc_t rsY = uniform_rsrc(sv_y, NBM * 32 * TL * 4);
+  const __amdgpu_buffer_rsrc_t rsZ = uniform_rsrc(sv_z, NBM * 32 * TL * 4);
+  const int voff = ((4 * half) * TL + wcol) * 4;
+  const float s2 = s0 * s0;
+  constexpr int MB = NBM % 2 == 0 ? 2 : 1;  // 64 loads in flight
+#pragma unroll
+  for (int m0 = 0; m0 < NBM; m0 += MB) {
+    float y[MB][16], z[MB][16];
+#pragma unroll
+    for (int mm = 0; mm < MB; ++mm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int soff = (32 * (m0 + mm) + (r & 3) + 8 * (r >> 2)) * TL * 4;
+        y[mm][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsY, voff, soff, 0));
+        z[mm][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsZ, voff, soff, 0));
+      }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mm = 0; mm < MB; ++mm)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const int m = m0 + mm;
+        const float p = acc[m][r], q = acc[m][r + 1];
+        const float yr = y[mm][r], yi = y[mm][r + 1], za = z[mm][r], zb = z[mm][r + 1];
+        const float ka = -2.f * s2 * za, kb = -omega - 2.f * s2 * zb;
+        const int row = 32 * m + (r & 3) + 8 * (r >> 2);
+        Rl[row * INR_LDS_LD] = fmaf(p, fmaf(ka, yr, -omega * yi), q * fmaf(ka, yi, omega * yr));
+        Rl[(row + 1) * INR_LDS_LD] = fmaf(p, kb * yr, q * (kb * yi));
+      }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // WIRE, eager activation: the owner of row blocks [m0, m0+MT) holds both rows of every complex feature in registers
 // (2p, 2p+1), so the Gabor wavelet (one sincos + one exp per feature, networks.py:199-204) and the four Jacobian
 // entries of the pair are formed ONCE -- the lazy form evaluates them in both lane halves of both waves of the pair
 // (4x the transcendentals).  Writes y into the image rows (the next GEMM's plain B operand) and y, dA, dB to the
-// stash rows (Rown / sv_* already point at this wave's rows).
+// stash rows (Rown / sv_* already point at this wave's rows): slot 0 <- y, slot 1 <- z = (a, b); slot 1 is where backward
+// later leaves dZ for the batch GEMM, slot 2 of these plans stays unused.
 template <int MT, int TL>
 __device__ __forceinline__ void wire_epilogue(const f32x16 (&acc)[MT], const float* __restrict__ bias, float* Rown,
-                                              float* __restrict__ sv_h, float* __restrict__ sv_dA,
-                                              float* __restrict__ sv_dB, bool save, float omega, float s0, int wcol,
-                                              int lane) {
+                                              float* __restrict__ sv_h, float* __restrict__ sv_z, bool save, float omega,
+                                              float s0, int wcol, int lane) {
   const int half = lane >> 5, col = lane & 31;
   float* Rl = Rown + (4 * half) * INR_LDS_LD + col;
   const int voff = ((4 * half) * TL + wcol) * 4;  // per-lane byte offset; the row offset goes in an SGPR (stash_store)
   const __amdgpu_buffer_rsrc_t rh = uniform_rsrc(save ? sv_h : (const float*)bias, MT * 32 * TL * 4);
-  const __amdgpu_buffer_rsrc_t ra = uniform_rsrc(save ? sv_dA : (const float*)bias, MT * 32 * TL * 4);
-  const __amdgpu_buffer_rsrc_t rb = uniform_rsrc(save ? sv_dB : (const float*)bias, MT * 32 * TL * 4);
+  const __amdgpu_buffer_rsrc_t rz = uniform_rsrc(save ? sv_z : (const float*)bias, MT * 32 * TL * 4);
   const float* bl = bias + 4 * half;
   const float s2 = s0 * s0;
 #pragma unroll
@@ -92,14 +144,11 @@ __device__ __forceinline__ void wire_epilogue(const f32x16 (&acc)[MT], const flo
         const float yr = E * cs, yi = E * sn;
         Rl[row * INR_LDS_LD] = yr;
         Rl[(row + 1) * INR_LDS_LD] = yi;
-        if (save) {
-          const float ka = -2.f * s2 * za, kb = -omega - 2.f * s2 * zb;
+        if (save) {  // y for the next GEMM's dW and z for the backward pass, which forms the Jacobian from both
           stash_store(rh, voff, row * TL * 4, yr);
           stash_store(rh, voff, (row + 1) * TL * 4, yi);
-          stash_store(ra, voff, row * TL * 4, fmaf(ka, yr, -omega * yi));  // d y_r / d a
-          stash_store(rb, voff, row * TL * 4, fmaf(ka, yi, omega * yr));   // d y_i / d a
-          stash_store(ra, voff, (row + 1) * TL * 4, kb * yr);              // d y_r / d b
-          stash_store(rb, voff, (row + 1) * TL * 4, kb * yi);              // d y_i / d b
+          stash_store(rz, voff, row * TL * 4, za);
+          stash_store(rz, voff, (row + 1) * TL * 4, zb);
         }
       }
     }
@@ -193,8 +242,7 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
         INR_STAMP(si); ++si;
         if (EAGER)
           wire_epilogue<MT, TL>(acc, a.packed + L0.pbias_off + m0 * 32, Rown, sv + (size_t)m0 * 32 * TL,
-                                sv + (size_t)1 * HSZ + (size_t)m0 * 32 * TL, sv + (size_t)2 * HSZ + (size_t)m0 * 32 * TL,
-                                saving, L0.omega, L0.s0, wcol, lane);
+                                sv + (size_t)1 * HSZ + (size_t)m0 * 32 * TL, saving, L0.omega, L0.s0, wcol, lane);
         else
           acc_to_lds<MT, true>(acc, Rown, a.packed + L0.pbias_off + m0 * 32, lane);
         if (G2D) {  // orth_0 = V_0 x + c_0 (own rows) -> stash slots 5, 6 of layer 0
@@ -226,8 +274,8 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
         __syncthreads();  // both waves of the pair have read z_{l-1}; h_{l-1} is in the stash
         if (EAGER) {
           float* so = sv + (size_t)(NS * l) * HSZ + (size_t)m0 * 32 * TL;
-          wire_epilogue<MT, TL>(acc, a.packed + Ll.pbias_off + m0 * 32, Rown, so, so + HSZ, so + 2 * (size_t)HSZ, saving,
-                                Ll.omega, Ll.s0, wcol, lane);
+          wire_epilogue<MT, TL>(acc, a.packed + Ll.pbias_off + m0 * 32, Rown, so, so + HSZ, saving, Ll.omega, Ll.s0, wcol,
+                                lane);
         } else {
           acc_to_lds<MT, true>(acc, Rown, a.packed + Ll.pbias_off + m0 * 32, lane);
         }
@@ -319,7 +367,10 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
       bwd_dx<MT, TL, false, false, NB>(gacc, R, a.packed + LL.pb_off + aoff, LL.Mpad8, nullptr, wcol, lane);
       INR_STAMP(si); ++si;
       __syncthreads();  // all reads of dZ_last are done
-      if (D == 2)
+      if (D == 2 && EAGER)
+        acc_times_jac_to_lds<MT, TL>(gacc, Rown, sv + (size_t)m0 * 32 * TL, sv + (size_t)1 * HSZ + (size_t)m0 * 32 * TL,
+                                     nd.L[0].omega, nd.L[0].s0, wcol, lane);  // dZ_0 (own rows)
+      else if (D == 2)
         acc_times_d_to_lds<MT, TL, PAIR>(gacc, Rown, sv + (size_t)1 * HSZ + (size_t)m0 * 32 * TL,
                                          sv + (size_t)2 * HSZ + (size_t)m0 * 32 * TL, wcol, lane);  // dZ_0 (own rows)
       else
@@ -329,8 +380,11 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
         INR_STAMP(si); ++si;
         __syncthreads();  // dH_l complete
         if (G2D) rows_copy<TL, RH, true>(R, sv_g, RH * hh, wcol, lane);  // needed again for the orth Linear
-        rows_times<TL, RH, PAIR>(R, sv + (size_t)(NS * l + 1) * HSZ, sv + (size_t)(NS * l + 2) * HSZ, RH * hh, wcol,
-                                 lane);  // own rows: dZ_l = dH_l * act'
+        if (EAGER)  // own rows: dZ_l = J_l dH_l with J_l from the stashed (y_l, z_l)
+          rows_times<TL, RH, true, true>(R, sv + (size_t)(NS * l) * HSZ, sv + (size_t)(NS * l + 1) * HSZ, RH * hh, wcol, lane,
+                                         Ll.omega, Ll.s0);
+        else  // own rows: dZ_l = dH_l * act'
+          rows_times<TL, RH, PAIR>(R, sv + (size_t)(NS * l + 1) * HSZ, sv + (size_t)(NS * l + 2) * HSZ, RH * hh, wcol, lane);
         INR_STAMP(si); ++si;
         __syncthreads();
 #pragma unroll
@@ -350,7 +404,10 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
           rows_copy<TL, RH, true>(R, sv + (size_t)(NS * l + 3) * HSZ, RH * hh, wcol, lane);  // dZ_orth (own rows)
           __syncthreads();
         }
-        if (l == 1)
+        if (l == 1 && EAGER)
+          acc_times_jac_to_lds<MT, TL>(gacc, Rown, sv + (size_t)m0 * 32 * TL, sv + (size_t)1 * HSZ + (size_t)m0 * 32 * TL,
+                                       nd.L[0].omega, nd.L[0].s0, wcol, lane);
+        else if (l == 1)
           acc_times_d_to_lds<MT, TL, PAIR>(gacc, Rown, sv + (size_t)1 * HSZ + (size_t)m0 * 32 * TL,
                                            sv + (size_t)2 * HSZ + (size_t)m0 * 32 * TL, wcol, lane);
         else
