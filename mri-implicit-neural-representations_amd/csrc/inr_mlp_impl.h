@@ -366,14 +366,27 @@ struct ActParams {
   float s0;  // WIRE scale_0 of the producing layer
 };
 
-template <int HACT>
+// ZSTASH (WIRE2D on the two-waves-per-group kernel): only y is formed; `d` carries the lane's own pre-activation row
+// (a for the Re row, b for the Im row) to the stash in the slot the Jacobian entry used to take -- every entry of the
+// wavelet's Jacobian is y times a polynomial in (a, b, u, v), which the backward row passes evaluate from the stashed
+// y, z and orth rows (three stashed tensors per layer instead of seven; the lazy loop loses 12 of its 20 stores per group).
+template <int HACT, bool ZSTASH = false>
 __device__ __forceinline__ void lazy_act(const float (&z)[4], const float (&zp)[4], const float (&zo)[4],
                                          const float (&zq)[4], const ActParams& ap, int half, float (&h)[4],
                                          float (&d)[4], float (&d2)[4], float (&d3)[4], float (&d4)[4]) {
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     d3[e] = d4[e] = 0.f;
-    if (HACT == ACT_GABOR2D) {
+    if (HACT == ACT_GABOR2D && ZSTASH) {
+      float sn, cs;
+      sincos_cw(ap.w0 * z[e], sn, cs);
+      const float s2 = ap.s0 * ap.s0;
+      const float Ef = expf(-ap.w0 * zp[e]);
+      const float G = expf(-s2 * ((z[e] * z[e] + zp[e] * zp[e]) + zq[e]));
+      h[e] = half ? (Ef * sn) * G : (Ef * cs) * G;  // (same association as act_gabor2d)
+      d[e] = half ? zp[e] : z[e];
+      d2[e] = 0.f;
+    } else if (HACT == ACT_GABOR2D) {
       act_gabor2d(z[e], zp[e], zo[e], zq[e], ap.w0, ap.s0, half, h[e], d[e], d2[e], d3[e], d4[e]);
     } else if (HACT == ACT_GABOR) {
       // z = Re row value, zp = Im row value of the pair (both halves read both rows)
@@ -411,7 +424,7 @@ __device__ __forceinline__ void load_oq(float (&zo)[4], float (&zq)[4], const fl
   }
 }
 
-template <int NBOUT, int TL, int HACT, bool SAVE, bool ALDS = false>
+template <int NBOUT, int TL, int HACT, bool SAVE, bool ALDS = false, bool ZSTASH = false>
 __device__ __forceinline__ void fwd_group(f32x16 (&acc)[NBOUT], const f32x4 (&a_use)[NBOUT],
                                           f32x4 (&a_load)[NBOUT], const f32x4* p_next, float (&z_buf)[4],
                                           float (&zp_buf)[4], float (&zo_buf)[4], float (&zq_buf)[4],
@@ -433,15 +446,15 @@ __device__ __forceinline__ void fwd_group(f32x16 (&acc)[NBOUT], const f32x4 (&a_
   load_z<HACT == ACT_GABOR || G2D>(z_next, zp_next, Rcol, s4_next2, half);
   load_oq<TL, G2D>(zo_next, zq_next, svl + 5 * hsz, hsz, s4_next2);
   __builtin_amdgcn_sched_barrier(0);  // operands of the following groups are in flight behind the MFMAs
-  lazy_act<HACT>(z_buf, zp_buf, zo_buf, zq_buf, ap, half, h_load, d_load, d2_load, d3_load, d4_load);
+  lazy_act<HACT, ZSTASH>(z_buf, zp_buf, zo_buf, zq_buf, ap, half, h_load, d_load, d2_load, d3_load, d4_load);
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     if (SAVE) {
       const int so = (8 * s4 + 2 * e) * TL * 4;  // bytes; the tensors of a layer are hsz floats apart
       stash_store(rs, voff, so, h_use[e]);
       stash_store(rs, voff, so + hsz * 4, d_use[e]);
-      if (HACT == ACT_GABOR || G2D) stash_store(rs, voff, so + 2 * hsz * 4, d2_use[e]);
-      if (G2D) {
+      if ((HACT == ACT_GABOR || G2D) && !ZSTASH) stash_store(rs, voff, so + 2 * hsz * 4, d2_use[e]);
+      if (G2D && !ZSTASH) {
         stash_store(rs, voff, so + 3 * hsz * 4, d3_use[e]);
         stash_store(rs, voff, so + 4 * hsz * 4, d4_use[e]);
       }
@@ -464,7 +477,7 @@ __device__ __forceinline__ void fwd_group(f32x16 (&acc)[NBOUT], const f32x4 (&a_
 // (s4 * 2 + half) * 4 + row, then one float4 of zeros that the lanes of rows 4..31 read.  With the fragments in L2 the
 // loop ran at one L2 + store-acknowledge latency per group: four MFMAs do not cover a load that waits, in the in-order
 // vmcnt, behind the eight stash stores issued before it.
-template <int NB, int NBOUT, int TL, int HACT, bool SAVE, int NBT = NBOUT, bool ALDS = false>
+template <int NB, int NBOUT, int TL, int HACT, bool SAVE, int NBT = NBOUT, bool ALDS = false, bool ZSTASH = false>
 __device__ __forceinline__ void fwd_layer(f32x16 (&acc)[NBOUT], const float* R, const float* wp,
                                           const ActParams& ap, float* __restrict__ sv, int wcol, int lane) {
   static_assert(!ALDS || NBOUT == 1, "LDS fragments: one-block layers only");
@@ -488,16 +501,16 @@ __device__ __forceinline__ void fwd_layer(f32x16 (&acc)[NBOUT], const float* R, 
     load_afrag<NBOUT>(A0, p);
   load_z<PAIR>(Z, ZP, Rcol, 0, half);
   load_oq<TL, G2D>(ZO, ZQ, svl + 5 * hsz, hsz, 0);
-  lazy_act<HACT>(Z, ZP, ZO, ZQ, ap, half, H0, D0, E0, F0, G0);
+  lazy_act<HACT, ZSTASH>(Z, ZP, ZO, ZQ, ap, half, H0, D0, E0, F0, G0);
   load_z<PAIR>(Z, ZP, Rcol, 1, half);  // group 1 (n4 >= 4)
   load_oq<TL, G2D>(ZO, ZQ, svl + 5 * hsz, hsz, 1);
 #pragma unroll 1
   for (int s4 = 0; s4 < n4; s4 += 2) {
     const int n2 = (s4 + 2 < n4) ? (s4 + 2) : s4;
     const int n3 = (s4 + 3 < n4) ? (s4 + 3) : s4;
-    fwd_group<NBOUT, TL, HACT, SAVE, ALDS>(acc, A0, A1, p + (size_t)(s4 + 1) * gstride, Z, ZP, ZO, ZQ, Rcol, n2, s4, ap,
+    fwd_group<NBOUT, TL, HACT, SAVE, ALDS, ZSTASH>(acc, A0, A1, p + (size_t)(s4 + 1) * gstride, Z, ZP, ZO, ZQ, Rcol, n2, s4, ap,
                                            half, svl, hsz, rs, voff, H0, D0, E0, F0, G0, H1, D1, E1, F1, G1);
-    fwd_group<NBOUT, TL, HACT, SAVE, ALDS>(acc, A1, A0, p + (size_t)n2 * gstride, Z, ZP, ZO, ZQ, Rcol, n3, s4 + 1, ap,
+    fwd_group<NBOUT, TL, HACT, SAVE, ALDS, ZSTASH>(acc, A1, A0, p + (size_t)n2 * gstride, Z, ZP, ZO, ZQ, Rcol, n3, s4 + 1, ap,
                                            half, svl, hsz, rs, voff, H1, D1, E1, F1, G1, H0, D0, E0, F0, G0);
   }
 }

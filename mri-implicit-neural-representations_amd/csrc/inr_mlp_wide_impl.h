@@ -19,10 +19,11 @@ namespace inr {
 // every complex feature, and the four Jacobian entries of the Gabor wavelet are formed here from them -- the same
 // expressions, in the same order, that round 1 evaluated in the forward epilogue and stashed (six stores per feature
 // instead of four: the epilogues run at the CU's share of the HBM write rate).
-template <int TL, int RH, bool PAIR, bool JAC = false>
+// JAC == 2 (WIRE2D, second Linear of a layer): dB argument = the stashed orth rows (u, v); d y / d o = -2 s0^2 o y.
+template <int TL, int RH, bool PAIR, int JAC = 0>
 __device__ __forceinline__ void rows_times(float* R, const float* __restrict__ dA, const float* __restrict__ dB, int r0,
                                            int wcol, int lane, float omega = 0.f, float s0 = 0.f) {
-  static_assert(!JAC || PAIR, "the Jacobian form is the complex one");
+  static_assert(JAC == 0 || PAIR, "the Jacobian forms are the complex ones");
   const float s2 = s0 * s0;
   const int half = lane >> 5, col = lane & 31;
   // The Jacobian entries come from the stash (HBM / L2): with four rows in flight per lane the pass ran at one memory
@@ -53,12 +54,18 @@ __device__ __forceinline__ void rows_times(float* R, const float* __restrict__ d
 #pragma unroll
     for (int i = 0; i < BT; ++i) {
       const int r = r0 + (b + i) * STEP + (PAIR ? 2 * half : half);
-      if (JAC) {
+      if (JAC == 1) {
         const float p = R[swz(r, col)], q = R[swz(r + 1, col)];
         const float yr = a0[i], yi = a1[i], za = b0[i], zb = b1[i];
         const float ka = -2.f * s2 * za, kb = -omega - 2.f * s2 * zb;
         R[swz(r, col)] = fmaf(p, fmaf(ka, yr, -omega * yi), q * fmaf(ka, yi, omega * yr));
         R[swz(r + 1, col)] = fmaf(p, kb * yr, q * (kb * yi));
+      } else if (JAC == 2) {
+        const float p = R[swz(r, col)], q = R[swz(r + 1, col)];
+        const float yr = a0[i], yi = a1[i];
+        const float ku = -2.f * s2 * b0[i], kv = -2.f * s2 * b1[i];
+        R[swz(r, col)] = fmaf(p, ku * yr, q * (ku * yi));
+        R[swz(r + 1, col)] = fmaf(p, kv * yr, q * (kv * yi));
       } else if (PAIR) {
         const float p = R[swz(r, col)], q = R[swz(r + 1, col)];
         R[swz(r, col)] = fmaf(p, a0[i], q * b0[i]);
@@ -73,7 +80,7 @@ __device__ __forceinline__ void rows_times(float* R, const float* __restrict__ d
 
 // First layer of the eager WIRE path: dZ_0 = J_0 dH_0 formed while the dX accumulators are stored to the image (own rows),
 // J_0 from the stashed (y_0, z_0) as in rows_times<.., JAC>.  Registers (2p, 2p+1) of a lane are the (Re, Im) rows of a pair.
-template <int NBM, int TL>
+template <int NBM, int TL, bool ORTH = false>
 __device__ __forceinline__ void acc_times_jac_to_lds(const f32x16 (&acc)[NBM], float* R, const float* __restrict__ sv_y,
                                                      const float* __restrict__ sv_z, float omega, float s0, int wcol,
                                                      int lane) {
@@ -103,10 +110,16 @@ __device__ __forceinline__ void acc_times_jac_to_lds(const f32x16 (&acc)[NBM], f
         const int m = m0 + mm;
         const float p = acc[m][r], q = acc[m][r + 1];
         const float yr = y[mm][r], yi = y[mm][r + 1], za = z[mm][r], zb = z[mm][r + 1];
-        const float ka = -2.f * s2 * za, kb = -omega - 2.f * s2 * zb;
         const int row = 32 * m + (r & 3) + 8 * (r >> 2);
-        Rl[row * INR_LDS_LD] = fmaf(p, fmaf(ka, yr, -omega * yi), q * fmaf(ka, yi, omega * yr));
-        Rl[(row + 1) * INR_LDS_LD] = fmaf(p, kb * yr, q * (kb * yi));
+        if (ORTH) {  // sv_z = the orth rows (u, v): d y / d o = -2 s0^2 o y
+          const float ku = -2.f * s2 * za, kv = -2.f * s2 * zb;
+          Rl[row * INR_LDS_LD] = fmaf(p, ku * yr, q * (ku * yi));
+          Rl[(row + 1) * INR_LDS_LD] = fmaf(p, kv * yr, q * (kv * yi));
+        } else {
+          const float ka = -2.f * s2 * za, kb = -omega - 2.f * s2 * zb;
+          Rl[row * INR_LDS_LD] = fmaf(p, fmaf(ka, yr, -omega * yi), q * fmaf(ka, yi, omega * yr));
+          Rl[(row + 1) * INR_LDS_LD] = fmaf(p, kb * yr, q * (kb * yi));
+        }
       }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -267,9 +280,9 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
         if (EAGER)  // plain GEMM on the activations in the image
           bwd_dx<MT, TL, false, false, NB>(acc, R, a.packed + Ll.pf_off + aoff, NB * 32, nullptr, wcol, lane);
         else if (stash)
-          fwd_layer<NB, MT, TL, HACT, true, NB>(acc, R, a.packed + Ll.pf_off + aoff, ap, sh, wcol, lane);
+          fwd_layer<NB, MT, TL, HACT, true, NB, false, G2D>(acc, R, a.packed + Ll.pf_off + aoff, ap, sh, wcol, lane);
         else
-          fwd_layer<NB, MT, TL, HACT, false, NB>(acc, R, a.packed + Ll.pf_off + aoff, ap, G2D ? sh : nullptr, wcol, lane);  // WIRE2D reads orth terms from sh
+          fwd_layer<NB, MT, TL, HACT, false, NB, false, G2D>(acc, R, a.packed + Ll.pf_off + aoff, ap, G2D ? sh : nullptr, wcol, lane);  // WIRE2D reads orth terms from sh
         INR_STAMP(si); ++si;
         __syncthreads();  // both waves of the pair have read z_{l-1}; h_{l-1} is in the stash
         if (EAGER) {
@@ -300,9 +313,9 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
         if (EAGER)
           bwd_dx<1, TL, false, false>(accL, R, a.packed + LL.pf_off, NB * 32, nullptr, wcol, lane);
         else if (saving)
-          fwd_layer<NB, 1, TL, HACT, true>(accL, R, a.packed + LL.pf_off, ap, sh, wcol, lane);
+          fwd_layer<NB, 1, TL, HACT, true, 1, false, G2D>(accL, R, a.packed + LL.pf_off, ap, sh, wcol, lane);
         else
-          fwd_layer<NB, 1, TL, HACT, false>(accL, R, a.packed + LL.pf_off, ap, nullptr, wcol, lane);
+          fwd_layer<NB, 1, TL, HACT, false, 1, false, G2D>(accL, R, a.packed + LL.pf_off, ap, nullptr, wcol, lane);
         float zl[4], y[4];
         const bool ctanh = nd.last_act == ACT_CTANH;
 #pragma unroll
@@ -367,7 +380,7 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
       bwd_dx<MT, TL, false, false, NB>(gacc, R, a.packed + LL.pb_off + aoff, LL.Mpad8, nullptr, wcol, lane);
       INR_STAMP(si); ++si;
       __syncthreads();  // all reads of dZ_last are done
-      if (D == 2 && EAGER)
+      if (D == 2 && (EAGER || G2D))
         acc_times_jac_to_lds<MT, TL>(gacc, Rown, sv + (size_t)m0 * 32 * TL, sv + (size_t)1 * HSZ + (size_t)m0 * 32 * TL,
                                      nd.L[0].omega, nd.L[0].s0, wcol, lane);  // dZ_0 (own rows)
       else if (D == 2)
@@ -380,8 +393,8 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
         INR_STAMP(si); ++si;
         __syncthreads();  // dH_l complete
         if (G2D) rows_copy<TL, RH, true>(R, sv_g, RH * hh, wcol, lane);  // needed again for the orth Linear
-        if (EAGER)  // own rows: dZ_l = J_l dH_l with J_l from the stashed (y_l, z_l)
-          rows_times<TL, RH, true, true>(R, sv + (size_t)(NS * l) * HSZ, sv + (size_t)(NS * l + 1) * HSZ, RH * hh, wcol, lane,
+        if (EAGER || G2D)  // own rows: dZ_l = J_l dH_l with J_l from the stashed (y_l, z_l)
+          rows_times<TL, RH, true, 1>(R, sv + (size_t)(NS * l) * HSZ, sv + (size_t)(NS * l + 1) * HSZ, RH * hh, wcol, lane,
                                          Ll.omega, Ll.s0);
         else  // own rows: dZ_l = dH_l * act'
           rows_times<TL, RH, PAIR>(R, sv + (size_t)(NS * l + 1) * HSZ, sv + (size_t)(NS * l + 2) * HSZ, RH * hh, wcol, lane);
@@ -398,13 +411,14 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
         if (G2D) {  // second Linear of the layer: dZ_orth = J_orth dH_l, dH_{l-1} += V_l^T dZ_orth, dV_l
           const LayerDesc& Ol = nd.L[nd.orth0 + l];
           rows_copy<TL, RH, false>(R, sv_g, RH * hh, wcol, lane);
-          rows_times<TL, RH, true>(R, sv + (size_t)(NS * l + 3) * HSZ, sv + (size_t)(NS * l + 4) * HSZ, RH * hh, wcol, lane);
+          rows_times<TL, RH, true, 2>(R, sv + (size_t)(NS * l) * HSZ, sv + (size_t)(NS * l + 5) * HSZ, RH * hh, wcol, lane,
+                                      Ll.omega, Ll.s0);  // dZ_orth = J_orth dH_l from the stashed (y_l, orth_l)
           __syncthreads();
           bwd_dx<MT, TL, false, false, NB>(gacc, R, a.packed + Ol.pb_off + aoff, Ol.Mpad8, nullptr, wcol, lane);
           rows_copy<TL, RH, true>(R, sv + (size_t)(NS * l + 3) * HSZ, RH * hh, wcol, lane);  // dZ_orth (own rows)
           __syncthreads();
         }
-        if (l == 1 && EAGER)
+        if (l == 1 && (EAGER || G2D))
           acc_times_jac_to_lds<MT, TL>(gacc, Rown, sv + (size_t)m0 * 32 * TL, sv + (size_t)1 * HSZ + (size_t)m0 * 32 * TL,
                                        nd.L[0].omega, nd.L[0].s0, wcol, lane);
         else if (l == 1)
@@ -430,8 +444,8 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
           if (G2D) {  // dV_0 from dZ_0,orth = J_orth,0 dH_0 (the accumulators still hold dH_0)
             const LayerDesc& O0 = nd.L[nd.orth0];
             __syncthreads();
-            acc_times_d_to_lds<MT, TL, true>(gacc, Rown, sv + (size_t)3 * HSZ + (size_t)m0 * 32 * TL,
-                                             sv + (size_t)4 * HSZ + (size_t)m0 * 32 * TL, wcol, lane);
+            acc_times_jac_to_lds<MT, TL, true>(gacc, Rown, sv + (size_t)m0 * 32 * TL, sv + (size_t)5 * HSZ + (size_t)m0 * 32 * TL,
+                                               nd.L[0].omega, nd.L[0].s0, wcol, lane);  // J_orth,0 from (y_0, orth_0)
             __syncthreads();
             for (int it = w; it < 2 * O0.Kblk; it += NW) {
               const int n = it >> 1, c = it & 1;

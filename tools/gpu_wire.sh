@@ -10,4 +10,4 @@ import json,sys
 d=json.load(open('gpurun_out/'+sys.argv[1]+'_bench_models.json'))
 for k,v in d.items(): print('%-42s %8.3f ms  frac %.3f'%(k, v['ms_per_step'], v['frac_f32_mfma']))
 PY
-timeout -k 10 120 python tools/stamps.py 25000 wire 2>&1 | grep -v amdgpu.ids
+timeout -k 10 120 python tools/stamps.py 25000 ${STAMP_MODE:-wire} 2>&1 | grep -v amdgpu.ids
