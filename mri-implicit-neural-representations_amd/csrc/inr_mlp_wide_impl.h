@@ -168,6 +168,58 @@ __device__ __forceinline__ void wire_epilogue(const f32x16 (&acc)[MT], const flo
   }
 }
 
+// WIRE2D, eager activation (wire2d.py:49-60): the owner of a row block holds the rows (a, b) of the layer's Linear in `acc`
+// and the rows (u, v) of its second Linear (scale_orth) in `acc2` -- same registers, same lane -- so
+//   y = exp(j omega lin) * exp(-s0^2 (|lin|^2 + |orth|^2))
+// is formed once per complex feature (the lazy form evaluated it in both lane halves of both waves of the pair, inside
+// the GEMM loop, and needed a second GEMM that read h back from the stash).  Writes y into the image rows and y, z, orth to
+// the stash (slots 0, 1, 5 of the layer); backward rebuilds both Jacobians from those (rows_times<.., 1 / 2>).
+template <int MT, int TL>
+__device__ __forceinline__ void wire2d_epilogue(const f32x16 (&acc)[MT], const f32x16 (&acc2)[MT],
+                                                const float* __restrict__ bias, const float* __restrict__ bias2,
+                                                float* Rown, float* __restrict__ sv_h, float* __restrict__ sv_z,
+                                                float* __restrict__ sv_o, bool save, float omega, float s0, int wcol,
+                                                int lane) {
+  const int half = lane >> 5, col = lane & 31;
+  float* Rl = Rown + (4 * half) * INR_LDS_LD + col;
+  const int voff = ((4 * half) * TL + wcol) * 4;
+  const __amdgpu_buffer_rsrc_t rh = uniform_rsrc(save ? sv_h : (const float*)bias, MT * 32 * TL * 4);
+  const __amdgpu_buffer_rsrc_t rz = uniform_rsrc(save ? sv_z : (const float*)bias, MT * 32 * TL * 4);
+  const __amdgpu_buffer_rsrc_t ro = uniform_rsrc(save ? sv_o : (const float*)bias, MT * 32 * TL * 4);
+  const float* bl = bias + 4 * half;
+  const float* bl2 = bias2 + 4 * half;
+  const float s2 = s0 * s0;
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(bl + 32 * m + 8 * g);
+      const f32x4 c4 = *reinterpret_cast<const f32x4*>(bl2 + 32 * m + 8 * g);
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int row = 32 * m + 8 * g + 2 * p;  // Re row (+ 4*half folded into Rl / voff); Im row = row + 1
+        const float za = acc[m][4 * g + 2 * p] + b4[2 * p], zb = acc[m][4 * g + 2 * p + 1] + b4[2 * p + 1];
+        const float u = acc2[m][4 * g + 2 * p] + c4[2 * p], v = acc2[m][4 * g + 2 * p + 1] + c4[2 * p + 1];
+        float sn, cs;
+        sincos_cw(omega * za, sn, cs);
+        const float Ef = expf(-omega * zb);                                    // |exp(1j*omega*lin)|
+        const float G = expf(-s2 * ((za * za + zb * zb) + (u * u + v * v)));   // gauss_term (association of act_gabor2d)
+        const float yr = (Ef * cs) * G, yi = (Ef * sn) * G;
+        Rl[row * INR_LDS_LD] = yr;
+        Rl[(row + 1) * INR_LDS_LD] = yi;
+        if (save) {
+          stash_store(rh, voff, row * TL * 4, yr);
+          stash_store(rh, voff, (row + 1) * TL * 4, yi);
+          stash_store(rz, voff, row * TL * 4, za);
+          stash_store(rz, voff, (row + 1) * TL * 4, zb);
+          stash_store(ro, voff, row * TL * 4, u);
+          stash_store(ro, voff, (row + 1) * TL * 4, v);
+        }
+      }
+    }
+  }
+}
+
 // own rows of the image <-> global scratch [rows][TL] (WIRE2D: a layer's output gradient is needed twice)
 template <int TL, int RH, bool TO_GLOBAL>
 __device__ __forceinline__ void rows_copy(float* R, float* __restrict__ G, int r0, int wcol, int lane) {
@@ -188,7 +240,7 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr bool G2D = HACT == ACT_GABOR2D;  // WIRE2D: second Linear (scale_orth) per layer, L[orth0 + l]
   constexpr bool PAIR = HACT == ACT_GABOR || G2D;
-  constexpr bool EAGER = HACT == ACT_GABOR;  // WIRE: the image holds activations y, formed by the row owners
+  constexpr bool EAGER = PAIR;  // WIRE / WIRE2D: the image holds activations y, formed once by the row owners
   constexpr int MT = NB / 2, NG = 2, NW = 4, NS = G2D ? 7 : (PAIR ? 3 : 2);
   constexpr int RH = MT * 32;  // image rows per wave of a pair
   constexpr int TL = NG * 32;
@@ -253,19 +305,21 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
                                L0.Kpad8, lane);
         }
         INR_STAMP(si); ++si;
-        if (EAGER)
+        if (G2D) {  // orth_0 = V_0 x + c_0 in a second set of accumulators, then the wavelet of both
+          const LayerDesc& O0 = nd.L[nd.orth0];
+          f32x16 acc2[MT];
+#pragma unroll
+          for (int m = 0; m < MT; ++m) acc2[m] = zero16();
+          fwd_layer0_x<MT, NB>(acc2, a.packed + O0.pf_off + aoff, a.x + (size_t)(valid ? crow : 0) * O0.K, valid, O0.K,
+                               O0.Kpad8, lane);
+          wire2d_epilogue<MT, TL>(acc, acc2, a.packed + L0.pbias_off + m0 * 32, a.packed + O0.pbias_off + m0 * 32, Rown,
+                                  sv + (size_t)m0 * 32 * TL, sv + (size_t)1 * HSZ + (size_t)m0 * 32 * TL,
+                                  sv + (size_t)5 * HSZ + (size_t)m0 * 32 * TL, saving, L0.omega, L0.s0, wcol, lane);
+        } else if (EAGER) {
           wire_epilogue<MT, TL>(acc, a.packed + L0.pbias_off + m0 * 32, Rown, sv + (size_t)m0 * 32 * TL,
                                 sv + (size_t)1 * HSZ + (size_t)m0 * 32 * TL, saving, L0.omega, L0.s0, wcol, lane);
-        else
+        } else {
           acc_to_lds<MT, true>(acc, Rown, a.packed + L0.pbias_off + m0 * 32, lane);
-        if (G2D) {  // orth_0 = V_0 x + c_0 (own rows) -> stash slots 5, 6 of layer 0
-          const LayerDesc& O0 = nd.L[nd.orth0];
-#pragma unroll
-          for (int m = 0; m < MT; ++m) acc[m] = zero16();
-          fwd_layer0_x<MT, NB>(acc, a.packed + O0.pf_off + aoff, a.x + (size_t)(valid ? crow : 0) * O0.K, valid, O0.K,
-                               O0.Kpad8, lane);
-          orth_epilogue<MT, TL, NB>(acc, a.packed + O0.pbias_off + m0 * 32, sv + (size_t)5 * HSZ + (size_t)m0 * 32 * TL,
-                                    wcol, lane);
         }
       }
       INR_STAMP(si); ++si;
@@ -277,31 +331,34 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
 #pragma unroll
         for (int m = 0; m < MT; ++m) acc[m] = zero16();
         float* sh = sv + (size_t)(NS * (l - 1)) * HSZ;
+        f32x16 acc2[G2D ? MT : 1];
         if (EAGER)  // plain GEMM on the activations in the image
           bwd_dx<MT, TL, false, false, NB>(acc, R, a.packed + Ll.pf_off + aoff, NB * 32, nullptr, wcol, lane);
         else if (stash)
-          fwd_layer<NB, MT, TL, HACT, true, NB, false, G2D>(acc, R, a.packed + Ll.pf_off + aoff, ap, sh, wcol, lane);
+          fwd_layer<NB, MT, TL, HACT, true, NB>(acc, R, a.packed + Ll.pf_off + aoff, ap, sh, wcol, lane);
         else
-          fwd_layer<NB, MT, TL, HACT, false, NB, false, G2D>(acc, R, a.packed + Ll.pf_off + aoff, ap, G2D ? sh : nullptr, wcol, lane);  // WIRE2D reads orth terms from sh
+          fwd_layer<NB, MT, TL, HACT, false, NB>(acc, R, a.packed + Ll.pf_off + aoff, ap, nullptr, wcol, lane);
+        if constexpr (G2D) {  // orth_l = V_l y_{l-1} + c_l: a second plain GEMM on the same image, second accumulators
+#pragma unroll
+          for (int m = 0; m < MT; ++m) acc2[m] = zero16();
+          bwd_dx<MT, TL, false, false, NB>(acc2, R, a.packed + nd.L[nd.orth0 + l].pf_off + aoff, NB * 32, nullptr, wcol, lane);
+        }
         INR_STAMP(si); ++si;
-        __syncthreads();  // both waves of the pair have read z_{l-1}; h_{l-1} is in the stash
-        if (EAGER) {
+        __syncthreads();  // both waves of the pair have read the image (z_{l-1}, or y_{l-1} in the eager kernels)
+        if constexpr (G2D) {
+          const LayerDesc& Ol = nd.L[nd.orth0 + l];
+          float* so = sv + (size_t)(NS * l) * HSZ + (size_t)m0 * 32 * TL;
+          wire2d_epilogue<MT, TL>(acc, acc2, a.packed + Ll.pbias_off + m0 * 32, a.packed + Ol.pbias_off + m0 * 32, Rown, so,
+                                  so + HSZ, so + 5 * (size_t)HSZ, saving, Ll.omega, Ll.s0, wcol, lane);
+        } else if (EAGER) {
           float* so = sv + (size_t)(NS * l) * HSZ + (size_t)m0 * 32 * TL;
           wire_epilogue<MT, TL>(acc, a.packed + Ll.pbias_off + m0 * 32, Rown, so, so + HSZ, saving, Ll.omega, Ll.s0, wcol,
                                 lane);
         } else {
           acc_to_lds<MT, true>(acc, Rown, a.packed + Ll.pbias_off + m0 * 32, lane);
         }
-        if (G2D) {  // orth_l = V_l h_{l-1} + c_l (own rows) with h_{l-1} back from the stash -> slots 5, 6 of layer l
-          const LayerDesc& Ol = nd.L[nd.orth0 + l];
-#pragma unroll
-          for (int m = 0; m < MT; ++m) acc[m] = zero16();
-          gemm_stash_nat<MT, TL, NB, NB>(acc, a.packed + Ol.pf_off + aoff, sh, wcol, lane);
-          orth_epilogue<MT, TL, NB>(acc, a.packed + Ol.pbias_off + m0 * 32,
-                                    sv + (size_t)(NS * l + 5) * HSZ + (size_t)m0 * 32 * TL, wcol, lane);
-        }
         INR_STAMP(si); ++si;
-        __syncthreads();  // z_l (and orth_l) complete
+        __syncthreads();  // the layer's image rows are complete
       }
       float g4[4] = {0.f, 0.f, 0.f, 0.f}, dy[4] = {0.f, 0.f, 0.f, 0.f};
       int nrows_last = nd.out_f;
@@ -313,9 +370,9 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
         if (EAGER)
           bwd_dx<1, TL, false, false>(accL, R, a.packed + LL.pf_off, NB * 32, nullptr, wcol, lane);
         else if (saving)
-          fwd_layer<NB, 1, TL, HACT, true, 1, false, G2D>(accL, R, a.packed + LL.pf_off, ap, sh, wcol, lane);
+          fwd_layer<NB, 1, TL, HACT, true>(accL, R, a.packed + LL.pf_off, ap, sh, wcol, lane);
         else
-          fwd_layer<NB, 1, TL, HACT, false, 1, false, G2D>(accL, R, a.packed + LL.pf_off, ap, nullptr, wcol, lane);
+          fwd_layer<NB, 1, TL, HACT, false>(accL, R, a.packed + LL.pf_off, ap, nullptr, wcol, lane);
         float zl[4], y[4];
         const bool ctanh = nd.last_act == ACT_CTANH;
 #pragma unroll
