@@ -1,5 +1,5 @@
 """Diagnostic: per-phase cycle shares of a fused kernel (needs `make -C csrc dbg`).
-Run on the GPU box:  python tools/stamps.py [B] [f32|bf16|mfn|wire|wire2d]
+Run on the GPU box:  python tools/stamps.py [B] [f32|bf16|mfn|wire|wire2d|siren512]
 
 The stamp buffer holds 64 slots per WAVE of the launch: every fused kernel runs 4 waves per workgroup whatever
 its tile (128-coordinate tiles: one wave per 32 coordinates; 64-coordinate tiles: two waves per coordinate
@@ -37,6 +37,13 @@ if PREC == "mfn":  # BASELINE config 4: MultiscaleKFourier 8x512, LSL + consiste
 
     def step():
         eng.train_step(coords, enc.B.contiguous(), gt, spec, dist=dist, scale=0.5, cons=cons)
+elif PREC == "siren512":  # the reference's shipped config_siren_kspace.yaml: SIREN depth 8 / width 512, gauss-512
+    net = dict(network_input_size=512, network_output_size=2, network_depth=8, network_width=512, last_tanh=True)
+    model = M.SIREN(net).to(dev)
+    eng = model.fused_engine(256)
+
+    def step():
+        eng.train_step(coords, enc.B.contiguous(), gt, M.LossSpec(L.LOSS_L2_HALF))
 elif PREC == "wire2d":  # the reference's shipped config_wire2d_kspace.yaml: WIRE2D depth 3 / width 256 (256 complex), L2
     net = dict(network_input_size=3, network_output_size=2, network_depth=3, network_width=256, first_omega_0=30,
                hidden_omega_0=30, scale=15)
@@ -82,8 +89,8 @@ if PREC == "mfn":
     names[50] = "stage 0 g_u -> stash"
     order.append(50)
     last = 50
-elif PREC in ("wire", "wire2d"):  # inr_mlp_wide_kernel: stamps 0, 1, 2, ... in program order
-    NH = 4 if PREC == "wire" else 3  # hidden complex layers (network_depth)
+elif PREC in ("wire", "wire2d", "siren512"):  # inr_mlp_wide_kernel: stamps 0, 1, 2, ... in program order
+    NH = {"wire": 4, "wire2d": 3, "siren512": 6}[PREC]  # hidden layers behind the first
     labels = ["start", "L0 GEMM", "L0 epilogue"]
     for l in range(1, NH + 1):
         labels += [f"sync + L{l} GEMM", f"sync + L{l} epilogue"]
