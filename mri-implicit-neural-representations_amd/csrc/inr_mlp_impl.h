@@ -777,16 +777,36 @@ __device__ INR_DW_ATTR void dw_pass_impl(const float* Rall, int region_stride, B
   const float* Rl = Rall + li * INR_LDS_LD + 4 * half;
   // software pipeline over groups q of 8 coordinates: operands of group q+1 are fetched while
   // group q is multiplied; coordinate 8q + 4*half + e lives in wave image q>>2, column 8(q&3)+4*half+e
-  f32x4 B0 = bsrc.finish(bsrc.fetch(n, 0, lane)), B1;
-  f32x4 A0[MT], A1[MT];
-  load_dw_a<MT>(A0, Rl);
+  if (MT == 1 && TL == 64) {
+    // one row block on the 64-coordinate tiles (last layer / heads of the two-waves-per-group kernels): 4 MFMAs per group
+    // cannot cover a stash load fetched one group ahead -- all eight B operands are requested first
+    typename BSrc::Raw raws[TL / 8];
+#pragma unroll
+    for (int q = 0; q < TL / 8; ++q) raws[q] = bsrc.fetch(n, q, lane);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < TL / 8; ++q) {
+      f32x4 A[MT];
+      load_dw_a<MT>(A, Rl + (q >> 2) * region_stride + 8 * (q & 3));
+      const f32x4 B = bsrc.finish(raws[q]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (BIAS) bsum[0] += A[0][e];
+        acc[0] = mfma32(A[0][e], B[e], acc[0]);
+      }
+    }
+  } else {
+    f32x4 B0 = bsrc.finish(bsrc.fetch(n, 0, lane)), B1;
+    f32x4 A0[MT], A1[MT];
+    load_dw_a<MT>(A0, Rl);
 #pragma unroll 1
-  for (int q = 0; q < TL / 8; q += 2) {
-    const int q2 = (q + 2 < TL / 8) ? q + 2 : q;
-    dw_group<MT, BIAS, BSrc>(acc, bsum, A0, A1, B0, B1, bsrc, n, q + 1,
-                             Rl + ((q + 1) >> 2) * region_stride + 8 * ((q + 1) & 3), lane);
-    dw_group<MT, BIAS, BSrc>(acc, bsum, A1, A0, B1, B0, bsrc, n, q2, Rl + (q2 >> 2) * region_stride + 8 * (q2 & 3),
-                             lane);
+    for (int q = 0; q < TL / 8; q += 2) {
+      const int q2 = (q + 2 < TL / 8) ? q + 2 : q;
+      dw_group<MT, BIAS, BSrc>(acc, bsum, A0, A1, B0, B1, bsrc, n, q + 1,
+                               Rl + ((q + 1) >> 2) * region_stride + 8 * ((q + 1) & 3), lane);
+      dw_group<MT, BIAS, BSrc>(acc, bsum, A1, A0, B1, B0, bsrc, n, q2, Rl + (q2 >> 2) * region_stride + 8 * (q2 & 3),
+                               lane);
+    }
   }
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
