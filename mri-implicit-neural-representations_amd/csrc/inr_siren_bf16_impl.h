@@ -130,6 +130,31 @@ __device__ __forceinline__ bf16x8 w2_frag(const char* ring, int q, int s_l, int 
   return *reinterpret_cast<const bf16x8*>(ring + (q & (W2_SLOTS - 1)) * W2_CHUNK_BYTES + ((s_l * 8 + mo) * 64 + lane) * 16);
 }
 
+// ---- vector loads the compiler does not see (see the backward epilogue) ------------------------------------------
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4 w2_rsrc_words(const void* p, int bytes) {  // the descriptor uniform_rsrc() builds, as SGPR words
+  const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+  u32x4 r;
+  r[0] = __builtin_amdgcn_readfirstlane((unsigned)a);
+  r[1] = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  r[2] = (unsigned)bytes;
+  r[3] = 0x00020000u;
+  return r;
+}
+__device__ __forceinline__ unsigned w2_load_asm(const u32x4& rsrc, int voff, int soff) {
+  unsigned v;
+  asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(v) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+  return v;
+}
+// at most N vector-memory operations outstanding; the eight registers are operands so that no use moves above the wait
+template <int N>
+__device__ __forceinline__ void w2_wait_rows(unsigned (&z)[8]) {
+  asm volatile("s_waitcnt vmcnt(%8)"
+               : "+v"(z[0]), "+v"(z[1]), "+v"(z[2]), "+v"(z[3]), "+v"(z[4]), "+v"(z[5]), "+v"(z[6]), "+v"(z[7])
+               : "n"(N)
+               : "memory");
+}
+
 // one chunk = four K = 16 steps against B fragments b[0..3], 8 row blocks (the partner wave hides the LDS latency)
 // REQUEST: chunk q is not the first of its phase -- the slot chunk q - 1 left takes chunk q + 3, behind the first K-step
 template <bool REQUEST>
@@ -345,22 +370,28 @@ __global__ __launch_bounds__(512, 2) void inr_siren_bf16_kernel(const NetDesc nd
     INR_STAMP(si); ++si;
     for (int l = D - 2; l >= 0; --l) {
       // dZ_l = dH_l * w0 cos(w0 z_l): z_l back from the stash (row pairs), dZ_l to the stash and into hB
-      const __amdgpu_buffer_rsrc_t rz = uniform_rsrc(sv + (size_t)l * (HSZ2 / 2), ts_bytes);
       const __amdgpu_buffer_rsrc_t rg = uniform_rsrc(sv + (size_t)(D - 1 + l) * (HSZ2 / 2), ts_bytes);
       // the layer's 64 row pairs of this coordinate, all in flight before the first use (the B operands of the GEMM
       // that just ended are dead, the next ones not yet formed: the registers are there)
+      // The loads are INLINE ASSEMBLY with hand-placed waits (w2_wait_rows): gfx9 has one counter for vector loads and
+      // stores, hipcc's wait insertion treats loads and stores pending together as able to return out of order and
+      // answers every such wait with vmcnt(0) -- here that drained all 64 loads AND the weight DMAs in flight in front
+      // of the first row block (the backward epilogues took 14-18 k cycles against 5 k forward; without the dZ stores,
+      // i.e. with only loads pending, the same code ran at forward speed).  The counter retires in order: behind the
+      // last load of row block m lie the 8 (7 - m) later loads and the 8 m stores of the blocks already done = 56.
       unsigned zall[NB][8];
+      const u32x4 rz4 = w2_rsrc_words(sv + (size_t)l * (HSZ2 / 2), ts_bytes);
 #pragma unroll
       for (int m = 0; m < NB; ++m)
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
           const int so = (16 * m + 4 * gq) * TL * 4;
-          zall[m][2 * gq] = __builtin_amdgcn_raw_buffer_load_b32(rz, voff, so, 0);
-          zall[m][2 * gq + 1] = __builtin_amdgcn_raw_buffer_load_b32(rz, voff, so + TL * 4, 0);
+          zall[m][2 * gq] = w2_load_asm(rz4, voff, so);
+          zall[m][2 * gq + 1] = w2_load_asm(rz4, voff, so + TL * 4);
         }
-      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int m = 0; m < NB; ++m) {
+        w2_wait_rows<56>(zall[m]);
         const unsigned (&zz)[8] = zall[m];
         float dz[16];
 #pragma unroll
@@ -386,6 +417,7 @@ __global__ __launch_bounds__(512, 2) void inr_siren_bf16_kernel(const NetDesc nd
         }
         hB[2 * m] = pack8(lo);  // (hB is free: the forward pass is over)
         hB[2 * m + 1] = pack8(hi);
+        __builtin_amdgcn_sched_barrier(0);  // row block by row block, so that each waits for its own eight loads only
       }
       INR_STAMP(si); ++si;
       if (l == 0) break;
