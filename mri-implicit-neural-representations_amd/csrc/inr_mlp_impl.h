@@ -171,15 +171,28 @@ __device__ __forceinline__ void acc_to_lds(const f32x16 (&acc)[NBM], float* R, c
   const int half = lane >> 5, col = lane & 31;
   float* Rl = R + (4 * half) * INR_LDS_LD + col;
   const float* bl = bias + 4 * half;
+  // The bias float4s of MB row blocks are requested TOGETHER, then used: written as "load, add, store" per group the
+  // compiler kept that order and put s_waitcnt vmcnt(0) behind every one of the 4 NBM loads -- 32 serialized L2 round
+  // trips per layer (each also draining the stash stores in flight), a third of the forward layers' overhead.
+  constexpr int MB = NBM % 4 == 0 ? 4 : (NBM % 2 == 0 ? 2 : 1);
 #pragma unroll
-  for (int m = 0; m < NBM; ++m) {
+  for (int m0 = 0; m0 < NBM; m0 += MB) {
+    f32x4 b4[MB][4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-      if (BIAS) b4 = *reinterpret_cast<const f32x4*>(bl + 32 * m + 8 * g);
+    for (int mm = 0; mm < MB; ++mm)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) Rl[(32 * m + 8 * g + j) * INR_LDS_LD] = acc[m][4 * g + j] + b4[j];
-    }
+      for (int g = 0; g < 4; ++g) {
+        b4[mm][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (BIAS) b4[mm][g] = *reinterpret_cast<const f32x4*>(bl + 32 * (m0 + mm) + 8 * g);
+      }
+    if (BIAS) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mm = 0; mm < MB; ++mm)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          Rl[(32 * (m0 + mm) + 8 * g + j) * INR_LDS_LD] = acc[m0 + mm][4 * g + j] + b4[mm][g][j];
   }
 }
 
