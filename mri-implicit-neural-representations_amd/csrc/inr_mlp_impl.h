@@ -777,13 +777,20 @@ __device__ INR_DW_ATTR void dw_pass_impl(const float* Rall, int region_stride, B
     bsum[m] = 0.f;
     acc[m] = zero16();
     if (!first) {  // continue this block's running sum (second and later tiles of a persistent block)
+      float v[16];  // (all 16 loads first: "load, select" per element became a vmcnt(0) behind every load)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int rowu = 32 * m + (r & 3) + 8 * (r >> 2);  // uniform part of the row
         const bool ok = colok && (FULLM || rowu + 4 * half < M);
         const float* rowp = slab_w + (size_t)(FULLM ? rowu : 0) * K;
-        const float v = rowp[ok ? (FULLM ? lane_off : rowu * K + lane_off) : 0];
-        acc[m][r] = ok ? v : 0.f;
+        v[r] = rowp[ok ? (FULLM ? lane_off : rowu * K + lane_off) : 0];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rowu = 32 * m + (r & 3) + 8 * (r >> 2);
+        const bool ok = colok && (FULLM || rowu + 4 * half < M);
+        acc[m][r] = ok ? v[r] : 0.f;
       }
     }
   }
@@ -932,6 +939,22 @@ __global__ __launch_bounds__(NW * 64) void inr_mlp_kernel(const NetDesc nd, cons
     float* sv_enc = sv_last + 4 * TL;                   // [Kblk0*32][TL] encoder features (gauss mode)
     float* sv_g = sv_last + 4 * TL;                     // WIRE2D (never gauss): copy of a layer's output gradient
 
+    // what the loss section needs from memory, requested now: fetched where it is used, the sampling mask, the target row
+    // and the four last-layer biases were up to seven serialized round trips between the last GEMM and the loss
+    float gt_pre[4] = {0.f, 0.f, 0.f, 0.f}, lb_pre[4] = {0.f, 0.f, 0.f, 0.f};
+    bool sampled_pre = false;
+    if (MODE != MODE_BWD) {
+      const int nrows_b = nd.last_act == ACT_CTANH ? 2 * nd.out_f : nd.out_f;
+#pragma unroll
+      for (int o = 0; o < 4; ++o)
+        if (o < nrows_b) lb_pre[o] = a.packed[LL.pbias_off + o];
+      if (MODE == MODE_FUSED && half == 0 && valid) {
+        sampled_pre = a.mask == nullptr || a.mask[crow] != 0;
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+          if (o < nd.out_f) gt_pre[o] = a.gt[crow * nd.out_f + o];
+      }
+    }
     // ================================ forward =================================
     INR_STAMP(0);
     if (MODE != MODE_BWD) {
@@ -1013,7 +1036,7 @@ __global__ __launch_bounds__(NW * 64) void inr_mlp_kernel(const NetDesc nd, cons
 #pragma unroll
       for (int o = 0; o < 4; ++o) {
         zl[o] = accL[0][o];
-        if (o < nrows_in) zl[o] += a.packed[LL.pbias_off + o];
+        if (o < nrows_in) zl[o] += lb_pre[o];
         g[o] = 0.f;
       }
       const int nrows = last_layer_act(nd.last_act, nd.out_f, nd.w0, zl, y, dy);  // dy[r]: per image row
@@ -1027,11 +1050,7 @@ __global__ __launch_bounds__(NW * 64) void inr_mlp_kernel(const NetDesc nd, cons
         }
       } else {
         // fused: pointwise loss of this row (both outputs of a row sit in one half-0 lane)
-        if (half == 0 && valid && (a.mask == nullptr || a.mask[crow] != 0)) {
-          float t[4] = {0.f, 0.f, 0.f, 0.f};
-          for (int o = 0; o < nd.out_f; ++o) t[o] = a.gt[crow * nd.out_f + o];
-          loss_acc += loss_row(ld, nd.out_f, y, t, g);
-        }
+        if (sampled_pre) loss_acc += loss_row(ld, nd.out_f, y, gt_pre, g);
         // dZ_last = dY * act'(z_last) -> image rows 0..3 (half 0); rows 4..31 are zero
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
