@@ -101,14 +101,22 @@ __device__ __forceinline__ void mfn_epilogue(const f32x16 (&accU)[MT], const f32
   const float* gl = GABOR ? gm + 32 * m0 + 4 * half : nullptr;
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
+    // the row block's constants first (fetched where they are used, every float4 load got a vmcnt(0) behind it: a
+    // serialized L2 round trip that also drained the stash stores in flight -- 32 of them per stage)
+    f32x4 c4s[4], ga4s[4], m24s[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const f32x4 c4 = *reinterpret_cast<const f32x4*>(bl + 32 * m + 8 * g);
-      f32x4 ga4 = {0.f, 0.f, 0.f, 0.f}, m24 = {0.f, 0.f, 0.f, 0.f};
+      c4s[g] = *reinterpret_cast<const f32x4*>(bl + 32 * m + 8 * g);
+      ga4s[g] = m24s[g] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (GABOR) {
-        ga4 = *reinterpret_cast<const f32x4*>(gl + 32 * m + 8 * g);
-        m24 = *reinterpret_cast<const f32x4*>(gl + NB * 32 + 32 * m + 8 * g);
+        ga4s[g] = *reinterpret_cast<const f32x4*>(gl + 32 * m + 8 * g);
+        m24s[g] = *reinterpret_cast<const f32x4*>(gl + NB * 32 + 32 * m + 8 * g);
       }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 c4 = c4s[g], ga4 = ga4s[g], m24 = m24s[g];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int row = 32 * m + 8 * g + j;  // + 32*m0 + 4*half folded into Rl / svl

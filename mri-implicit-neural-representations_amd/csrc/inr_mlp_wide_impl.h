@@ -142,11 +142,19 @@ __device__ __forceinline__ void wire_epilogue(const f32x16 (&acc)[MT], const flo
   const __amdgpu_buffer_rsrc_t rz = uniform_rsrc(save ? sv_z : (const float*)bias, MT * 32 * TL * 4);
   const float* bl = bias + 4 * half;
   const float s2 = s0 * s0;
+  // (the bias float4s of all row blocks first: fetched where they are used, every one of the 4 MT loads got a
+  // vmcnt(0) behind it -- a serialized L2 round trip that also drained the stash stores in flight)
+  f32x4 bias4[MT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bias4[m][g] = *reinterpret_cast<const f32x4*>(bl + 32 * m + 8 * g);
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const f32x4 b4 = *reinterpret_cast<const f32x4*>(bl + 32 * m + 8 * g);
+      const f32x4 b4 = bias4[m][g];
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
         const int row = 32 * m + 8 * g + 2 * p;  // Re row (+ 4*half folded into Rl / so); Im row = row + 1
@@ -191,10 +199,17 @@ __device__ __forceinline__ void wire2d_epilogue(const f32x16 (&acc)[MT], const f
   const float s2 = s0 * s0;
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
+    f32x4 bias4[4], bias24[4];  // (both bias sets of the row block first, see wire_epilogue)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const f32x4 b4 = *reinterpret_cast<const f32x4*>(bl + 32 * m + 8 * g);
-      const f32x4 c4 = *reinterpret_cast<const f32x4*>(bl2 + 32 * m + 8 * g);
+      bias4[g] = *reinterpret_cast<const f32x4*>(bl + 32 * m + 8 * g);
+      bias24[g] = *reinterpret_cast<const f32x4*>(bl2 + 32 * m + 8 * g);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 b4 = bias4[g];
+      const f32x4 c4 = bias24[g];
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
         const int row = 32 * m + 8 * g + 2 * p;  // Re row (+ 4*half folded into Rl / voff); Im row = row + 1
