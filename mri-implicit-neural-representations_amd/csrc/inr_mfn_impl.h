@@ -22,13 +22,20 @@ namespace inr {
 // U += F . X^T with X^T rows read from the encoder-feature stash [2E rows][TL] (gauss k order:
 // k-step s -> half 0: row s, half 1: row E+s), prefetched one group of 4 k-steps ahead.
 // ---------------------------------------------------------------------------------------------
+// Both operands come through buffer descriptors (wave-uniform base, per-lane byte offset formed once, group offset in an
+// SGPR): with per-lane 64-bit pointers the loop carried two VGPR pairs that the 512-row build spilled -- a scratch
+// reload with s_waitcnt vmcnt(0) at the head of every iteration, draining the prefetch it had just issued.
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 template <int NB, int TL>
 __device__ __forceinline__ void stash_group(f32x16 (&acc)[NB], const f32x4 (&a_use)[NB], f32x4 (&a_load)[NB],
-                                            const f32x4* p_next, const float (&b_use)[4], float (&b_load)[4],
-                                            const float* svl_next) {
-  load_afrag<NB>(a_load, p_next);
+                                            __amdgpu_buffer_rsrc_t rw, int voff_a, int soff_a, const float (&b_use)[4],
+                                            float (&b_load)[4], __amdgpu_buffer_rsrc_t rx, int voff_b, int soff_b) {
 #pragma unroll
-  for (int e = 0; e < 4; ++e) b_load[e] = svl_next[e * TL];
+  for (int m = 0; m < NB; ++m)
+    a_load[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, voff_a, soff_a + m * 1024, 0));
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    b_load[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, voff_b, soff_b + e * TL * 4, 0));
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -42,19 +49,23 @@ template <int NB, int TL, int NBT = NB>
 __device__ __forceinline__ void gemm_enc_stash(f32x16 (&acc)[NB], const float* __restrict__ wp,
                                                const float* __restrict__ sv_enc, int E, int wcol, int lane) {
   const int half = lane >> 5;
-  const float* svl = sv_enc + (half ? E : 0) * TL + wcol;
-  const f32x4* p = reinterpret_cast<const f32x4*>(wp) + lane;
   const int n4 = E >> 2;  // even
+  const __amdgpu_buffer_rsrc_t rw = uniform_rsrc(wp, n4 * NBT * 1024);  // groups of NBT fragments of 1 KB
+  const __amdgpu_buffer_rsrc_t rx = uniform_rsrc(sv_enc, 2 * E * TL * 4);
+  const int voff_a = lane * 16;
+  const int voff_b = ((half ? E : 0) * TL + wcol) * 4;
   f32x4 A0[NB], A1[NB];
   float B0[4], B1[4];
-  load_afrag<NB>(A0, p);
 #pragma unroll
-  for (int e = 0; e < 4; ++e) B0[e] = svl[e * TL];
+  for (int m = 0; m < NB; ++m)
+    A0[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, voff_a, m * 1024, 0));
+#pragma unroll
+  for (int e = 0; e < 4; ++e) B0[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, voff_b, e * TL * 4, 0));
 #pragma unroll 1
   for (int s4 = 0; s4 < n4; s4 += 2) {
     const int n2 = (s4 + 2 < n4) ? (s4 + 2) : s4;
-    stash_group<NB, TL>(acc, A0, A1, p + (size_t)(s4 + 1) * NBT * 64, B0, B1, svl + 4 * (s4 + 1) * TL);
-    stash_group<NB, TL>(acc, A1, A0, p + (size_t)n2 * NBT * 64, B1, B0, svl + 4 * n2 * TL);
+    stash_group<NB, TL>(acc, A0, A1, rw, voff_a, (s4 + 1) * NBT * 1024, B0, B1, rx, voff_b, 4 * (s4 + 1) * TL * 4);
+    stash_group<NB, TL>(acc, A1, A0, rw, voff_a, n2 * NBT * 1024, B1, B0, rx, voff_b, 4 * n2 * TL * 4);
   }
 }
 

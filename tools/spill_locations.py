@@ -6,9 +6,12 @@ Prints, per matching kernel, a histogram {length of the innermost enclosing loop
 import re,sys,subprocess,os
 obj=sys.argv[1]; pat=sys.argv[2]
 LL="/opt/rocm/lib/llvm/bin"
-subprocess.run([f"{LL}/llvm-objdump","--offloading",obj],cwd="/tmp",capture_output=True)
-dev=[f for f in os.listdir("/tmp") if f.startswith(os.path.basename(obj)+".") and "gfx950" in f][0]
-txt=subprocess.run([f"{LL}/llvm-objdump","-d","/tmp/"+dev],capture_output=True,text=True).stdout.split("\n")
+tmp="/tmp/_spl"; os.makedirs(tmp,exist_ok=True)
+for f in os.listdir(tmp): os.remove(os.path.join(tmp,f))
+subprocess.run(["cp",obj,tmp+"/x.o"],check=True)
+subprocess.run([f"{LL}/llvm-objdump","--offloading","x.o"],cwd=tmp,capture_output=True)
+dev=[f for f in os.listdir(tmp) if f.startswith("x.o.") and "gfx950" in f][0]
+txt=subprocess.run([f"{LL}/llvm-objdump","-d",tmp+"/"+dev],capture_output=True,text=True).stdout.split("\n")
 # split into functions
 funcs={}; cur=None
 for l in txt:
