@@ -223,16 +223,21 @@ __global__ __launch_bounds__(512, 2) void inr_siren_bf16_kernel(const NetDesc nd
     const int ts_bytes = tile_ok ? HSZ2 * 2 : 0;  // extent of a stashed tensor: 0 makes every buffer access a no-op
     // per-lane byte offset inside a stashed tensor: pair (2 half) of block 0 group 0, own coordinate
     const int voff = (2 * half * TL + wcol) * 4;
-    float x0 = 0.f, x1 = 0.f, x2 = 0.f, gtv[4] = {0.f, 0.f, 0.f, 0.f};
-    bool sampled = false;
-    if (valid) {
-      x0 = a.x[3 * crow + 0];
-      x1 = a.x[3 * crow + 1];
-      x2 = a.x[3 * crow + 2];
-      if (half == 0) {
-        sampled = a.mask == nullptr || a.mask[crow] != 0;
-        for (int o = 0; o < nd.out_f; ++o) gtv[o] = a.gt[crow * nd.out_f + o];
-      }
+    // coordinates, sampling mask and target row in ONE batch of loads (from row 0 where the lane has no coordinate): nested
+    // under `if (valid) ... if (mask[crow])` they were three serialized round trips at the start of every tile
+    float x0, x1, x2, gtv[4] = {0.f, 0.f, 0.f, 0.f};
+    bool sampled;
+    {
+      const long long cr = valid ? crow : 0;
+      x0 = a.x[3 * cr + 0];
+      x1 = a.x[3 * cr + 1];
+      x2 = a.x[3 * cr + 2];
+      const unsigned char mk = a.mask != nullptr ? a.mask[cr] : (unsigned char)1;
+#pragma unroll
+      for (int o = 0; o < 4; ++o)
+        if (o < nd.out_f) gtv[o] = a.gt[cr * nd.out_f + o];
+      if (!valid) x0 = x1 = x2 = 0.f;
+      sampled = valid && half == 0 && mk != 0;
     }
     const float quarter = half ? 0.25f : 0.f;
     bf16x8 hB[16];  // B operands of the next GEMM: K-step t = 2 m + s  <-  registers 8s .. 8s+7 of accumulator block m
