@@ -696,7 +696,8 @@ struct BSrcStash {  // h_{l-1} stash [feature][TL]
   };
   __device__ __forceinline__ Raw fetch(int n, int q, int lane) const {
     const int j = 32 * n + (lane & 31);
-    return Raw{*reinterpret_cast<const f32x4*>(h + j * TL + 8 * q + 4 * (lane >> 5))};
+    typedef const __attribute__((address_space(1))) f32x4* gptr;  // (global, not generic: see BSrcX::fetch)
+    return Raw{*(gptr)(h + j * TL + 8 * q + 4 * (lane >> 5))};
   }
   __device__ __forceinline__ f32x4 finish(const Raw& r) const { return r.v; }
 };
@@ -707,20 +708,30 @@ struct BSrcX {  // x [B,K0] row-major
   int K0;
   struct Raw {
     f32x4 v;
+    unsigned ok;  // bit e: element e is inside the matrix
   };
+  // (the selects happen in finish(), a group later: "load, select" per element put a vmcnt(0) behind every load)
   __device__ __forceinline__ Raw fetch(int n, int q, int lane) const {
     const int j = 32 * n + (lane & 31);
     Raw r;
+    r.ok = 0;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const long long row = row0 + 8 * q + 4 * (lane >> 5) + e;
       const bool ok = j < K0 && row < B;
-      const float v = x[ok ? row * K0 + j : 0];
-      r.v[e] = ok ? v : 0.f;
+      // (global address space spelled out: through the struct reference of the non-inlined pass the pointer is generic,
+      // and a flat load counts on both vmcnt and lgkmcnt -- every wait behind one is a full drain)
+      r.v[e] = ((const __attribute__((address_space(1))) float*)x)[ok ? row * K0 + j : 0];
+      r.ok |= ok ? (1u << e) : 0u;
     }
     return r;
   }
-  __device__ __forceinline__ f32x4 finish(const Raw& r) const { return r.v; }
+  __device__ __forceinline__ f32x4 finish(const Raw& r) const {
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (r.ok >> e) & 1u ? r.v[e] : 0.f;
+    return o;
+  }
 };
 
 // the 4 k-steps of one row block: A[coord 8q+4h+e][feature 32m+li], e = 0..3 (contiguous in the image row)
@@ -729,7 +740,8 @@ __device__ __forceinline__ void load_dw_a(f32x4 (&a)[MT], const float* Rq) {
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     if ((INR_LDS_LD & 3) == 0) {
-      a[m] = *reinterpret_cast<const f32x4*>(Rq + 32 * m * INR_LDS_LD);  // ds_read_b128
+      // (LDS address space spelled out: inside the non-inlined passes Rq is a generic pointer and this would be a flat load)
+      a[m] = *(const __attribute__((address_space(3))) f32x4*)(Rq + 32 * m * INR_LDS_LD);  // ds_read_b128
     } else {
 #pragma unroll
       for (int e = 0; e < 4; ++e) a[m][e] = Rq[32 * m * INR_LDS_LD + e];
@@ -764,8 +776,13 @@ __device__ __forceinline__ void dw_group(f32x16 (&acc)[MT], float (&bsum)[MT], c
 #define INR_DW_ATTR __forceinline__
 #endif
 template <int MT, int TL, bool FULLM, bool BIAS, class BSrc>
-__device__ INR_DW_ATTR void dw_pass_impl(const float* Rall, int region_stride, BSrc& bsrc, int n, float* slab_w,
-                                             float* slab_b, int M, int K, bool first, int lane) {
+__device__ INR_DW_ATTR void dw_pass_impl(const float* Rall, int region_stride, BSrc& bsrc, int n, float* slab_w_generic,
+                                             float* slab_b_generic, int M, int K, bool first, int lane) {
+  // (compiled as a real function in the WIRE / filter-network units, the pass sees its pointer arguments as GENERIC:
+  // flat loads and stores, which count on vmcnt and lgkmcnt both and make every wait a full drain.  The slabs are global.)
+  typedef __attribute__((address_space(1))) float gfloat;
+  gfloat* slab_w = (gfloat*)slab_w_generic;
+  gfloat* slab_b = (gfloat*)slab_b_generic;
   const int half = lane >> 5, li = lane & 31;
   f32x16 acc[MT];
   float bsum[MT];
@@ -782,7 +799,7 @@ __device__ INR_DW_ATTR void dw_pass_impl(const float* Rall, int region_stride, B
       for (int r = 0; r < 16; ++r) {
         const int rowu = 32 * m + (r & 3) + 8 * (r >> 2);  // uniform part of the row
         const bool ok = colok && (FULLM || rowu + 4 * half < M);
-        const float* rowp = slab_w + (size_t)(FULLM ? rowu : 0) * K;
+        const gfloat* rowp = slab_w + (size_t)(FULLM ? rowu : 0) * K;
         v[r] = rowp[ok ? (FULLM ? lane_off : rowu * K + lane_off) : 0];
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -834,7 +851,7 @@ __device__ INR_DW_ATTR void dw_pass_impl(const float* Rall, int region_stride, B
       if (colok) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          float* rowp = slab_w + (size_t)(32 * m + (r & 3) + 8 * (r >> 2)) * K;
+          gfloat* rowp = slab_w + (size_t)(32 * m + (r & 3) + 8 * (r >> 2)) * K;
           rowp[lane_off] = acc[m][r];
         }
       }
