@@ -144,6 +144,15 @@ __device__ __forceinline__ void load_afrag(f32x4 (&a)[NBM], const f32x4* __restr
   for (int m = 0; m < NBM; ++m) a[m] = p[m * 64];
 }
 
+// A-fragment stream through a buffer descriptor: wave-uniform base, the lane's byte offset, the group offset in an SGPR --
+// `p + n` (n in float4s, as with the plain pointer it replaces) only moves the scalar offset, so the loops carry no
+// per-lane 64-bit address and spend no vector ALU on it.
+struct AFragPtr {
+  __amdgpu_buffer_rsrc_t rs;
+  int voff, soff;
+  __device__ __forceinline__ AFragPtr operator+(size_t n) const { return AFragPtr{rs, voff, soff + (int)n * 16}; }
+};
+
 // Buffer descriptor from a wave-uniform pointer (readfirstlane makes the uniformity provable, so
 // hipcc emits plain buffer_load ... offen with an SGPR descriptor instead of waterfall loops or --
 // worse -- 128 hoisted 64-bit VGPR addresses that it then spills around the tile loop).
@@ -194,6 +203,16 @@ __device__ __forceinline__ void acc_to_lds(const f32x16 (&acc)[NBM], float* R, c
         for (int j = 0; j < 4; ++j)
           Rl[(32 * (m0 + mm) + 8 * g + j) * INR_LDS_LD] = acc[m0 + mm][4 * g + j] + b4[mm][g][j];
   }
+}
+
+__device__ __forceinline__ AFragPtr afrag_ptr(const float* wp, int lane) {  // wp: wave-uniform start of a packed image
+  return AFragPtr{uniform_rsrc(wp, 0x7ffffff0), lane * 16, 0};
+}
+template <int NBM>
+__device__ __forceinline__ void load_afrag(f32x4 (&a)[NBM], const AFragPtr& p) {
+#pragma unroll
+  for (int m = 0; m < NBM; ++m)
+    a[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(p.rs, p.voff, p.soff + m * 1024, 0));
 }
 
 // First layer: dZ_0 = dH_0 * act'(z_0) is formed while the dX accumulators are stored to the image
@@ -299,7 +318,7 @@ __device__ __forceinline__ float gauss_feature(const float* encB_lds, int s, flo
 
 template <int NB, int TL, bool SAVE>
 __device__ __forceinline__ void gauss_group(f32x16 (&acc)[NB], const f32x4 (&a_use)[NB], f32x4 (&a_load)[NB],
-                                            const f32x4* p_next, const float* encB_lds, int s4_next, float xs0,
+                                            const AFragPtr& p_next, const float* encB_lds, int s4_next, float xs0,
                                             float xs1, float xs2, int half, const float (&b_use)[4],
                                             float (&b_load)[4], __amdgpu_buffer_rsrc_t rs, int voff, int s4) {
   load_afrag<NB>(a_load, p_next);
@@ -325,7 +344,7 @@ __device__ __forceinline__ void fwd_layer0_gauss(f32x16 (&acc)[NB], const float*
   const int half = lane >> 5;
   const __amdgpu_buffer_rsrc_t rs = uniform_rsrc(SAVE ? sv_enc : wp, 2 * E * TL * 4);
   const int voff = ((half ? E : 0) * TL + wcol) * 4;
-  const f32x4* p = reinterpret_cast<const f32x4*>(wp) + lane;
+  const AFragPtr p = afrag_ptr(wp, lane);
   const int n4 = E >> 2;  // even (E % 8 == 0)
   f32x4 A0[NB], A1[NB];
   float F0[4], F1[4];
@@ -437,9 +456,9 @@ __device__ __forceinline__ void load_oq(float (&zo)[4], float (&zq)[4], const fl
   }
 }
 
-template <int NBOUT, int TL, int HACT, bool SAVE, bool ALDS = false, bool ZSTASH = false>
+template <int NBOUT, int TL, int HACT, bool SAVE, bool ALDS = false, bool ZSTASH = false, class AP = AFragPtr>
 __device__ __forceinline__ void fwd_group(f32x16 (&acc)[NBOUT], const f32x4 (&a_use)[NBOUT],
-                                          f32x4 (&a_load)[NBOUT], const f32x4* p_next, float (&z_buf)[4],
+                                          f32x4 (&a_load)[NBOUT], const AP& p_next, float (&z_buf)[4],
                                           float (&zp_buf)[4], float (&zo_buf)[4], float (&zq_buf)[4],
                                           const float* Rcol, int s4_next2, int s4,
                                           const ActParams& ap, int half, float* __restrict__ svl, int hsz,
@@ -451,7 +470,7 @@ __device__ __forceinline__ void fwd_group(f32x16 (&acc)[NBOUT], const f32x4 (&a_
   // z_buf holds the pre-activations of group s4+1 (fetched one group ago); they become h_load/d_load
   // during this group's MFMAs, and z_buf is refilled with group s4+2.
   constexpr bool G2D = HACT == ACT_GABOR2D;
-  if (ALDS)
+  if constexpr (ALDS)
     a_load[0] = *p_next;  // one-block last layer: its live rows' fragments sit in LDS (see fwd_layer)
   else
     load_afrag<NBOUT>(a_load, p_next);
@@ -496,7 +515,14 @@ __device__ __forceinline__ void fwd_layer(f32x16 (&acc)[NBOUT], const float* R, 
   static_assert(!ALDS || NBOUT == 1, "LDS fragments: one-block layers only");
   const int half = lane >> 5, col = lane & 31;
   constexpr int n4tot = NB * 4;
-  const f32x4* p = reinterpret_cast<const f32x4*>(wp) + (ALDS ? (col < 4 ? half * 4 + col : n4tot * 8) : lane);
+  // fragment stream: LDS pointer (ALDS: per-lane stride, rows >= 4 read the zero slot) or buffer-descriptor "pointer"
+  auto make_p = [&]() {
+    if constexpr (ALDS)
+      return reinterpret_cast<const f32x4*>(wp) + (col < 4 ? half * 4 + col : n4tot * 8);
+    else
+      return afrag_ptr(wp, lane);
+  };
+  const auto p = make_p();
   const int gstride = ALDS ? (col < 4 ? 8 : 0) : NBT * 64;  // float4s between consecutive groups
   constexpr int n4 = NB * 4;  // K = 32*NB features -> 16*NB k-steps -> 4*NB groups of 4 (even)
   constexpr int hsz = NB * 32 * TL;
@@ -508,7 +534,7 @@ __device__ __forceinline__ void fwd_layer(f32x16 (&acc)[NBOUT], const float* R, 
   const int voff = (half * TL + wcol) * 4;
   f32x4 A0[NBOUT], A1[NBOUT];
   float Z[4], ZP[4], ZO[4], ZQ[4], H0[4], D0[4], E0[4], F0[4], G0[4], H1[4], D1[4], E1[4], F1[4], G1[4];
-  if (ALDS)
+  if constexpr (ALDS)
     A0[0] = *p;
   else
     load_afrag<NBOUT>(A0, p);
@@ -521,9 +547,9 @@ __device__ __forceinline__ void fwd_layer(f32x16 (&acc)[NBOUT], const float* R, 
   for (int s4 = 0; s4 < n4; s4 += 2) {
     const int n2 = (s4 + 2 < n4) ? (s4 + 2) : s4;
     const int n3 = (s4 + 3 < n4) ? (s4 + 3) : s4;
-    fwd_group<NBOUT, TL, HACT, SAVE, ALDS, ZSTASH>(acc, A0, A1, p + (size_t)(s4 + 1) * gstride, Z, ZP, ZO, ZQ, Rcol, n2, s4, ap,
+    fwd_group<NBOUT, TL, HACT, SAVE, ALDS, ZSTASH, decltype(p)>(acc, A0, A1, p + (size_t)(s4 + 1) * gstride, Z, ZP, ZO, ZQ, Rcol, n2, s4, ap,
                                            half, svl, hsz, rs, voff, H0, D0, E0, F0, G0, H1, D1, E1, F1, G1);
-    fwd_group<NBOUT, TL, HACT, SAVE, ALDS, ZSTASH>(acc, A1, A0, p + (size_t)n2 * gstride, Z, ZP, ZO, ZQ, Rcol, n3, s4 + 1, ap,
+    fwd_group<NBOUT, TL, HACT, SAVE, ALDS, ZSTASH, decltype(p)>(acc, A1, A0, p + (size_t)n2 * gstride, Z, ZP, ZO, ZQ, Rcol, n3, s4 + 1, ap,
                                            half, svl, hsz, rs, voff, H1, D1, E1, F1, G1, H0, D0, E0, F0, G0);
   }
 }
@@ -617,7 +643,7 @@ __device__ __forceinline__ void image_copy(float* R, float* __restrict__ G, int 
 // ---------------------------------------------------------------------------------------------
 template <int NB, int TL, bool PAIR, bool HASD>
 __device__ __forceinline__ void dx_group(f32x16 (&acc)[NB], const f32x4 (&a_use)[NB], f32x4 (&a_load)[NB],
-                                         const f32x4* p_next, const float (&g_use)[4], const float (&gp_use)[4],
+                                         const AFragPtr& p_next, const float (&g_use)[4], const float (&gp_use)[4],
                                          float (&g_load)[4], float (&gp_load)[4], const float (&d_use)[4],
                                          const float (&d2_use)[4], float (&d_load)[4], float (&d2_load)[4],
                                          float* Rcol, int s4, int s4_next, const float* dl, int hsz, int half,
@@ -654,7 +680,7 @@ template <int NB, int TL, bool PAIR, bool HASD, int NBT = NB>
 __device__ __forceinline__ void bwd_dx(f32x16 (&acc)[NB], float* R, const float* __restrict__ wpT, int Mpad8,
                                        const float* __restrict__ sv_d, int wcol, int lane) {
   const int half = lane >> 5, col = lane & 31;
-  const f32x4* p = reinterpret_cast<const f32x4*>(wpT) + lane;
+  const AFragPtr p = afrag_ptr(wpT, lane);
   const int n4 = Mpad8 >> 3;
   constexpr int hsz = NB * 32 * TL;
   float* Rcol = R + col;
