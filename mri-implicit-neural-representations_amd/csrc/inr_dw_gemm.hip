@@ -48,11 +48,17 @@ __device__ __forceinline__ void dwg_mma(f32x16 (&acc)[WBM][WB], float (&bsum)[WB
 
 // one K-step (32 coordinates) of a workgroup's operands: 128 WB rows x 128 B, thread t fetches 16-byte segment t & 7
 // of rows (t >> 3) + 32 k -- whole cache lines per 8 lanes
+// (through a buffer descriptor on the tile's wave-uniform base + the K-step: the per-thread part of the address is the
+// 32-bit byte offset roff[k], formed once -- no 64-bit vector adds per load inside the MFMA stream)
 template <int NF>
 __device__ __forceinline__ void dwg_fetch(f32x4 (&v)[NF], const float* __restrict__ sv, const int (&roff)[NF],
                                           int kstep) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(sv + 32 * kstep);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  const __amdgpu_buffer_rsrc_t rs =
+      __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, 0x7ffffff0, 0x00020000);
 #pragma unroll
-  for (int k = 0; k < NF; ++k) v[k] = *reinterpret_cast<const f32x4*>(sv + roff[k] + 32 * kstep);
+  for (int k = 0; k < NF; ++k) v[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, roff[k], 0, 0));
 }
 
 template <int NF>
@@ -90,7 +96,7 @@ __device__ __forceinline__ void dwg_body(const DwGemmArgs& a, const DwGemmItem& 
     const bool isg = r < TR;
     const int blk = isg ? mb0 + (r >> 5) : nb0 + ((r - TR) >> 5);
     const int row = (blk < (isg ? it.Mblk : it.Kblk)) ? blk * 32 + (r & 31) : 0;
-    roff[k] = (isg ? it.g_off : it.h_off) + row * TL + (t & 7) * 4;
+    roff[k] = ((isg ? it.g_off : it.h_off) + row * TL + (t & 7) * 4) * 4;  // bytes
   }
   constexpr int KS = TL / 32;  // K-steps per tile
   // chunk kc = tiles [kc tpc, (kc + 1) tpc)
