@@ -145,22 +145,32 @@ __device__ __forceinline__ void dwgb_body(const DwGemmBf16Args& a, const DwGemmB
 #pragma unroll
   for (int k = 0; k < GB_NI; ++k) bsum[k][0] = bsum[k][1] = 0.f;
 
+  // (through a buffer descriptor on the tile's wave-uniform base: the thread's part of an address is the byte offset of its
+  // (row pair, segment), formed once; tensor and K-step offsets are scalar -- no 64-bit vector adds in the loop)
+  int voffA[GB_NI], voffB[GB_NI];
+#pragma unroll
+  for (int k = 0; k < GB_NI; ++k) {
+    voffA[k] = ((pair0 + 64 * k) * TL + 8 * seg) * 4;
+    voffB[k] = ((it.n0 / 2 + pair0 + 64 * k) * TL + 8 * seg) * 4;
+  }
   auto fetch = [&](int s, u32x4 (&A)[GB_NI][2], u32x4 (&B)[GB_NI][2]) {
     if (s >= n_steps) s = n_steps - 1;  // past the end: the last stage again (loaded, never multiplied)
     const int tile = t0 + s / KS_PER_TILE, c0 = (s % KS_PER_TILE) * GB_KS;
-    const unsigned* base = sv + (size_t)tile * tile_dwords;
+    const unsigned long long ba = reinterpret_cast<unsigned long long>(sv + (size_t)tile * tile_dwords + c0);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)ba), hi = __builtin_amdgcn_readfirstlane((unsigned)(ba >> 32));
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, 0x7ffffff0, 0x00020000);
+    const int soA = it.dz_off * 4, soB = it.z_off * 4;
 #pragma unroll
     for (int k = 0; k < GB_NI; ++k) {
       const int pair = pair0 + 64 * k;
       if (!LASTROWS || pair < 2) {
-        const unsigned* p = base + it.dz_off + (size_t)pair * TL + c0 + 8 * seg;
-        A[k][0] = *reinterpret_cast<const u32x4*>(p);
-        A[k][1] = *reinterpret_cast<const u32x4*>(p + 4);
+        A[k][0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voffA[k], soA, 0));
+        A[k][1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voffA[k], soA + 16, 0));
       }
       if (!ENC) {
-        const unsigned* p = base + it.z_off + (size_t)(it.n0 / 2 + pair) * TL + c0 + 8 * seg;
-        B[k][0] = *reinterpret_cast<const u32x4*>(p);
-        B[k][1] = *reinterpret_cast<const u32x4*>(p + 4);
+        B[k][0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voffB[k], soB, 0));
+        B[k][1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voffB[k], soB + 16, 0));
       }
     }
   };
