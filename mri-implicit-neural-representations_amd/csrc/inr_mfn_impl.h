@@ -107,7 +107,9 @@ __device__ __forceinline__ void mfn_epilogue(const f32x16 (&accU)[MT], const f32
   const int half = lane >> 5, col = lane & 31;
   constexpr int hsz = NB * 32 * TL;
   float* Rl = R + (32 * m0 + 4 * half) * INR_LDS_LD + col;
-  float* svl = sv + (32 * m0 + 4 * half) * TL + wcol;
+  // stash stores through a buffer descriptor (tensor and row offsets scalar): three per element, no 64-bit vector adds
+  const __amdgpu_buffer_rsrc_t rsv = uniform_rsrc(sv, 3 * hsz * 4);
+  const int voff = ((32 * m0 + 4 * half) * TL + wcol) * 4;
   const float* bl = cbias + 32 * m0 + 4 * half;
   const float* gl = GABOR ? gm + 32 * m0 + 4 * half : nullptr;
 #pragma unroll
@@ -146,9 +148,9 @@ __device__ __forceinline__ void mfn_epilogue(const f32x16 (&accU)[MT], const f32
           lc = l * cs;
         }
         Rl[row * INR_LDS_LD] = h;
-        svl[row * TL] = sn;
-        svl[hsz + row * TL] = lc;
-        svl[2 * hsz + row * TL] = h;
+        stash_store(rsv, voff, row * TL * 4, sn);
+        stash_store(rsv, voff, (hsz + row * TL) * 4, lc);
+        stash_store(rsv, voff, (2 * hsz + row * TL) * 4, h);
       }
     }
   }

@@ -646,15 +646,16 @@ __device__ __forceinline__ void dx_group(f32x16 (&acc)[NB], const f32x4 (&a_use)
                                          const AFragPtr& p_next, const float (&g_use)[4], const float (&gp_use)[4],
                                          float (&g_load)[4], float (&gp_load)[4], const float (&d_use)[4],
                                          const float (&d2_use)[4], float (&d_load)[4], float (&d2_load)[4],
-                                         float* Rcol, int s4, int s4_next, const float* dl, int hsz, int half,
-                                         bool prefetch) {
+                                         float* Rcol, int s4, int s4_next, __amdgpu_buffer_rsrc_t rd, int voff_d, int hsz,
+                                         int half, bool prefetch) {
   if (prefetch) {
     load_afrag<NB>(a_load, p_next);
     load_z<HASD && PAIR>(g_load, gp_load, Rcol, s4_next, half);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      d_load[e] = HASD ? dl[(8 * s4_next + 2 * e) * TL] : 1.f;
-      d2_load[e] = (HASD && PAIR) ? dl[hsz + (8 * s4_next + 2 * e) * TL] : 0.f;
+    for (int e = 0; e < 4; ++e) {  // act' entries of the lane's row through the descriptor: row offset in an SGPR
+      const int so = (8 * s4_next + 2 * e) * TL * 4;
+      d_load[e] = HASD ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, voff_d, so, 0)) : 1.f;
+      d2_load[e] = (HASD && PAIR) ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, voff_d, so + hsz * 4, 0)) : 0.f;
     }
   }
   __builtin_amdgcn_sched_barrier(0);
@@ -684,27 +685,29 @@ __device__ __forceinline__ void bwd_dx(f32x16 (&acc)[NB], float* R, const float*
   const int n4 = Mpad8 >> 3;
   constexpr int hsz = NB * 32 * TL;
   float* Rcol = R + col;
-  const float* dl = HASD ? sv_d + half * TL + wcol : nullptr;  // own row's act' entries
+  // own row's act' entries (the two tensors of a PAIR layer are hsz floats apart)
+  const __amdgpu_buffer_rsrc_t rd = uniform_rsrc(HASD ? (const void*)sv_d : (const void*)wpT, 2 * hsz * 4);
+  const int voff_d = (half * TL + wcol) * 4;
   f32x4 A0[NB], A1[NB];
   float G0[4], P0[4], G1[4], P1[4], D0[4], E0[4], D1[4], E1[4];
   load_afrag<NB>(A0, p);
   load_z<HASD && PAIR>(G0, P0, Rcol, 0, half);
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    D0[e] = HASD ? dl[(2 * e) * TL] : 1.f;
-    E0[e] = (HASD && PAIR) ? dl[hsz + (2 * e) * TL] : 0.f;
+    D0[e] = HASD ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, voff_d, (2 * e) * TL * 4, 0)) : 1.f;
+    E0[e] = (HASD && PAIR) ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, voff_d, ((2 * e) * TL + hsz) * 4, 0)) : 0.f;
   }
   if (n4 == 1) {  // last layer: out_features <= 8 -> a single group
-    dx_group<NB, TL, PAIR, HASD>(acc, A0, A1, p, G0, P0, G1, P1, D0, E0, D1, E1, Rcol, 0, 0, dl, hsz, half, false);
+    dx_group<NB, TL, PAIR, HASD>(acc, A0, A1, p, G0, P0, G1, P1, D0, E0, D1, E1, Rcol, 0, 0, rd, voff_d, hsz, half, false);
     return;
   }
 #pragma unroll 1
   for (int s4 = 0; s4 < n4; s4 += 2) {  // n4 even for hidden layers
     const int n2 = (s4 + 2 < n4) ? (s4 + 2) : s4;
     dx_group<NB, TL, PAIR, HASD>(acc, A0, A1, p + (size_t)(s4 + 1) * NBT * 64, G0, P0, G1, P1, D0, E0, D1, E1, Rcol, s4,
-                                 s4 + 1, dl, hsz, half, true);
+                                 s4 + 1, rd, voff_d, hsz, half, true);
     dx_group<NB, TL, PAIR, HASD>(acc, A1, A0, p + (size_t)n2 * NBT * 64, G1, P1, G0, P0, D1, E1, D0, E0, Rcol, s4 + 1,
-                                 n2, dl, hsz, half, true);
+                                 n2, rd, voff_d, hsz, half, true);
   }
 }
 
