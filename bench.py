@@ -114,13 +114,14 @@ def bf16_path(cfg, image, coords, shape, dev, args, fused_kernel_ms_of, main_lin
     Adam).  Reported next to the graded fp32 line, never instead of it: bf16 operands cannot meet the 1e-5 parity
     bar, so this object carries its own PSNR after the same number of steps (north-star: within 0.1 dB)."""
     from inr_mi355x.train import INRTrainer
-    tr = INRTrainer(dict(cfg, precision="bf16"), image, coords, shape, dev, seed=0)
+    tr = INRTrainer(dict(cfg, precision="bf16"), image, coords, shape, dev, seed=0, graph_steps=bool(args.graph))
     spe = tr.steps_per_epoch
 
     def run(n, start):
         for i in range(n):
             tr.step((start + i) // spe, (start + i) % spe)
 
+    tr.prepare_graphs()
     run(args.warmup, 0)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -232,6 +233,9 @@ def main():
     ap.add_argument("--psnr-steps", type=int, default=1000, help="total steps before the PSNR read-out (N=1)")
     ap.add_argument("--no-multiscale", action="store_true", help="skip the config-4 (multi-scale) object")
     ap.add_argument("--ms-steps", type=int, default=10, help="timed steps of the config-4 object")
+    ap.add_argument("--graph", type=int, default=0,
+                    help="N=1: replay each batch's step as one captured HIP graph.  Off by default: measured slower "
+                         "than eager launches on this stack (profiles/r02g_graph_vs_eager.json)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -264,7 +268,8 @@ def main():
     image, coords, shape = make_kspace(*SHAPE, seed=1234, normalization="coil")
     cfg = dict(CONFIG)
     cfg["batch_size"] = args.batch * world  # weak scaling: every rank keeps `--batch` rows per step
-    tr = INRTrainer(cfg, image, coords, shape, dev, seed=0, rank=rank, world=world, process_group=pg)
+    tr = INRTrainer(cfg, image, coords, shape, dev, seed=0, rank=rank, world=world, process_group=pg,
+                    graph_steps=bool(args.graph))
     spe = tr.steps_per_epoch
 
     def run(n, start):
@@ -283,6 +288,7 @@ def main():
     slo, shi = 0, min(tr.bs, tr.n) // world
     for _ in range(30):
         tr.engine.train_step(tr.coords[slo:shi], tr.enc_B, tr.image[slo:shi], tr.loss, count=tr.bs)
+    tr.prepare_graphs()  # no-op unless graph_steps: captures happen here, not inside the timed region
     run(args.warmup, 0)
     barrier()
     t0 = time.perf_counter()
@@ -368,7 +374,8 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "SIREN 5x256 gauss-512 k-space fit, synthetic 640x368x15-coil, L2, Adam",
                    "batch_per_gpu": args.batch, "global_batch": args.batch * world,
-                   "parallelism": f"dp{world}" if world > 1 else "single"},
+                   "parallelism": f"dp{world}" if world > 1 else "single",
+                   "launch": "hip-graph per batch" if tr.graph_steps else "eager"},
         "roofline": {"bound": "mfma", "kernel": "inr_mlp_kernel<8,GAUSS,SIN,FUSED>", "achieved": achieved,
                      "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS,
                      "kernel_ms": k_ms, "flop_per_sample": FLOP_FUSED_F32, "traffic": traffic,

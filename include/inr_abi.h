@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define INR_ABI_VERSION 3
+#define INR_ABI_VERSION 4
 
 /* error codes */
 #define INR_OK 0
@@ -277,6 +277,21 @@ int inr_plan_heads(const inr_plan* plan, int32_t* n_heads);
 int inr_adam_step(const inr_plan* plan, float* params, const float* grads, float* exp_avg,
                   float* exp_avg_sq, float* packed, double lr, double beta1, double beta2, double eps,
                   double weight_decay, double l1, double l2, int32_t step, void* stream);
+
+/* The same update with the step count in DEVICE memory, so that the launch carries no argument that changes from
+ * one step to the next and a whole step (inr_train_step + this) can be captured once in a HIP graph and replayed:
+ * `step_dev` holds the number of steps taken so far (t); the kernel reads (step_size, bc2_sqrt) from
+ * `sched[2*min(t, n_sched-1)]` — device copy of a table made by inr_adam_schedule — and a one-thread kernel behind it
+ * stores t + 1.  Results are bit-identical to inr_adam_step(step = t + 1) while t < n_sched; with beta1 = 0.9,
+ * beta2 = 0.999 both fp32 terms have converged after 16 600 steps, so a table of 32 768 entries is exact for any run
+ * length.  A new learning rate (the per-epoch LambdaLR of train.py:153,251) means a new table, not a new graph. */
+int inr_adam_step_dev(const inr_plan* plan, float* params, const float* grads, float* exp_avg,
+                      float* exp_avg_sq, float* packed, const float* sched, int32_t n_sched,
+                      int32_t* step_dev, double beta1, double beta2, double eps, double weight_decay,
+                      double l1, double l2, void* stream);
+/* Host helper: host_out[2*t] = float(lr / (1 - beta1^(t+1))), host_out[2*t+1] = float(sqrt(1 - beta2^(t+1))),
+ * t = 0..n-1, in the doubles torch.optim.Adam uses (the same code path as inr_adam_step).  No GPU work. */
+int inr_adam_schedule(double lr, double beta1, double beta2, int32_t n, float* host_out);
 
 #ifdef __cplusplus
 }

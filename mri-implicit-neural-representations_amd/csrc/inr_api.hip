@@ -1010,6 +1010,47 @@ int inr_train_step_multi(const inr_plan* plan, const inr_loss_desc* loss, const 
                           "inr_train_step_multi");
 }
 
+// torch computes these in Python doubles and passes them to fp32 kernels as scalars
+static void adam_bias_terms(double lr, double beta1, double beta2, int32_t step, float* step_size, float* bc2_sqrt) {
+  const double bc1 = 1.0 - std::pow(beta1, (double)step);
+  const double bc2 = 1.0 - std::pow(beta2, (double)step);
+  *step_size = (float)(lr / bc1);
+  *bc2_sqrt = (float)std::sqrt(bc2);
+}
+
+int inr_adam_schedule(double lr, double beta1, double beta2, int32_t n, float* host_out) {
+  if (host_out == nullptr || n < 1) return fail(INR_ERR_INVALID, "inr_adam_schedule: null table or n < 1");
+  for (int32_t t = 0; t < n; ++t) adam_bias_terms(lr, beta1, beta2, t + 1, host_out + 2 * t, host_out + 2 * t + 1);
+  return INR_OK;
+}
+
+int inr_adam_step_dev(const inr_plan* plan, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                      float* packed, const float* sched, int32_t n_sched, int32_t* step_dev, double beta1,
+                      double beta2, double eps, double weight_decay, double l1, double l2, void* stream) {
+  if (plan == nullptr || params == nullptr || grads == nullptr || exp_avg == nullptr || exp_avg_sq == nullptr ||
+      packed == nullptr || sched == nullptr || step_dev == nullptr)
+    return fail(INR_ERR_INVALID, "inr_adam_step_dev: null argument");
+  if (n_sched < 1) return fail(INR_ERR_INVALID, "inr_adam_step_dev: empty schedule");
+  inr::AdamArgs aa;
+  aa.do_update = 1;
+  aa.step_size = 0.f;
+  aa.bc2_sqrt = 1.f;
+  aa.sched = sched;
+  aa.step_dev = step_dev;
+  aa.n_sched = n_sched;
+  aa.omb1 = (float)(1.0 - beta1);
+  aa.beta2 = (float)beta2;
+  aa.omb2 = (float)(1.0 - beta2);
+  aa.eps = (float)eps;
+  aa.weight_decay = (float)weight_decay;
+  aa.l1 = (float)l1;
+  aa.l2 = (float)l2;
+  hipError_t e = inr::launch_adam_pack(plan->nd, params, grads, exp_avg, exp_avg_sq, packed, aa, (hipStream_t)stream);
+  if (e == hipSuccess) e = inr::launch_step_advance(step_dev, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "inr_adam_step_dev");
+  return INR_OK;
+}
+
 int inr_adam_step(const inr_plan* plan, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                   float* packed, double lr, double beta1, double beta2, double eps, double weight_decay,
                   double l1, double l2, int32_t step, void* stream) {
@@ -1019,11 +1060,10 @@ int inr_adam_step(const inr_plan* plan, float* params, const float* grads, float
   if (step < 1) return fail(INR_ERR_INVALID, "inr_adam_step: step %d (counts from 1)", step);
   inr::AdamArgs aa;
   aa.do_update = 1;
-  // torch computes these in Python doubles and passes them to fp32 kernels as scalars
-  const double bc1 = 1.0 - std::pow(beta1, (double)step);
-  const double bc2 = 1.0 - std::pow(beta2, (double)step);
-  aa.step_size = (float)(lr / bc1);
-  aa.bc2_sqrt = (float)std::sqrt(bc2);
+  aa.sched = nullptr;
+  aa.step_dev = nullptr;
+  aa.n_sched = 0;
+  adam_bias_terms(lr, beta1, beta2, step, &aa.step_size, &aa.bc2_sqrt);
   aa.omb1 = (float)(1.0 - beta1);
   aa.beta2 = (float)beta2;
   aa.omb2 = (float)(1.0 - beta2);

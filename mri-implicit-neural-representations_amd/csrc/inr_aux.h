@@ -14,6 +14,11 @@ struct AdamArgs {
   float omb1;         // float(1 - beta1): the lerp weight torch passes to exp_avg.lerp_
   float beta2, omb2;  // float(beta2), float(1 - beta2)
   float eps, weight_decay, l1, l2;
+  // graph-replayable form (inr_adam_step_dev): the step is read from device memory and indexes a table of
+  // (step_size, bc2_sqrt) pairs, so that no kernel argument changes from one step to the next
+  const float* sched;   // nullptr: use step_size / bc2_sqrt above
+  const int* step_dev;  // steps taken so far
+  int n_sched;
 };
 
 
@@ -27,6 +32,7 @@ struct SlabSplit {
 hipError_t launch_reduce_slabs(const NetDesc& nd, const float* slabs, int n_blocks, float* grads, float* loss_out,
                                const float* params, const float* packed, hipStream_t st,
                                SlabSplit split = SlabSplit{0, 0, 0, 0});
+hipError_t launch_step_advance(int* step_dev, hipStream_t st);
 hipError_t launch_adam_pack(const NetDesc& nd, float* params, const float* grads, float* m1, float* m2,
                             float* packed, const AdamArgs& aa, hipStream_t st);
 hipError_t launch_encode_logf(const float* coords, const float* bands, long long B, int nb, float* out,

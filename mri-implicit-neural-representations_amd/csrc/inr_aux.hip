@@ -383,11 +383,17 @@ __global__ __launch_bounds__(256) void adam_pack_kernel(const NetDesc nd, float*
     if (aa.weight_decay != 0.f) g = fmaf(aa.weight_decay, p, g);
     if (aa.l1 != 0.f) g += aa.l1 * (p > 0.f ? 1.f : (p < 0.f ? -1.f : 0.f));  // d/dp lambda*sum|p|
     if (aa.l2 != 0.f) g = fmaf(2.f * aa.l2, p, g);                             // d/dp lambda*|sum p^2|
+    float step_size = aa.step_size, bc2_sqrt = aa.bc2_sqrt;
+    if (aa.sched != nullptr) {  // wave-uniform: scalar loads
+      const int t = min(*aa.step_dev, aa.n_sched - 1);
+      step_size = aa.sched[2 * t];
+      bc2_sqrt = aa.sched[2 * t + 1];
+    }
     float m = m1[i], v = m2[i];
     m = m + (g - m) * aa.omb1;                // exp_avg.lerp_(grad, 1 - beta1)
     v = fmaf(g * g, aa.omb2, v * aa.beta2);   // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1 - beta2)
-    const float denom = sqrtf(v) / aa.bc2_sqrt + aa.eps;
-    p = p - aa.step_size * (m / denom);       // param.addcdiv_(exp_avg, denom, value=-step_size)
+    const float denom = sqrtf(v) / bc2_sqrt + aa.eps;
+    p = p - step_size * (m / denom);          // param.addcdiv_(exp_avg, denom, value=-step_size)
     m1[i] = m;
     m2[i] = v;
     params[i] = p;
@@ -424,6 +430,13 @@ __global__ __launch_bounds__(256) void adam_pack_kernel(const NetDesc nd, float*
     if (L.pb_off >= 0) put_tr(L, packed, vp.row[t], vp.col[t], vp.sign[t] * p);
   }
   if (vp.bias_row >= 0) packed[L.pbias_off + vp.bias_row] = p;
+}
+
+__global__ void step_advance_kernel(int* step_dev) { *step_dev += 1; }
+
+hipError_t launch_step_advance(int* step_dev, hipStream_t st) {
+  hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, st, step_dev);
+  return hipGetLastError();
 }
 
 hipError_t launch_adam_pack(const NetDesc& nd, float* params, const float* grads, float* m1, float* m2,

@@ -36,7 +36,7 @@ class LossDesc(C.Structure):
                 ("cons_inv", C.c_float * 4)]
 
 
-ABI_VERSION = 3  # INR_ABI_VERSION of include/inr_abi.h
+ABI_VERSION = 4  # INR_ABI_VERSION of include/inr_abi.h
 
 
 class Workspace(C.Structure):
@@ -79,6 +79,9 @@ SYMBOLS = {
                                        C.POINTER(Workspace), _P, _P, _P]),
     "inr_adam_step": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_double, C.c_double, C.c_double, C.c_double,
                                 C.c_double, C.c_double, C.c_double, C.c_int32, _P]),
+    "inr_adam_step_dev": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int32, _P, C.c_double, C.c_double, C.c_double,
+                                    C.c_double, C.c_double, C.c_double, _P]),
+    "inr_adam_schedule": (C.c_int, [C.c_double, C.c_double, C.c_double, C.c_int32, _P]),
 }
 
 _lib = None

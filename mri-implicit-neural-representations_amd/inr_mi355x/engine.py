@@ -7,8 +7,9 @@ from __future__ import annotations
 
 import ctypes as C
 from dataclasses import dataclass
-from typing import Optional
+from typing import Callable, Optional
 
+import numpy as np
 import torch
 
 from . import _lib as L
@@ -86,6 +87,9 @@ class MLPEngine:
         self.params: Optional[torch.Tensor] = None
         self.grads = self.exp_avg = self.exp_avg_sq = self.packed = None
         self._save = self._slabs = self._loss = None
+        self._ws_generation = 0
+        self._sched = self._sched_key = self._step_dev = None
+        self._step_dev_mirror = 0
         self.step = 0
 
     def __del__(self):
@@ -139,12 +143,14 @@ class MLPEngine:
         need = n_slots * self.save_floats_per_tile
         if self._save is None or self._save.numel() < need:
             self._save = torch.zeros(need, device=self.params.device)
+            self._ws_generation += 1  # captured step graphs hold the old address
         return self._save
 
     def _ws_slabs(self, n_blocks: int) -> torch.Tensor:
         need = n_blocks * self.slab_floats
         if self._slabs is None or self._slabs.numel() < need:
             self._slabs = torch.empty(need, device=self.params.device)
+            self._ws_generation += 1
         return self._slabs
 
     def _ws(self, save_slots: int, n_slabs: int):
@@ -267,6 +273,86 @@ class MLPEngine:
                                        _ptr(self.exp_avg, "exp_avg"), _ptr(self.exp_avg_sq, "exp_avg_sq"),
                                        _ptr(self.packed, "packed"), lr, beta1, beta2, eps, weight_decay, l1, l2,
                                        self.step, self._stream()))
+
+    # ---- the step as a HIP graph ----------------------------------------------------------------
+    N_SCHED = 32768  # both fp32 bias-correction terms have converged long before (include/inr_abi.h)
+
+    def _adam_schedule(self, lr: float, beta1: float, beta2: float) -> torch.Tensor:
+        """Device table of (step_size, bc2_sqrt) per step for this learning rate; rebuilt only when lr changes
+        (the per-epoch LambdaLR, train.py:153,251).  The copy is ordered on the current stream."""
+        key = (float(lr), float(beta1), float(beta2))
+        if self._sched_key != key:
+            host = np.empty(2 * self.N_SCHED, dtype=np.float32)
+            L.check(self.lib.inr_adam_schedule(key[0], key[1], key[2], self.N_SCHED, host.ctypes.data))
+            if self._sched is None:
+                self._sched = torch.empty(2 * self.N_SCHED, device=self.params.device)
+            self._sched.copy_(torch.from_numpy(host))
+            self._sched_key = key
+        return self._sched
+
+    def _sync_step_dev(self) -> torch.Tensor:
+        """The device copy of ``self.step``; refreshed only after eager adam_step calls moved the host count."""
+        if self._step_dev is None:
+            self._step_dev = torch.zeros(1, dtype=torch.int32, device=self.params.device)
+            self._step_dev_mirror = 0
+        if self._step_dev_mirror != self.step:
+            self._step_dev.fill_(self.step)
+            self._step_dev_mirror = self.step
+        return self._step_dev
+
+    def adam_step_dev(self, lr: float, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,
+                      weight_decay: float = 0.0, l1: float = 0.0, l2: float = 0.0) -> None:
+        """adam_step with the step count and the bias corrections read from device memory: the launch has no
+        argument that changes between steps (bit-identical results; tests/test_gpu_parity.py)."""
+        sched = self._adam_schedule(lr, beta1, beta2)
+        sd = self._sync_step_dev()
+        L.check(self.lib.inr_adam_step_dev(self.plan, _ptr(self.params, "params"), _ptr(self.grads, "grads"),
+                                           _ptr(self.exp_avg, "exp_avg"), _ptr(self.exp_avg_sq, "exp_avg_sq"),
+                                           _ptr(self.packed, "packed"), _ptr(sched, "sched"), self.N_SCHED,
+                                           _ptr(sd, "step_dev", torch.int32), beta1, beta2, eps, weight_decay, l1,
+                                           l2, self._stream()))
+        self.step += 1
+        self._step_dev_mirror += 1
+
+    def capture_step(self, gradient_step: Callable[[], object], lr: float, beta1: float = 0.9,
+                     beta2: float = 0.999, eps: float = 1e-8, weight_decay: float = 0.0, l1: float = 0.0,
+                     l2: float = 0.0) -> "StepGraph":
+        """Capture ``gradient_step()`` (a closure over train_step on FIXED input views) + the Adam update as one
+        HIP graph.  ``gradient_step`` runs once eagerly first, so that workspaces exist and nothing is allocated
+        while capturing; it only overwrites the gradient buffer."""
+        gradient_step()
+        self._adam_schedule(lr, beta1, beta2)
+        self._sync_step_dev()
+        graph = torch.cuda.CUDAGraph()
+        step0 = self.step
+        with torch.cuda.graph(graph):
+            gradient_step()
+            self.adam_step_dev(lr, beta1, beta2, eps, weight_decay, l1, l2)
+        self.step = self._step_dev_mirror = step0  # capturing launched nothing
+        return StepGraph(self, graph, (beta1, beta2))
+
+
+class StepGraph:
+    """One captured step (fused kernel, weight-gradient GEMM, slab reduction, Adam + re-pack, step advance)."""
+
+    def __init__(self, engine: MLPEngine, graph: "torch.cuda.CUDAGraph", betas):
+        self.engine, self.graph, self.betas = engine, graph, betas
+        self.generation = engine._ws_generation
+
+    @property
+    def stale(self) -> bool:
+        return self.generation != self.engine._ws_generation
+
+    def replay(self, lr: float) -> torch.Tensor:
+        eng = self.engine
+        if self.stale:
+            raise RuntimeError("the engine's workspaces were re-allocated after this step was captured")
+        eng._adam_schedule(lr, *self.betas)
+        eng._sync_step_dev()
+        self.graph.replay()
+        eng.step += 1
+        eng._step_dev_mirror += 1
+        return eng._loss_word[0]
 
 
 def encode_gauss(coords: torch.Tensor, enc_B: torch.Tensor) -> torch.Tensor:

@@ -112,7 +112,7 @@ def center_pair_rows(kcoords: torch.Tensor, min_sample: int, n_bands: int = 2):
 class INRTrainer:
     def __init__(self, config: dict, image: torch.Tensor, coords: torch.Tensor, shape, device,
                  seed: int = 0, mask: Optional[torch.Tensor] = None, rank: int = 0, world: int = 1,
-                 process_group=None, mask_seed: Optional[int] = None):
+                 process_group=None, mask_seed: Optional[int] = None, graph_steps: bool = False):
         config = set_default_configs(dict(config))
         self.config = config
         self.device = torch.device(device)
@@ -188,6 +188,14 @@ class INRTrainer:
         self.steps_per_epoch = math.ceil(self.n / self.bs)
         self.global_step = 0
         self._hdr_A = {}
+        # graph_steps: every batch of the epoch becomes one captured HIP graph (fused kernel, weight-gradient GEMM,
+        # reduction, Adam, step advance) replayed from then on -- the batches are fixed views of the resident data
+        # (sequential sampler, models/utils.py:126-130), the step count and learning rate live in device memory.
+        # Single rank only (the gradient all-reduce sits between the two halves) and only where a step is ONE
+        # fused launch sequence on resident views.
+        self.graph_steps = bool(graph_steps) and world == 1 and not self.use_tv and \
+            self.loss.kind != L.LOSS_CENTER and (self.enc_B is not None or emb == "none")
+        self._graphs = {}
         if "pretrain" in config:  # train.py:117-121
             self.load_checkpoint(torch.load(config["pretrain"], map_location=self.device))
 
@@ -216,6 +224,8 @@ class INRTrainer:
         else:
             count = hi - lo
         A = self._batch_hdr_A(it, lo, hi)
+        if self.graph_steps:
+            return self._graph_step(epoch, it, lo, hi, count, A)
         if self.use_tv:
             loss = self._tv_step(lo, count, A)
         elif self.loss.kind == L.LOSS_CENTER:
@@ -240,6 +250,42 @@ class INRTrainer:
                               self.l1, self.l2)
         self.global_step += 1
         return loss
+
+    def _graph_step(self, epoch: int, it: int, lo: int, hi: int, count: int, A: float) -> torch.Tensor:
+        cfg = self.config
+        lr = cfg["lr"] * lr_factor(epoch, cfg["max_epoch"])
+        g = self._graphs.get(it)
+        if g is None or g.stale:
+            m = self.mask[lo:hi] if self.mask is not None else None
+            g = self.engine.capture_step(lambda: self._fused(lo, hi, count, m, A), lr, cfg["beta1"], cfg["beta2"], 1e-8,
+                                         cfg["weight_decay"], self.l1, self.l2)
+            self._graphs[it] = g
+        penalty = None  # value of the penalty at the parameters the step starts from, as in step()
+        if self.l1:
+            penalty = self.l1 * self.engine.params.abs().sum()
+        if self.l2:
+            penalty = self.l2 * (self.engine.params * self.engine.params).sum()
+        loss = g.replay(lr)
+        self.global_step += 1
+        return loss if penalty is None else loss + penalty
+
+    def prepare_graphs(self, epoch: int = 0) -> None:
+        """Capture every batch of an epoch up front (largest first), so that no capture falls into a timed region.
+        Runs each batch's gradient launch once; parameters and the step count do not move."""
+        if not self.graph_steps:
+            return
+        cfg = self.config
+        lr = cfg["lr"] * lr_factor(epoch, cfg["max_epoch"])
+        for it in range(self.steps_per_epoch):
+            lo, hi = it * self.bs, min((it + 1) * self.bs, self.n)
+            count = int(self.mask_cpu[lo:hi].sum()) if self.mask_cpu is not None else hi - lo
+            A = self._batch_hdr_A(it, lo, hi)
+            g = self._graphs.get(it)
+            if g is None or g.stale:
+                m = self.mask[lo:hi] if self.mask is not None else None
+                self._graphs[it] = self.engine.capture_step(
+                    lambda lo=lo, hi=hi, count=count, m=m, A=A: self._fused(lo, hi, count, m, A), lr, cfg["beta1"],
+                    cfg["beta2"], 1e-8, cfg["weight_decay"], self.l1, self.l2)
 
     def _fused(self, slo, shi, count, m, A):
         return self.engine.train_step(self._inputs(slo, shi), self.enc_B, self.image[slo:shi], self.loss,

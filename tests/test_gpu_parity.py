@@ -278,6 +278,55 @@ def test_trajectory_golden(dev):
                                        msg=lambda m: f"{tag} {k}: {m}")
 
 
+def test_device_resident_adam_and_graph_steps(dev):
+    """(i) inr_adam_step_dev (step count + bias corrections read from device memory) leaves bit-identical parameters,
+    moments and packed weights to inr_adam_step; (ii) a fit whose steps are replayed HIP graphs (one per batch of
+    the epoch, captured on first use; the per-epoch learning-rate change is a new table, not a new graph; a short last
+    batch; L1 penalty + weight decay inside the Adam kernel) is bit-identical to the same fit launched eagerly."""
+    import inr_mi355x as M
+    from inr_mi355x.synthetic import make_kspace
+    from inr_mi355x.train import INRTrainer
+    net = dict(network_input_size=64, network_output_size=2, network_depth=3, network_width=64)
+    engs = []
+    for _ in range(2):
+        torch.manual_seed(5)
+        engs.append(M.SIREN(net).to(dev)._engine())
+    g = torch.Generator().manual_seed(1)
+    for t in range(1, 8):
+        grad = torch.randn(engs[0].n_params, generator=g).to(dev) * 1e-3
+        for e in engs:
+            e.grads.copy_(grad)
+        lr = 1e-3 if t < 5 else 7e-4
+        engs[0].adam_step(lr, 0.9, 0.999, 1e-8, 1e-4, 1e-6, 0.0)
+        if t == 3:  # an eager step in between moves the host count only: the device copy is refreshed
+            engs[1].adam_step(lr, 0.9, 0.999, 1e-8, 1e-4, 1e-6, 0.0)
+        else:
+            engs[1].adam_step_dev(lr, 0.9, 0.999, 1e-8, 1e-4, 1e-6, 0.0)
+        for name in ("params", "exp_avg", "exp_avg_sq", "packed"):
+            assert torch.equal(getattr(engs[0], name), getattr(engs[1], name)), (t, name)
+    assert int(engs[1]._step_dev) == engs[1].step == 7
+
+    image, kc, shape = make_kspace(2, 16, 12)  # 384 rows: batches of 150, 150, 84
+    enc = dict(embedding="gauss", scale=2, embedding_size=32, coordinates_size=3)
+    for extra in (dict(), dict(loss="HDR", loss_opts=dict(hdr_eps=1e-2, hdr_ff_sigma=1.0, hdr_ff_factor=0.1)),
+                  dict(regularization=dict(type="L1", strenght=1e-6), weight_decay=1e-5)):
+        cfg = dict(model="SIREN", loss="L2", lr=1e-3, batch_size=150, max_epoch=3, weight_decay=0.0, beta1=0.9,
+                   beta2=0.999, net=net, encoder=enc)
+        cfg.update(extra)
+        fits = []
+        for graph in (False, True):
+            tr = INRTrainer(cfg, image, kc, shape, dev, seed=3, graph_steps=graph)
+            assert tr.graph_steps == graph
+            if graph and not extra:
+                tr.prepare_graphs()
+            losses = [s[1] for s in tr.fit(8, log_every=1)]  # 2 2/3 epochs: every graph replayed, two lr changes
+            fits.append((losses, tr.engine.params.clone(), tr.engine.exp_avg_sq.clone()))
+            if graph:
+                assert len(tr._graphs) == 3 and tr.engine.step == 8
+        assert fits[0][0] == fits[1][0], extra
+        assert torch.equal(fits[0][1], fits[1][1]) and torch.equal(fits[0][2], fits[1][2]), extra
+
+
 def test_center_loss_vs_reference_vectors(dev):
     """CenterLoss through inr_loss_grad(INR_LOSS_CENTER) + inr_center_pairs_grad against value and gradient of the
     reference class (tests/golden/center.npz, pairs from torch.randperm under the fixture's seed)."""

@@ -23,7 +23,25 @@ def test_abi_header_symbols_exported():
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.inr_abi_version() == 3
+    assert lib.inr_abi_version() == 4
+
+
+def test_adam_schedule_table():
+    """inr_adam_schedule (host-only): the (step_size, bc2_sqrt) pairs torch.optim.Adam derives in Python doubles
+    (torch/optim/adam.py _single_tensor_adam: step_size = lr / (1 - beta1^t), bias_correction2_sqrt), and both
+    have converged in fp32 well inside the 32 768 entries the device-resident step uses."""
+    from inr_mi355x import _lib
+    lib = _lib.load()
+    n, lr, b1, b2 = 32768, 3e-5, 0.9, 0.999
+    tab = np.empty(2 * n, dtype=np.float32)
+    assert lib.inr_adam_schedule(lr, b1, b2, n, tab.ctypes.data) == 0
+    for t in list(range(1, 300)) + [1000, 5000, 16000, 20000, n]:
+        assert tab[2 * (t - 1)] == np.float32(lr / (1.0 - b1 ** t)), t
+        assert tab[2 * (t - 1) + 1] == np.float32((1.0 - b2 ** t) ** 0.5), t
+    assert tab[2 * 20000] == np.float32(lr) and tab[2 * 20000 + 1] == np.float32(1.0)
+    assert (tab[2 * 20000:].reshape(-1, 2) == tab[-2:]).all()
+    assert lib.inr_adam_schedule(lr, b1, b2, 0, tab.ctypes.data) != 0
+    assert lib.inr_adam_schedule(lr, b1, b2, 4, None) != 0
 
 
 def test_plan_validation_and_sizes():
