@@ -27,6 +27,7 @@ struct MlpArgs {
   long long* dbg;      // diagnostic builds (-DINR_STAMPS) only: per-wave phase time stamps
   long long dbg_cap;   // entries behind dbg (a stamp past it is dropped)
   int ll_lds;          // inr_mlp_kernel: the last layer's live A fragments (rows 0..3) sit in LDS (set by launch_mlp)
+  int dz_lds;    // set by the launcher: dZ_last has its own LDS image (fused step; inr_mlp_impl.h)
 };
 
 

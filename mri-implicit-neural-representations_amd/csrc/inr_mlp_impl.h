@@ -456,7 +456,9 @@ __device__ __forceinline__ void load_oq(float (&zo)[4], float (&zq)[4], const fl
   }
 }
 
-template <int NBOUT, int TL, int HACT, bool SAVE, bool ALDS = false, bool ZSTASH = false, class AP = AFragPtr>
+// SAVE: 0 nothing, 1 h and the activation's derivative terms, 2 the derivative terms only (the fused step's last hidden
+// layer: its h is only ever read by the last layer's dW, which re-activates z from the LDS images -- dw_rows4_valu)
+template <int NBOUT, int TL, int HACT, int SAVE, bool ALDS = false, bool ZSTASH = false, class AP = AFragPtr>
 __device__ __forceinline__ void fwd_group(f32x16 (&acc)[NBOUT], const f32x4 (&a_use)[NBOUT],
                                           f32x4 (&a_load)[NBOUT], const AP& p_next, float (&z_buf)[4],
                                           float (&zp_buf)[4], float (&zo_buf)[4], float (&zq_buf)[4],
@@ -483,7 +485,7 @@ __device__ __forceinline__ void fwd_group(f32x16 (&acc)[NBOUT], const f32x4 (&a_
   for (int e = 0; e < 4; ++e) {
     if (SAVE) {
       const int so = (8 * s4 + 2 * e) * TL * 4;  // bytes; the tensors of a layer are hsz floats apart
-      stash_store(rs, voff, so, h_use[e]);
+      if (SAVE == 1) stash_store(rs, voff, so, h_use[e]);
       stash_store(rs, voff, so + hsz * 4, d_use[e]);
       if ((HACT == ACT_GABOR || G2D) && !ZSTASH) stash_store(rs, voff, so + 2 * hsz * 4, d2_use[e]);
       if (G2D && !ZSTASH) {
@@ -509,7 +511,7 @@ __device__ __forceinline__ void fwd_group(f32x16 (&acc)[NBOUT], const f32x4 (&a_
 // (s4 * 2 + half) * 4 + row, then one float4 of zeros that the lanes of rows 4..31 read.  With the fragments in L2 the
 // loop ran at one L2 + store-acknowledge latency per group: four MFMAs do not cover a load that waits, in the in-order
 // vmcnt, behind the eight stash stores issued before it.
-template <int NB, int NBOUT, int TL, int HACT, bool SAVE, int NBT = NBOUT, bool ALDS = false, bool ZSTASH = false>
+template <int NB, int NBOUT, int TL, int HACT, int SAVE, int NBT = NBOUT, bool ALDS = false, bool ZSTASH = false>
 __device__ __forceinline__ void fwd_layer(f32x16 (&acc)[NBOUT], const float* R, const float* wp,
                                           const ActParams& ap, float* __restrict__ sv, int wcol, int lane) {
   static_assert(!ALDS || NBOUT == 1, "LDS fragments: one-block layers only");
@@ -552,6 +554,72 @@ __device__ __forceinline__ void fwd_layer(f32x16 (&acc)[NBOUT], const float* R, 
     fwd_group<NBOUT, TL, HACT, SAVE, ALDS, ZSTASH, decltype(p)>(acc, A1, A0, p + (size_t)n2 * gstride, Z, ZP, ZO, ZQ, Rcol, n3, s4 + 1, ap,
                                            half, svl, hsz, rs, voff, H1, D1, E1, F1, G1, H0, D0, E0, F0, G0);
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The last layer (<= 4 output rows) of a real-activation network on the VECTOR ALUs.  As an MFMA layer it is one
+// 32-row block of which 2 rows are real: 128 MFMAs (8.2 k cycles on a matrix pipe that shares the FP32 ALUs) for
+// 16 k useful multiply-adds per wave.  Here a lane keeps its coordinate's partial sums over the features of its half
+// (k = 8 s4 + 2e + half, the rows the lazy activation gives it anyway): M FMAs per activated element, weights from
+// the LDS fragment copy `ll` (float4 (s4*2 + half)*4 + row = W[row][8 s4 + 2e + half], e = 0..3: a broadcast read),
+// the two halves added at the end.  out4[o], o < M, is complete in every lane.  SAVE as in fwd_group; HBACK: h is
+// written back over z in the image (the fused step's dW of this layer reads it there, dw_rows4_valu).
+// ---------------------------------------------------------------------------------------------
+template <int NB, int TL, int HACT, int SAVE, bool HBACK, bool WIDE>
+__device__ __forceinline__ void fwd_last_valu_impl(float (&out4)[4], float* R, const float* ll, const ActParams& ap,
+                                                   float* __restrict__ sv, int wcol, int lane) {
+  const int half = lane >> 5, col = lane & 31;
+  constexpr int n4 = NB * 4;
+  constexpr int hsz = NB * 32 * TL;
+  typedef __attribute__((address_space(3))) float lfloat;
+  typedef const __attribute__((address_space(3))) f32x4 lf4;
+  lfloat* Rz = (lfloat*)(R + col + half * INR_LDS_LD);  // row 8 s4 + 2e + half, this lane's column
+  lf4* wq = (lf4*)ll + half * 4;
+  const __amdgpu_buffer_rsrc_t rs = uniform_rsrc(SAVE ? (const void*)sv : (const void*)ll, 2 * hsz * 4);
+  const int voff = (half * TL + wcol) * 4;
+  constexpr bool wide = WIDE;  // rows 2, 3 exist (a branch per group otherwise)
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+  for (int s4 = 0; s4 < n4; ++s4) {
+    float z[4];
+    f32x4 wv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) z[e] = Rz[(8 * s4 + 2 * e) * INR_LDS_LD];
+    wv[0] = wq[s4 * 8 + 0];
+    wv[1] = wq[s4 * 8 + 1];
+    if (wide) {
+      wv[2] = wq[s4 * 8 + 2];
+      wv[3] = wq[s4 * 8 + 3];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float h, d;
+      act_fwd<HACT>(z[e], ap.w0, h, d);
+      if (SAVE) {
+        const int so = (8 * s4 + 2 * e) * TL * 4;
+        if (SAVE == 1) stash_store(rs, voff, so, h);
+        stash_store(rs, voff, so + hsz * 4, d);
+      }
+      if (HBACK) Rz[(8 * s4 + 2 * e) * INR_LDS_LD] = h;
+      acc[0] = fmaf(wv[0][e], h, acc[0]);
+      acc[1] = fmaf(wv[1][e], h, acc[1]);
+      if (wide) {
+        acc[2] = fmaf(wv[2][e], h, acc[2]);
+        acc[3] = fmaf(wv[3][e], h, acc[3]);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < 4; ++o) out4[o] = (o < 2 || WIDE) ? acc[o] + __shfl_xor(acc[o], 32) : 0.f;
+}
+
+template <int NB, int TL, int HACT, int SAVE, bool HBACK>
+__device__ __forceinline__ void fwd_last_valu(float (&out4)[4], float* R, const float* ll, int M, const ActParams& ap,
+                                              float* __restrict__ sv, int wcol, int lane) {
+  if (M > 2)
+    fwd_last_valu_impl<NB, TL, HACT, SAVE, HBACK, true>(out4, R, ll, ap, sv, wcol, lane);
+  else
+    fwd_last_valu_impl<NB, TL, HACT, SAVE, HBACK, false>(out4, R, ll, ap, sv, wcol, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -899,6 +967,166 @@ __device__ INR_DW_ATTR void dw_pass_impl(const float* Rall, int region_stride, B
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// dW / db of a layer with at most 4 output rows (the last layer: 2 rows, 4 for the complex heads) on the VECTOR ALUs.
+// As an MFMA pass this is one 32-row block of which 2-4 rows are real -- 64 MFMAs per column block whose operands
+// arrive one stash load per four of them: 26 k cycles of a 746 k tile for 0.1 % of its FLOPs, all latency.  Here a
+// group of TL/4 lanes reads one row of h_{l-1} (TL coordinates, contiguous in the stash: 512 B, a float4 per lane),
+// multiplies by the lane's slice of the dZ rows (loaded once from the waves' LDS images) and the group's partial sums
+// are added across lanes with DPP adds; 16 row loads are in flight per wave.  Wave w takes rows (it NW + w) RPI + sub.
+// The sum of a row lands in all lanes of the LAST 16-lane row of its group; iteration `it` is kept in lane (it & 15)
+// of that row, so the slab is touched with M loads / stores per 16 iterations instead of one per row.
+// Fixed summation order: deterministic.
+// ---------------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false);
+  return v + __builtin_bit_cast(float, t);
+}
+
+// sums over the TL/4 lanes of a group (32: a half wave, 16: one DPP row) of N independent values, step by step across
+// all of them (a DPP operand needs two wait states behind the instruction that wrote it: N chains in lockstep fill
+// them); complete in the lanes of each group's last 16-lane row
+template <int LPR, int N>
+__device__ __forceinline__ void group_sum_n(float (&v)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = dpp_add<0xB1, 0xf>(v[i]);  // quad_perm [1,0,3,2]
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = dpp_add<0x4E, 0xf>(v[i]);  // quad_perm [2,3,0,1]
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = dpp_add<0x141, 0xf>(v[i]);  // row_half_mirror
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = dpp_add<0x140, 0xf>(v[i]);  // row_mirror
+  if (LPR == 32) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = dpp_add<0x142, 0xa>(v[i]);  // row_bcast:15 into rows 1 and 3
+  }
+}
+
+// shift register along each 16-lane row: lanes 1..15 take their left neighbour's `keep`, lane 0 takes `v`
+__device__ __forceinline__ float row_push(float keep, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, keep),
+                                                               0x111 /* row_shr:1 */, 0xf, 0xf, false));
+}
+
+// ZACT < 0: h rows from the stash `h`, the dZ rows are rows 0..3 of the waves' images (lds_img, region_stride).
+// ZACT >= 0 (fused step): the rows are in the waves' LDS images -- h_{l-1} itself, written back over z by fwd_last_valu
+// (ZACT = ACT_ID), or z_{l-1} to be activated again on the way -- the dZ rows come from their own small images
+// `dz_img` (dz_stride apart), nothing is read from memory:
+// with all workgroups in lockstep the stash version read the whole h_{D-2} of the batch in one burst, 2.8 TB/s for
+// 21 k cycles with nothing to overlap.
+// MO: output rows computed (2, or 4 for the complex heads).  The sum of a row is pushed into a per-row shift register
+// (row_push): after a batch of 16 iterations lane l of a group's last 16-lane row holds iteration 15 - l, and the slab
+// is touched with MO loads / stores per batch.
+template <int TL, int NWAVES, int ZACT, int MO>
+__device__ __forceinline__ void dw_rows4_valu_impl(const float* lds_img, int region_stride, const float* __restrict__ h,
+                                                   int h_rows, int M, int K, float* slab_w, float* slab_b, bool first,
+                                                   int w, int lane, const float* dz_img, int dz_stride, float w0) {
+  constexpr int LPR = TL / 4;    // lanes per row of h
+  constexpr int RPI = 64 / LPR;  // rows per wave-wide load
+  constexpr int BATCH = 16;
+  static_assert(LPR == 32 || LPR == 16, "TL is 128 or 64");
+  typedef const __attribute__((address_space(3))) f32x4 lf4;
+  const int sub = lane / LPR, li = lane % LPR;
+  // this lane's 4 coordinates of the dZ rows: coordinate 4 li lives in wave image li >> 3, column 4 (li & 7)
+  f32x4 dz[MO];
+  {
+    const float* q = ZACT >= 0 ? dz_img + (li >> 3) * dz_stride + 4 * (li & 7)
+                               : lds_img + (li >> 3) * region_stride + 4 * (li & 7);
+#pragma unroll
+    for (int o = 0; o < MO; ++o) dz[o] = *(lf4*)(q + o * INR_LDS_LD);
+  }
+  const float* zq = lds_img + (li >> 3) * region_stride + 4 * (li & 7);  // this lane's columns of the images
+  const __amdgpu_buffer_rsrc_t rs = uniform_rsrc(ZACT >= 0 ? (const void*)slab_w : (const void*)h, h_rows * TL * 4);
+  const __amdgpu_buffer_rsrc_t rsw = uniform_rsrc(slab_w, M * K * 4);
+  const int voff = (sub * TL + 4 * li) * 4;
+  const int rows_per_it = NWAVES * RPI;
+  const int n_it = (K + rows_per_it - 1) / rows_per_it;
+  const bool res_lane = LPR == 32 ? (lane & 16) != 0 : true;  // lanes that end up holding complete sums
+  const int bl = 15 - (lane & 15);                            // the iteration of a batch this lane keeps
+  // (rows past h_rows: the descriptor's bound returns zeros; rows in [K, h_rows) are padding and never stored)
+#pragma unroll 1
+  for (int it0 = 0; it0 < n_it; it0 += BATCH) {
+    f32x4 hv[BATCH];
+#pragma unroll
+    for (int b = 0; b < BATCH; ++b) {
+      const int row0 = ((it0 + b) * NWAVES + w) * RPI;
+      if (ZACT >= 0) {
+        const int jr = row0 + sub < h_rows ? row0 + sub : 0;
+        hv[b] = *(lf4*)(zq + jr * INR_LDS_LD);
+      } else {
+        hv[b] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, row0 * TL * 4, 0));
+      }
+    }
+    const int j = ((it0 + bl) * NWAVES + w) * RPI + sub;  // the row whose sums this lane keeps
+    const bool jok = res_lane && j < K && it0 + bl < n_it;
+    int so[MO];  // byte offset of slab entry (o, j); out of the descriptor's range for lanes without one
+    float old[MO], keep[MO];
+#pragma unroll
+    for (int o = 0; o < MO; ++o) {
+      so[o] = (jok && o < M) ? (o * K + j) * 4 : 0x7ffffff0;
+      keep[o] = 0.f;
+      old[o] = first ? 0.f : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsw, so[o], 0, 0));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int b = 0; b < BATCH; b += 2) {
+      float p[2 * MO];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        f32x4 hh = hv[b + u];
+        if (ZACT > 0) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float a, dd;
+            act_fwd<(ZACT > 0 ? ZACT : 0)>(hh[e], w0, a, dd);
+            hh[e] = a;
+          }
+        }
+#pragma unroll
+        for (int o = 0; o < MO; ++o) {
+          float t = hh[0] * dz[o][0];
+          t = fmaf(hh[1], dz[o][1], t);
+          t = fmaf(hh[2], dz[o][2], t);
+          p[u * MO + o] = fmaf(hh[3], dz[o][3], t);
+        }
+      }
+      group_sum_n<LPR, 2 * MO>(p);
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int o = 0; o < MO; ++o) keep[o] = row_push(keep[o], p[u * MO + o]);
+    }
+#pragma unroll
+    for (int o = 0; o < MO; ++o)
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, old[o] + keep[o]), rsw, so[o], 0, 0);
+  }
+  if (w == 0) {  // db: the row sums of dZ over the tile's coordinates (lanes of group 0 hold all TL of them)
+    float sdz[MO];
+#pragma unroll
+    for (int o = 0; o < MO; ++o) sdz[o] = (dz[o][0] + dz[o][1]) + (dz[o][2] + dz[o][3]);
+    group_sum_n<LPR, MO>(sdz);
+    typedef __attribute__((address_space(1))) float gfloat;
+    gfloat* sb = (gfloat*)slab_b;
+#pragma unroll
+    for (int o = 0; o < MO; ++o)
+      if (lane == LPR - 1 && o < M) sb[o] = first ? sdz[o] : sb[o] + sdz[o];
+  }
+}
+
+template <int TL, int NWAVES, int ZACT = -1>
+__device__ __forceinline__ void dw_rows4_valu(const float* lds_img, int region_stride, const float* __restrict__ h,
+                                              int h_rows, int M, int K, float* slab_w, float* slab_b, bool first, int w,
+                                              int lane, const float* dz_img = nullptr, int dz_stride = 0,
+                                              float w0 = 0.f) {
+  if (M > 2)
+    dw_rows4_valu_impl<TL, NWAVES, ZACT, 4>(lds_img, region_stride, h, h_rows, M, K, slab_w, slab_b, first, w, lane,
+                                            dz_img, dz_stride, w0);
+  else
+    dw_rows4_valu_impl<TL, NWAVES, ZACT, 2>(lds_img, region_stride, h, h_rows, M, K, slab_w, slab_b, first, w, lane,
+                                            dz_img, dz_stride, w0);
+}
+
 // the column-block-0 pass also produces db (the row sums of dZ), the others skip that VALU work
 template <int MT, int TL, bool FULLM, class BSrc>
 __device__ __forceinline__ void dw_pass(const float* Rall, int region_stride, BSrc& bsrc, int n, float* slab_w,
@@ -947,6 +1175,12 @@ __global__ __launch_bounds__(NW * 64) void inr_mlp_kernel(const NetDesc nd, cons
   float* encB_lds = lds + NW * RS;  // [E][3] encoder matrix (gauss mode)
   // a.ll_lds: the last layer's fragments of output rows 0..3, [NB*4 groups][2 halves][4 rows] float4 + a float4 of zeros
   float* ll_lds = encB_lds + (INMODE == IN_GAUSS ? ((3 * nd.E + 3) & ~3) : 0);
+  // a.dz_lds (fused step, real activations): dZ_last gets its own 8-row image per wave behind the fragments, so that the
+  // waves' images still hold h_{D-2} (fwd_last_valu writes it back over z) when the last layer's dW is formed
+  float* dz_all = ll_lds + (NB * 4 * 8 + 1) * 4;  // [NW][8][INR_LDS_LD]
+  constexpr bool ZLDS_OK = MODE == MODE_FUSED && !PAIR && (TL == 128 || TL == 64);
+  const bool zlds = ZLDS_OK && a.dz_lds != 0;
+  float* dzw = dz_all + w * 8 * INR_LDS_LD;
   const int D = nd.D;
   if (a.ll_lds && MODE != MODE_BWD) {
     const f32x4* src = reinterpret_cast<const f32x4*>(a.packed + nd.L[D - 1].pf_off);
@@ -1065,7 +1299,18 @@ __global__ __launch_bounds__(NW * 64) void inr_mlp_kernel(const NetDesc nd, cons
       {
         const ActParams ap{nd.L[D - 2].omega, nd.L[D - 2].s0};
         float* sh = sv + (size_t)(NS * (D - 2)) * HSZ;
-        if (a.ll_lds) {
+        if (!PAIR && a.ll_lds) {  // (ll_lds: <= 4 output rows, their fragments in LDS)
+          float o4[4];
+          constexpr int HA = PAIR ? ACT_ID : HACT;
+          if (ZLDS_OK && zlds)
+            fwd_last_valu<NB, TL, HA, 2, true>(o4, R, ll_lds, LL.M, ap, sh, wcol, lane);
+          else if (saving)
+            fwd_last_valu<NB, TL, HA, 1, false>(o4, R, ll_lds, LL.M, ap, sh, wcol, lane);
+          else
+            fwd_last_valu<NB, TL, HA, 0, false>(o4, R, ll_lds, LL.M, ap, nullptr, wcol, lane);
+#pragma unroll
+          for (int o = 0; o < 4; ++o) accL[0][o] = o4[o];
+        } else if (a.ll_lds) {
           if (saving)
             fwd_layer<NB, 1, TL, HACT, true, 1, true>(accL, R, ll_lds, ap, sh, wcol, lane);
           else
@@ -1098,11 +1343,20 @@ __global__ __launch_bounds__(NW * 64) void inr_mlp_kernel(const NetDesc nd, cons
         // fused: pointwise loss of this row (both outputs of a row sit in one half-0 lane)
         if (sampled_pre) loss_acc += loss_row(ld, nd.out_f, y, gt_pre, g);
         // dZ_last = dY * act'(z_last) -> image rows 0..3 (half 0); rows 4..31 are zero
+        if (ZLDS_OK && zlds) {  // ... of the wave's dZ image: 8 rows, all that the dX GEMM of a <= 8-row layer reads
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float v = 0.f;
-          if (r < 4 && half == 0 && r < nrows) v = g[ctanh ? (r & 3) >> 1 : (r & 3)] * dy[r & 3];
-          R[swz(acc_row(r, half), col)] = v;
+          for (int r = 0; r < 4; ++r) {
+            float v = 0.f;
+            if (half == 0 && r < nrows) v = g[ctanh ? r >> 1 : r] * dy[r];
+            dzw[swz(r + 4 * half, col)] = v;
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float v = 0.f;
+            if (r < 4 && half == 0 && r < nrows) v = g[ctanh ? (r & 3) >> 1 : (r & 3)] * dy[r & 3];
+            R[swz(acc_row(r, half), col)] = v;
+          }
         }
       }
     }
@@ -1124,16 +1378,24 @@ __global__ __launch_bounds__(NW * 64) void inr_mlp_kernel(const NetDesc nd, cons
       INR_STAMP(11);
       // ---- last layer: dW, db from (dZ_last, h_{D-2}); dH_{D-2} = W_last^T dZ_last
       {
-        BSrcStash<TL> bs{sv + (size_t)(NS * (D - 2)) * HSZ};
-        for (int n = w; n < LL.Kblk; n += NW)
-          dw_pass<1, TL, false, BSrcStash<TL>>(lds, RS, bs, n, slab + LL.gw_off, slab + LL.gb_off, LL.M, LL.K, first,
-                                               n == 0, lane);
+        if (ZLDS_OK && zlds) {
+          dw_rows4_valu<TL == 128 ? 128 : 64, NW, ACT_ID>(lds, RS, nullptr, NB * 32, LL.M, LL.K, slab + LL.gw_off,
+                                                          slab + LL.gb_off, first, w, lane, dz_all, 8 * INR_LDS_LD, 0.f);
+        } else if (LL.M <= 4 && (TL == 128 || TL == 64)) {
+          dw_rows4_valu<TL == 128 ? 128 : 64, NW>(lds, RS, sv + (size_t)(NS * (D - 2)) * HSZ, NB * 32, LL.M, LL.K,
+                                                  slab + LL.gw_off, slab + LL.gb_off, first, w, lane);
+        } else {
+          BSrcStash<TL> bs{sv + (size_t)(NS * (D - 2)) * HSZ};
+          for (int n = w; n < LL.Kblk; n += NW)
+            dw_pass<1, TL, false, BSrcStash<TL>>(lds, RS, bs, n, slab + LL.gw_off, slab + LL.gb_off, LL.M, LL.K, first,
+                                                 n == 0, lane);
+        }
       }
       INR_STAMP(12);
       f32x16 gacc[NB];
 #pragma unroll
       for (int m = 0; m < NB; ++m) gacc[m] = zero16();
-      bwd_dx<NB, TL, PAIR, false>(gacc, R, a.packed + LL.pb_off, LL.Mpad8, nullptr, wcol, lane);
+      bwd_dx<NB, TL, PAIR, false>(gacc, (ZLDS_OK && zlds) ? dzw : R, a.packed + LL.pb_off, LL.Mpad8, nullptr, wcol, lane);
       __syncthreads();  // all dW reads of the images are done
       if (D == 2)
         acc_times_d_to_lds<NB, TL, PAIR>(gacc, R, sv + (size_t)1 * HSZ, sv + (size_t)2 * HSZ, wcol, lane);  // dZ_0
@@ -1250,6 +1512,11 @@ inline hipError_t launch_mlp(const NetDesc& nd, const LossDesc& ld, const MlpArg
                           (size_t)(NB * 4 * 8 + 1) * 4) * sizeof(float);
   a.ll_lds = (MODE != MODE_BWD && nd.L[nd.D - 1].M <= 4 && with_ll <= 160 * 1024) ? 1 : 0;
   if (a.ll_lds) lds_bytes = with_ll;
+  // ... and, in the fused step, an 8-row dZ_last image per wave behind them (see the kernel)
+  const size_t with_dz = with_ll + (size_t)NW * 8 * INR_LDS_LD * sizeof(float);
+  constexpr bool real_act = HACT != ACT_GABOR && HACT != ACT_GABOR2D;
+  a.dz_lds = (a.ll_lds && MODE == MODE_FUSED && real_act && nd.L[nd.D - 1].Mpad8 <= 8 && with_dz <= 160 * 1024) ? 1 : 0;
+  if (a.dz_lds) lds_bytes = with_dz;
 #ifdef INR_DWG_STATIC  // the kernel has no in-kernel dW passes for layers the GEMM can take: the caller must run it
   if (MODE != MODE_FWD && HACT != ACT_GABOR2D && !a.dw_gemm && (nd.D > 2 || INMODE == IN_GAUSS))
     return hipErrorInvalidValue;
