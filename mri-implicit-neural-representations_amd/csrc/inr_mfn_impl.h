@@ -536,10 +536,15 @@ __global__ __launch_bounds__(NW * 64) void inr_mfn_kernel(const NetDesc nd, cons
         __syncthreads();
         if (kh >= 0) {
           const LayerDesc& Hd = nd.L[nd.head_layer[kh]];
-          BSrcStash<TL> bs{svi + (size_t)2 * HSZ};  // h_i
-          for (int nn = w; nn < Hd.Kblk; nn += NW)
-            dw_pass<1, TL, false, BSrcStash<TL>>(HGall, HS, bs, nn, slab + Hd.gw_off, slab + Hd.gb_off, Hd.M, Hd.K,
-                                                 first, nn == 0, lane);
+          if (Hd.M <= 4 && (TL == 64 || TL == 128)) {  // head rows on the vector ALUs (inr_mlp_impl.h)
+            dw_rows4_valu<(TL == 128 ? 128 : 64), NW>(HGall, HS, svi + (size_t)2 * HSZ, NB * 32, Hd.M, Hd.K,
+                                                      slab + Hd.gw_off, slab + Hd.gb_off, first, w, lane);
+          } else {
+            BSrcStash<TL> bs{svi + (size_t)2 * HSZ};  // h_i
+            for (int nn = w; nn < Hd.Kblk; nn += NW)
+              dw_pass<1, TL, false, BSrcStash<TL>>(HGall, HS, bs, nn, slab + Hd.gw_off, slab + Hd.gb_off, Hd.M, Hd.K,
+                                                   first, nn == 0, lane);
+          }
         }
         // ---- dL_{i-1} = (g_h*f_i)^T h_{i-1} (+ db), dF_i = (g_h*l_i cos u_i)^T x (+ dc)
         {

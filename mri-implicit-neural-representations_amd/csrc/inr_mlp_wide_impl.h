@@ -440,10 +440,15 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
       INR_STAMP(si); ++si;
       __syncthreads();  // every group's dZ_last is in LDS
       {
-        BSrcStash<TL> bs{sv + (size_t)(NS * (D - 2)) * HSZ};
-        for (int n = w; n < LL.Kblk; n += NW)
-          dw_pass<1, TL, false, BSrcStash<TL>>(lds, RS, bs, n, slab + LL.gw_off, slab + LL.gb_off, LL.M, LL.K, first,
-                                               n == 0, lane);
+        if (LL.M <= 4) {  // <= 4 rows: on the vector ALUs (inr_mlp_impl.h), not as a padded 32-row MFMA block
+          dw_rows4_valu<TL, NW>(lds, RS, sv + (size_t)(NS * (D - 2)) * HSZ, NB * 32, LL.M, LL.K, slab + LL.gw_off,
+                                slab + LL.gb_off, first, w, lane);
+        } else {
+          BSrcStash<TL> bs{sv + (size_t)(NS * (D - 2)) * HSZ};
+          for (int n = w; n < LL.Kblk; n += NW)
+            dw_pass<1, TL, false, BSrcStash<TL>>(lds, RS, bs, n, slab + LL.gw_off, slab + LL.gb_off, LL.M, LL.K, first,
+                                                 n == 0, lane);
+        }
       }
       INR_STAMP(si); ++si;
       f32x16 gacc[MT];
