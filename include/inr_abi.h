@@ -9,9 +9,13 @@
  *     (thread-local); nothing throws or aborts across the ABI;
  *   - all tensor arguments are DEVICE pointers to contiguous row-major fp32 buffers owned by the
  *     caller; the library never allocates device memory and retains no pointer across calls;
- *   - all work is enqueued on the hipStream_t passed as `stream` (void*); no implicit sync;
- *   - a plan is immutable after creation and may be shared between threads and streams as long as
- *     each in-flight call has its own workspace buffers.
+ *   - all work is ordered on the hipStream_t passed as `stream` (void*); no implicit sync.  One exception to
+ *     "enqueued on": a fused step whose tiles leave the last round of the persistent grid partly empty runs part of
+ *     its weight-gradient GEMM on a low-priority side stream the plan creates on first use, forked from and joined
+ *     back into `stream` with events inside the call (csrc/inr_api.hip step_schedule; INR_OVERLAP=0 disables it) --
+ *     to the caller the call still behaves as work on `stream`, including under stream capture;
+ *   - a plan's description is immutable after creation (that side stream is its only state) and it may be shared
+ *     between threads and streams as long as each in-flight call has its own workspace buffers.
  *
  * Parameter layout ("flat params", P floats): layer k's weight [M_k, K_k] (PyTorch [out,in]
  * layout) followed by its bias [M_k], k = 0..D-1 -- i.e. the reference's state_dict order

@@ -5,7 +5,9 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 
 #include "../../include/inr_abi.h"
@@ -54,6 +56,11 @@ struct inr_plan {
   inr_net_desc desc;
   NetDesc nd;
   int64_t packed_floats;
+  // split steps (step_schedule below): a low-priority stream for the part of the weight-gradient GEMM that runs beside
+  // the fused kernel's last, partial round.  Created on first use, destroyed with the plan; the only state a plan has.
+  mutable std::mutex side_mu;
+  mutable hipStream_t side = nullptr;
+  mutable int side_dev = -1;
 };
 
 // Multiplicative filter networks (models/mfn.py).  L[] = filters 0..n | linears 0..n-1 | heads; flat
@@ -391,6 +398,7 @@ int inr_plan_create(const inr_net_desc* d, inr_plan** out) {
 }
 
 int inr_plan_destroy(inr_plan* plan) {
+  if (plan != nullptr && plan->side != nullptr) (void)hipStreamDestroy(plan->side);
   delete plan;
   return INR_OK;
 }
@@ -520,6 +528,92 @@ static bool dw_gemm_plan(const inr_plan* plan) {
 // fused steps of these plans stash per TILE (n_tiles slots): a batch-level GEMM reads the whole batch's stash
 static bool step_save_by_tile(const inr_plan* plan) { return dw_gemm_plan(plan) || w2_plan(plan); }
 
+// ---------------------------------------------------------------------------------------------
+// How a fused step of a batch-GEMM plan is launched.  With more tiles than workgroups the persistent grid runs whole
+// rounds and then a partial one, during which `idle` = n_blocks - (n_tiles mod n_blocks) CUs have nothing to do (WIRE at
+// 25 000 rows: 391 tiles of 64 coordinates = 256 + 135; the multiscale config: 1563 = 6 x 256 + 27) -- while the
+// weight-gradient GEMM of the tiles already finished only needs their stash.  Split step:
+//   main stream:  fused kernel on tiles [0, full)  ->  fused kernel on tiles [full, nt), `rem` workgroups, accumulating
+//                 into the slabs of workgroups 0..rem-1  ->  (join)  ->  GEMM part B: tiles [tA, nt)  ->  reduction
+//   side stream:  (after the first kernel)  GEMM part A: tiles [0, tA), at most `idle` workgroups
+// Part A is sized to end with the partial round: a tile costs the GEMM about kGemmTileShare of the fused kernel's time
+// for it on one CU (dW is half of forward + dX, at a slightly better MFMA rate).  Chunk slabs of A, then of B, follow
+// the fused kernel's; every sum keeps a fixed order (deterministic), though not the order of the unsplit launch.
+// INR_OVERLAP=0 in the environment turns the split off.
+// ---------------------------------------------------------------------------------------------
+constexpr double kGemmTileShare = 0.4;
+
+struct StepSchedule {
+  bool split;
+  int64_t full, rem, tA;
+  inr::DwGemmArgs gA, gB;  // (gB alone when !split)
+  inr::SlabSplit red;      // for the reduction: n2 = all chunk slabs
+};
+
+static bool overlap_enabled() {  // (read per call: a test compares the two schedules in one process)
+  const char* e = getenv("INR_OVERLAP");
+  return !(e != nullptr && e[0] == '0');
+}
+
+// chunks of tiles [tile0, tile1) for about `max_wgs` workgroups (same rules as dw_gemm_setup: half-height tiles for short chunks)
+static void rechunk(inr::DwGemmArgs& g, int64_t tile0, int64_t tile1, int max_wgs) {
+  const int64_t n = tile1 - tile0;
+  g.tile0 = (int)tile0, g.n_tiles = (int)tile1;
+  auto chunking = [&]() {
+    const int units = std::max(1, inr::dw_gemm_units(g));
+    const int target = std::max(1, max_wgs / units);
+    g.tiles_per_chunk = (int)((n + target - 1) / target);
+    g.n_chunks = (int)((n + g.tiles_per_chunk - 1) / g.tiles_per_chunk);
+  };
+  g.WBM = 0;
+  chunking();
+  if (g.TL == 128 && g.WB == 4 && n > 1 && (int64_t)g.tiles_per_chunk * g.TL < 1024) {
+    g.WBM = 2;
+    chunking();
+  }
+}
+
+static bool step_schedule(const inr_plan* plan, int64_t nt, int64_t nb, StepSchedule* sc) {
+  sc->split = false;
+  sc->full = nt, sc->rem = 0, sc->tA = 0;
+  if (!dw_gemm_setup(plan, nt, &sc->gB, &sc->red)) return false;
+  sc->gA = sc->gB;
+  sc->gA.n_chunks = 0;
+  if (!overlap_enabled() || nt <= nb || nt % nb == 0) return true;
+  const int64_t rem = nt % nb, full = nt - rem, idle = nb - rem;
+  {
+    inr::DwGemmArgs probe = sc->gB;
+    probe.WBM = 0;
+    if (idle < inr::dw_gemm_units(probe)) return true;  // not even one chunk's workgroups fit beside the partial round
+  }
+  int64_t tA = (int64_t)(0.9 * (double)idle / kGemmTileShare);
+  if (tA > full) tA = full;
+  if (tA < nt / 16 || tA < 1) return true;  // nothing worth a second launch
+  rechunk(sc->gA, 0, tA, (int)idle);
+  rechunk(sc->gB, tA, nt, 256);
+  sc->split = true;
+  sc->full = full, sc->rem = rem, sc->tA = tA;
+  sc->red.n2 = sc->gA.n_chunks + sc->gB.n_chunks;
+  return true;
+}
+
+static hipStream_t side_stream(const inr_plan* plan) {
+  std::lock_guard<std::mutex> lock(plan->side_mu);
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  if (plan->side != nullptr && plan->side_dev != dev) {
+    (void)hipStreamDestroy(plan->side);
+    plan->side = nullptr;
+  }
+  if (plan->side == nullptr) {
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (hipStreamCreateWithPriority(&plan->side, hipStreamNonBlocking, least) != hipSuccess) plan->side = nullptr;
+    plan->side_dev = dev;
+  }
+  return plan->side;
+}
+
 // a call's scratch against what the plan needs: `save_slots` stash slots (0: none), `n_slabs` slabs (0: none)
 static int check_ws(const inr_plan* plan, const inr_workspace* ws, int64_t save_slots, int64_t n_slabs,
                     const char* who) {
@@ -566,7 +660,9 @@ int inr_plan_workspace(const inr_plan* plan, int64_t B, int64_t* step_save_slots
     inr::DwGemmArgs g;
     inr::SlabSplit split;
     dw_gemm_setup(plan, nt, &g, &split);
-    *n_slabs = nb + g.n_chunks;
+    StepSchedule sc;
+    step_schedule(plan, nt, nb, &sc);  // (a split step has its own chunking; the unfused backward keeps the plain one)
+    *n_slabs = nb + std::max(g.n_chunks, sc.red.n2);
   }
   return INR_OK;
 }
@@ -753,6 +849,50 @@ int inr_backward(const inr_plan* plan, const float* params, const float* packed,
   return finish_gradients(plan, a, nt, nb, grads, nullptr, params, packed, (hipStream_t)stream, "inr_backward");
 }
 
+// fused step (mode 2) + weight gradients + reduction, split over two streams where step_schedule says so
+static int run_fused_step(const inr_plan* plan, const LossDesc& ld, const inr::MlpArgs& a, int64_t nt, int64_t nb,
+                          float* grads, float* loss_out, const float* params, const float* packed, hipStream_t st,
+                          const char* who) {
+  StepSchedule sc;
+  hipStream_t side = nullptr;
+  if (grads != nullptr && a.dw_gemm == 1 && step_schedule(plan, nt, nb, &sc) && sc.split) side = side_stream(plan);
+  if (side == nullptr) {
+    int rc = launch(plan, ld, a, 2, (int)nb, st);
+    if (rc != INR_OK) return rc;
+    if (grads == nullptr) return INR_OK;  // profiling: leave the per-block slabs unreduced
+    return finish_gradients(plan, a, nt, nb, grads, loss_out, params, packed, st, who);
+  }
+  hipEvent_t fork = nullptr, join = nullptr;
+  if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess) {
+    if (fork != nullptr) (void)hipEventDestroy(fork);
+    return fail(INR_ERR_HIP, "%s: event creation failed", who);
+  }
+  float* chunk_slabs = a.slabs + (size_t)nb * plan->nd.slab_floats;
+  inr::MlpArgs a1 = a, a2 = a;
+  a1.n_tiles = (int)sc.full;
+  a2.tile0 = (int)sc.full, a2.accumulate = 1;
+  sc.gA.save = sc.gB.save = a.save;
+  sc.gA.slabs = chunk_slabs;
+  sc.gB.slabs = chunk_slabs + (size_t)sc.gA.n_chunks * plan->nd.slab_floats;
+  int rc = launch(plan, ld, a1, 2, (int)nb, st);
+  hipError_t e = hipSuccess;
+  if (rc == INR_OK) e = hipEventRecord(fork, st);
+  if (rc == INR_OK && e == hipSuccess) rc = launch(plan, ld, a2, 2, (int)sc.rem, st);  // (queued before the GEMM: the critical path)
+  if (rc == INR_OK && e == hipSuccess) e = hipStreamWaitEvent(side, fork, 0);
+  if (rc == INR_OK && e == hipSuccess) e = inr::launch_dw_gemm(sc.gA, side);
+  if (rc == INR_OK && e == hipSuccess) e = hipEventRecord(join, side);
+  if (rc == INR_OK && e == hipSuccess) e = hipStreamWaitEvent(st, join, 0);
+  if (rc == INR_OK && e == hipSuccess) e = inr::launch_dw_gemm(sc.gB, st);
+  if (rc == INR_OK && e == hipSuccess)
+    e = inr::launch_reduce_slabs(plan->nd, a.slabs, (int)nb, grads, loss_out, params, packed, st, sc.red);
+  (void)hipEventDestroy(fork);
+  (void)hipEventDestroy(join);
+  if (rc != INR_OK) return rc;
+  if (e != hipSuccess) return hip_fail(e, (std::string(who) + ": split step").c_str());
+  return INR_OK;
+}
+
 static void to_loss_desc(const inr_loss_desc* l, LossDesc* o) {
   memset(o, 0, sizeof(*o));
   o->scale = l->scale == 0.f ? 1.f : l->scale;
@@ -867,10 +1007,7 @@ int inr_train_step(const inr_plan* plan, const inr_loss_desc* loss, const float*
 #endif
   LossDesc ld;
   to_loss_desc(loss, &ld);
-  int rc = launch(plan, ld, a, 2, (int)nb, (hipStream_t)stream);
-  if (rc != INR_OK) return rc;
-  if (grads == nullptr) return INR_OK;  // profiling: leave the per-block slabs unreduced
-  return finish_gradients(plan, a, nt, nb, grads, loss_out, params, packed, (hipStream_t)stream, "inr_train_step");
+  return run_fused_step(plan, ld, a, nt, nb, grads, loss_out, params, packed, (hipStream_t)stream, "inr_train_step");
 }
 
 int inr_plan_set_bounds(inr_plan* plan, const float* lo, const float* hi, int32_t n) {
@@ -1003,11 +1140,8 @@ int inr_train_step_multi(const inr_plan* plan, const inr_loss_desc* loss, const 
 #endif
   LossDesc ld;
   to_loss_desc(loss, &ld);
-  int rc = launch(plan, ld, a, 2, (int)nb, (hipStream_t)stream);
-  if (rc != INR_OK) return rc;
-  if (grads == nullptr) return INR_OK;
-  return finish_gradients(plan, a, nt, nb, grads, loss_out, params, packed, (hipStream_t)stream,
-                          "inr_train_step_multi");
+  return run_fused_step(plan, ld, a, nt, nb, grads, loss_out, params, packed, (hipStream_t)stream,
+                        "inr_train_step_multi");
 }
 
 // torch computes these in Python doubles and passes them to fp32 kernels as scalars

@@ -95,7 +95,13 @@ __device__ __forceinline__ float slab_sum(const float* __restrict__ p, size_t st
 #pragma unroll
     for (int k = 0; k < 16; ++k) s += v[k];
   }
-  for (; b < n; ++b) s += p[(size_t)b * stride];
+  if (b < n) {  // the tail the same way (clamped addresses, selects after the loads): a chunk-slab set of 23 is a
+    float v[16];  // batch of 16 and then 7 -- as a scalar loop those were 7 serialized L2 / HBM round trips
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = p[(size_t)(b + k < n ? b + k : n - 1) * stride];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += b + k < n ? v[k] : 0.f;
+  }
   return s;
 }
 

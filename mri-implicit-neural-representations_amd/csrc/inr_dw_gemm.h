@@ -18,7 +18,8 @@ struct DwGemmArgs {
   float* slabs;        // n_chunks slabs of slab_floats floats (layout of the fused kernels' slabs)
   long long save_floats_per_tile;
   int slab_floats;
-  int n_tiles, n_chunks, tiles_per_chunk;
+  int n_tiles, n_chunks, tiles_per_chunk;  // chunk kc = tiles [tile0 + kc tpc, ...) below n_tiles
+  int tile0;
   int TL;              // coordinates per tile: 64 or 128
   int WB;              // 32-row blocks per wave-tile side: 4 (workgroup tile 256 x 256) or 3 (192 x 192)
   int WBM;             // 0: square tiles; 2 (with WB = 4, TL = 128): 128-row x 256-column workgroup tiles for short chunks

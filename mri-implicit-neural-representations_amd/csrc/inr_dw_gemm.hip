@@ -99,8 +99,8 @@ __device__ __forceinline__ void dwg_body(const DwGemmArgs& a, const DwGemmItem& 
     roff[k] = ((isg ? it.g_off : it.h_off) + row * TL + (t & 7) * 4) * 4;  // bytes
   }
   constexpr int KS = TL / 32;  // K-steps per tile
-  // chunk kc = tiles [kc tpc, (kc + 1) tpc)
-  const int t0 = kc * a.tiles_per_chunk;
+  // chunk kc = tiles [tile0 + kc tpc, tile0 + (kc + 1) tpc), below n_tiles
+  const int t0 = a.tile0 + kc * a.tiles_per_chunk;
   int n_mine = a.n_tiles - t0;
   if (n_mine > a.tiles_per_chunk) n_mine = a.tiles_per_chunk;
   const int n_steps = (n_mine > 0 ? n_mine : 0) * KS;

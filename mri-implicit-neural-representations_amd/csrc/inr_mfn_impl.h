@@ -367,9 +367,9 @@ __global__ __launch_bounds__(NW * 64) void inr_mfn_kernel(const NetDesc nd, cons
   constexpr int MT = NB > 8 ? 8 : NB;   // row blocks per register-sized chunk
   float* slab = (MODE != MODE_FWD) ? a.slabs + (size_t)blockIdx.x * nd.slab_floats : nullptr;
   float loss_acc = 0.f;
-  bool first = true;
+  bool first = a.accumulate == 0;  // accumulate: a follow-up launch of the same step (inr_api.hip, split launches)
 
-  for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+  for (int tile = a.tile0 + blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
     const long long row0 = (long long)tile * TL;
     const long long crow = row0 + wcol;
     const bool valid = crow < a.B;
@@ -598,7 +598,7 @@ __global__ __launch_bounds__(NW * 64) void inr_mfn_kernel(const NetDesc nd, cons
     if (tid == 0) {
       float t = 0.f;
       for (int i = 0; i < NW; ++i) t += lds[i];
-      slab[nd.slab_loss_off] = t;
+      slab[nd.slab_loss_off] = a.accumulate ? slab[nd.slab_loss_off] + t : t;
     }
   }
 }

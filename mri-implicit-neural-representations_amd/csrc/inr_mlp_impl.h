@@ -1197,7 +1197,7 @@ __global__ __launch_bounds__(NW * 64) void inr_mlp_kernel(const NetDesc nd, cons
   constexpr int HSZ = NB * 32 * TL;  // floats per stashed tensor
   float* slab = (MODE != MODE_FWD) ? a.slabs + (size_t)blockIdx.x * nd.slab_floats : nullptr;
   float loss_acc = 0.f;
-  bool first = true;
+  bool first = a.accumulate == 0;  // accumulate: a follow-up launch of the same step (inr_api.hip, split launches)
 #ifdef INR_DWG_STATIC  // 256-row builds: hidden-width dW ALWAYS comes from the batch-level GEMM (launch_mlp checks)
   constexpr bool dwg = !G2D;
 #else
@@ -1208,7 +1208,7 @@ __global__ __launch_bounds__(NW * 64) void inr_mlp_kernel(const NetDesc nd, cons
   // only pairs NB == 12 with that width (inr_api.hip)
   constexpr bool HFULL = true;  // hidden-layer slabs span all NB*32 rows (inr_plan_create)
 
-  for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+  for (int tile = a.tile0 + blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
     const long long row0 = (long long)tile * TL;
     const long long crow = row0 + wcol;
     const bool valid = crow < a.B;
@@ -1494,7 +1494,7 @@ __global__ __launch_bounds__(NW * 64) void inr_mlp_kernel(const NetDesc nd, cons
     if (tid == 0) {
       float t = 0.f;
       for (int i = 0; i < NW; ++i) t += lds[i];
-      slab[nd.slab_loss_off] = t;
+      slab[nd.slab_loss_off] = a.accumulate ? slab[nd.slab_loss_off] + t : t;
     }
   }
 }

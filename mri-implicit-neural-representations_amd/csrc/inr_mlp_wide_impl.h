@@ -276,11 +276,11 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
   const int D = nd.D;
   float* slab = (MODE != MODE_FWD) ? a.slabs + (size_t)blockIdx.x * nd.slab_floats : nullptr;
   float loss_acc = 0.f;
-  bool first = true;
+  bool first = a.accumulate == 0;  // accumulate: a follow-up launch of the same step (inr_api.hip, split launches)
   const LayerDesc& LL = nd.L[D - 1];
   const size_t aoff = (size_t)m0 * 256;
 
-  for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+  for (int tile = a.tile0 + blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
     const long long row0 = (long long)tile * TL;
     const long long crow = row0 + wcol;
     const bool valid = crow < a.B;
@@ -549,7 +549,7 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
     if (tid == 0) {
       float t = 0.f;
       for (int i = 0; i < NW; ++i) t += lds[i];
-      slab[nd.slab_loss_off] = t;
+      slab[nd.slab_loss_off] = a.accumulate ? slab[nd.slab_loss_off] + t : t;
     }
   }
 }

@@ -327,6 +327,64 @@ def test_device_resident_adam_and_graph_steps(dev):
         assert torch.equal(fits[0][1], fits[1][1]) and torch.equal(fits[0][2], fits[1][2]), extra
 
 
+@pytest.mark.parametrize("model,B", [("SIREN", 40000), ("WIRE", 25000), ("SIREN512", 20000)])
+def test_split_step_overlap_matches_plain_schedule(dev, model, B):
+    """Batches whose tiles do not fill the last round of the persistent grid (SIREN 5x256: 313 tiles of 128 rows =
+    256 + 57; WIRE: 391 tiles of 64 = 256 + 135; SIREN 8x512: 313 tiles of 64) run as a split step: the weight-gradient
+    GEMM of the finished tiles on a side stream beside the fused kernel's partial round (inr_api.hip, step_schedule).
+    Same forward, same per-tile sums, another chunking of the GEMM: loss and last-layer gradients bit-identical to
+    the plain schedule (INR_OVERLAP=0), the GEMM's layers to summation order; run-to-run deterministic; and the
+    workspace the plan asks for covers both schedules."""
+    import inr_mi355x as M
+    from inr_mi355x import _lib as L
+    torch.manual_seed(0)
+    if model == "SIREN":
+        enc = M.Positional_Encoder(FULL_ENC, device=dev)
+        eng = M.SIREN(FULL_NET).to(dev).fused_engine(256)
+        enc_B = enc.B.contiguous()
+    elif model == "SIREN512":
+        enc = M.Positional_Encoder(FULL_ENC, device=dev)
+        eng = M.SIREN(dict(FULL_NET, network_depth=4, network_width=512)).to(dev).fused_engine(256)
+        enc_B = enc.B.contiguous()
+    else:
+        eng = M.WIRE(dict(network_input_size=3, network_output_size=2, network_depth=4, network_width=256,
+                          first_omega_0=30, hidden_omega_0=30, scale=15)).to(dev)._engine()
+        enc_B = None
+    g = torch.Generator().manual_seed(7)
+    coords = (torch.rand(B, 3, generator=g) * 2 - 1).to(dev)
+    gt = (torch.randn(B, 2, generator=g) * 0.2).to(dev)
+    spec = M.LossSpec(L.LOSS_L2_HALF)
+    nt, nb = eng.launch_dims(B)
+    assert nt > nb and nt % nb != 0
+
+    def step():
+        l = float(eng.train_step(coords, enc_B, gt, spec))
+        torch.cuda.synchronize()
+        return l, eng.grads.clone()
+
+    old = os.environ.get("INR_OVERLAP")
+    try:
+        os.environ["INR_OVERLAP"] = "0"
+        slabs_plain = eng.workspace(B)[1]
+        l0, g0 = step()
+        os.environ["INR_OVERLAP"] = "1"
+        slabs_split = eng.workspace(B)[1]
+        l1, g1 = step()
+        l2, g2 = step()
+    finally:
+        if old is None:
+            os.environ.pop("INR_OVERLAP", None)
+        else:
+            os.environ["INR_OVERLAP"] = old
+    assert slabs_split > slabs_plain  # the split schedule is in use: part A's chunks come on top
+    assert l0 == l1 == l2
+    assert torch.equal(g1, g2)
+    assert rel_l2(g1, g0) < 2e-6
+    n_last = eng.out_features * (eng.desc.width + 1) if model != "WIRE" else 0
+    if n_last:  # the last layer's dW / db never pass through the GEMM: same sums, same order
+        assert torch.equal(g1[-n_last:], g0[-n_last:])
+
+
 def test_center_loss_vs_reference_vectors(dev):
     """CenterLoss through inr_loss_grad(INR_LOSS_CENTER) + inr_center_pairs_grad against value and gradient of the
     reference class (tests/golden/center.npz, pairs from torch.randperm under the fixture's seed)."""
