@@ -378,6 +378,20 @@ def test_split_step_overlap_matches_plain_schedule(dev, model, B):
             os.environ["INR_OVERLAP"] = old
     assert slabs_split > slabs_plain  # the split schedule is in use: part A's chunks come on top
     assert l0 == l1 == l2
+    if model == "SIREN":  # the fork into the side stream and the join are captured with the rest of the step
+        p0, m0 = eng.params.clone(), (eng.exp_avg.clone(), eng.exp_avg_sq.clone(), eng.step)
+        sg = eng.capture_step(lambda: eng.train_step(coords, enc_B, gt, spec), 1e-4)
+        sg.replay(1e-4)
+        torch.cuda.synchronize()
+        assert torch.equal(eng.grads, g1)
+        p_graph = eng.params.clone()
+        eng.params.copy_(p0); eng.exp_avg.copy_(m0[0]); eng.exp_avg_sq.copy_(m0[1]); eng.step = m0[2]
+        eng.pack()
+        eng.train_step(coords, enc_B, gt, spec)
+        eng.adam_step(1e-4)
+        assert torch.equal(eng.params, p_graph)
+        eng.params.copy_(p0); eng.exp_avg.copy_(m0[0]); eng.exp_avg_sq.copy_(m0[1]); eng.step = m0[2]
+        eng.pack()
     assert torch.equal(g1, g2)
     assert rel_l2(g1, g0) < 2e-6
     n_last = eng.out_features * (eng.desc.width + 1) if model != "WIRE" else 0
