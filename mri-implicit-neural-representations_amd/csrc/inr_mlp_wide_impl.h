@@ -250,6 +250,50 @@ __device__ __forceinline__ void rows_copy(float* R, float* __restrict__ G, int r
   }
 }
 
+// dW / db of a first layer on raw coordinates (K = 3: WIRE, WIRE2D) on the VECTOR ALUs.  As MFMA passes it is M/32
+// row blocks x one column block of which 3 columns are real, on two of the four waves: 35 k cycles of a 910 k WIRE tile
+// for 0.1 % of its FLOPs.  Here a thread owns a row of dZ_0 (read from the groups' images, a float4 per 4
+// coordinates), the tile's 64 x 3 coordinates sit in LDS (`xs`, broadcast reads) and the three sums + the row sum stay
+// in registers: 4 FMAs per coordinate.  Coordinates past the batch were loaded clamped; their dZ columns are zero.
+template <int TL, int NG>
+__device__ __forceinline__ void dw_first3_valu(const float* lds_img, int region_stride, const float* xs, int M,
+                                               float* slab_w_generic, float* slab_b_generic, bool first, int tid) {
+  typedef __attribute__((address_space(1))) float gfloat;
+  typedef const __attribute__((address_space(3))) f32x4 lf4;
+  gfloat* slab_w = (gfloat*)slab_w_generic;
+  gfloat* slab_b = (gfloat*)slab_b_generic;
+  for (int r = tid; r < M; r += 256) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, bs = 0.f;
+    float o0 = 0.f, o1 = 0.f, o2 = 0.f, ob = 0.f;
+    if (!first) {
+      o0 = slab_w[r * 3 + 0];
+      o1 = slab_w[r * 3 + 1];
+      o2 = slab_w[r * 3 + 2];
+      ob = slab_b[r];
+    }
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+#pragma unroll
+      for (int c4 = 0; c4 < 8; ++c4) {
+        const f32x4 d = *(lf4*)(lds_img + gi * region_stride + r * INR_LDS_LD + 4 * c4);
+        // coordinates 32 gi + 4 c4 + (0..3): twelve consecutive floats of xs
+        const f32x4 x0 = *(lf4*)(xs + (gi * 32 + 4 * c4) * 3 + 0);
+        const f32x4 x1 = *(lf4*)(xs + (gi * 32 + 4 * c4) * 3 + 4);
+        const f32x4 x2 = *(lf4*)(xs + (gi * 32 + 4 * c4) * 3 + 8);
+        a0 = fmaf(d[0], x0[0], a0), a1 = fmaf(d[0], x0[1], a1), a2 = fmaf(d[0], x0[2], a2);
+        a0 = fmaf(d[1], x0[3], a0), a1 = fmaf(d[1], x1[0], a1), a2 = fmaf(d[1], x1[1], a2);
+        a0 = fmaf(d[2], x1[2], a0), a1 = fmaf(d[2], x1[3], a1), a2 = fmaf(d[2], x2[0], a2);
+        a0 = fmaf(d[3], x2[1], a0), a1 = fmaf(d[3], x2[2], a1), a2 = fmaf(d[3], x2[3], a2);
+        bs += (d[0] + d[1]) + (d[2] + d[3]);
+      }
+    }
+    slab_w[r * 3 + 0] = o0 + a0;
+    slab_w[r * 3 + 1] = o1 + a1;
+    slab_w[r * 3 + 2] = o2 + a2;
+    slab_b[r] = ob + bs;
+  }
+}
+
 template <int NB, int INMODE, int HACT, int MODE>
 __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, const LossDesc ld, const MlpArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -274,6 +318,17 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
     __syncthreads();
   }
   const int D = nd.D;
+  // EAGER kernels, last layer of <= 4 rows: its fragments (rows 0..3; float4 (s4*2 + half)*4 + row) and the exchange
+  // buffer of the wave pairs' partial sums sit behind the encoder matrix (see the last layer below)
+  float* llw = encB_lds + (INMODE == IN_GAUSS ? ((3 * nd.E + 3) & ~3) : 0);
+  float* xw = llw + NB * 4 * 8 * 4;  // [NG][4][32]
+  const bool ll_valu = EAGER && MODE != MODE_BWD && nd.L[D - 1].M <= 4;
+  if (ll_valu) {
+    const f32x4* src = reinterpret_cast<const f32x4*>(a.packed + nd.L[D - 1].pf_off);
+    for (int c = tid; c < NB * 4 * 8; c += NW * 64)
+      reinterpret_cast<f32x4*>(llw)[c] = src[(c >> 3) * 64 + ((c >> 2) & 1) * 32 + (c & 3)];
+    __syncthreads();
+  }
   float* slab = (MODE != MODE_FWD) ? a.slabs + (size_t)blockIdx.x * nd.slab_floats : nullptr;
   float loss_acc = 0.f;
   bool first = a.accumulate == 0;  // accumulate: a follow-up launch of the same step (inr_api.hip, split launches)
@@ -292,6 +347,23 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
     float* sv_g = sv_last + 4 * TL;  // WIRE2D (never gauss): copy of a layer's output gradient [NB*32][TL]
     const bool stash = saving && hh == 0;  // one wave of the pair writes the (shared) lazy-activation stash
     int si = 0;  // diagnostic builds: phase stamps 0, 1, 2, ... in program order (tools/stamps.py wire)
+    // what the loss section needs from memory, requested now (fetched where it is used, the last-layer biases, the
+    // sampling mask and the target row were three serialized round trips between the last layer and the loss)
+    float gt_pre[4] = {0.f, 0.f, 0.f, 0.f}, lb_pre[4] = {0.f, 0.f, 0.f, 0.f};
+    bool sampled_pre = false;
+    constexpr bool PRE = !G2D;  // (the WIRE2D build has no registers to carry nine values across the tile: 134 -> 448 scratch instructions)
+    if (PRE && MODE != MODE_BWD && hh == 0) {
+      const int nrows_b = nd.last_act == ACT_CTANH ? 2 * nd.out_f : nd.out_f;
+#pragma unroll
+      for (int o = 0; o < 4; ++o)
+        if (o < nrows_b) lb_pre[o] = a.packed[LL.pbias_off + o];
+      if (MODE == MODE_FUSED && half == 0 && valid) {
+        sampled_pre = a.mask == nullptr || a.mask[crow] != 0;
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+          if (o < nd.out_f) gt_pre[o] = a.gt[crow * nd.out_f + o];
+      }
+    }
     INR_STAMP(si); ++si;
 
     // ================================ forward =================================
@@ -377,12 +449,53 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
       }
       float g4[4] = {0.f, 0.f, 0.f, 0.f}, dy[4] = {0.f, 0.f, 0.f, 0.f};
       int nrows_last = nd.out_f;
+      // The last layer (<= 4 rows) over the activated image on the VECTOR ALUs, both waves of a pair: as one 32-row MFMA
+      // block it kept ONE wave of each pair busy for 32 k cycles (192 k-steps, 4 useful rows of 32) while its partner
+      // waited.  A lane sums W[o][k] y[k][col] over the rows k = 8 s4 + 2e + half of its wave's half of the groups
+      // (weights: a broadcast float4 per row and group from LDS); lane halves, then the two waves (through `xw`) are
+      // added -- fixed order.
+      float o4[4] = {0.f, 0.f, 0.f, 0.f};
+      if (ll_valu) {
+        constexpr int per = NB * 4 / 2;
+        typedef const __attribute__((address_space(3))) f32x4 lf4;
+        typedef const __attribute__((address_space(3))) float lfl;
+        lfl* Ry = (lfl*)(R + col + half * INR_LDS_LD);
+        lf4* wq = (lf4*)llw + half * 4;
+        float ps[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+        for (int s4 = hh * per; s4 < (hh + 1) * per; ++s4) {
+          float yv[4];
+          f32x4 wv[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) yv[e] = Ry[(8 * s4 + 2 * e) * INR_LDS_LD];
+#pragma unroll
+          for (int o = 0; o < 4; ++o) wv[o] = wq[s4 * 8 + o];
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int o = 0; o < 4; ++o) ps[o] = fmaf(wv[o][e], yv[e], ps[o]);
+        }
+#pragma unroll
+        for (int o = 0; o < 4; ++o) ps[o] += __shfl_xor(ps[o], 32);
+        if (hh == 1 && half == 0) {
+#pragma unroll
+          for (int o = 0; o < 4; ++o) xw[(g * 4 + o) * 32 + col] = ps[o];
+        }
+        __syncthreads();
+        if (hh == 0) {
+#pragma unroll
+          for (int o = 0; o < 4; ++o) o4[o] = ps[o] + xw[(g * 4 + o) * 32 + col];
+        }
+      }
       if (hh == 0) {  // last layer: one row block
         f32x16 accL[1];
         accL[0] = zero16();
         const ActParams ap{nd.L[D - 2].omega, nd.L[D - 2].s0};
         float* sh = sv + (size_t)(NS * (D - 2)) * HSZ;
-        if (EAGER)
+        if (ll_valu) {
+#pragma unroll
+          for (int o = 0; o < 4; ++o) accL[0][o] = o4[o];
+        } else if (EAGER)
           bwd_dx<1, TL, false, false>(accL, R, a.packed + LL.pf_off, NB * 32, nullptr, wcol, lane);
         else if (saving)
           fwd_layer<NB, 1, TL, HACT, true>(accL, R, a.packed + LL.pf_off, ap, sh, wcol, lane);
@@ -393,7 +506,7 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
           zl[o] = accL[0][o];
-          if (o < (ctanh ? 2 * nd.out_f : nd.out_f)) zl[o] += a.packed[LL.pbias_off + o];
+          if (o < (ctanh ? 2 * nd.out_f : nd.out_f)) zl[o] += PRE ? lb_pre[o] : a.packed[LL.pbias_off + o];
         }
         nrows_last = last_layer_act(nd.last_act, nd.out_f, nd.w0, zl, y, dy);
 #pragma unroll
@@ -404,10 +517,11 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
 #pragma unroll
             for (int o = 0; o < 4; ++o) sv_last[o * TL + wcol] = dy[o];
           }
-        } else if (half == 0 && valid && (a.mask == nullptr || a.mask[crow] != 0)) {
-          float t[4] = {0.f, 0.f, 0.f, 0.f};
-          for (int o = 0; o < nd.out_f; ++o) t[o] = a.gt[crow * nd.out_f + o];
-          loss_acc += loss_row(ld, nd.out_f, y, t, g4);
+        } else if (PRE ? sampled_pre : (half == 0 && valid && (a.mask == nullptr || a.mask[crow] != 0))) {
+          if (!PRE) {
+            for (int o = 0; o < nd.out_f; ++o) gt_pre[o] = a.gt[crow * nd.out_f + o];
+          }
+          loss_acc += loss_row(ld, nd.out_f, y, gt_pre, g4);
         }
       }
       INR_STAMP(si); ++si;
@@ -510,6 +624,16 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
         __syncthreads();  // dZ_0 complete
         if (INMODE == IN_GAUSS) {
           rows_copy<TL, RH, true>(R, sv + (size_t)1 * HSZ, RH * hh, wcol, lane);  // dZ_0 (own rows), for the GEMM
+        } else if (EAGER && !G2D && L0.K == 3) {
+          // (xs = the pair exchange buffer of the last layer, free here: 64 coordinates x 3, clamped to the batch.  Not in the
+          // WIRE2D build: with dH_0 still live in 128 accumulator registers the unrolled pass spills -- 134 -> 528 scratch
+          // instructions -- and the step got 3 % slower; its dW_0 / dV_0 stay MFMA passes, compiled as real functions)
+          if (tid < TL * 3) {
+            const long long xr = row0 + tid / 3 < a.B ? row0 + tid / 3 : a.B - 1;
+            xw[tid] = a.x[xr * 3 + tid % 3];
+          }
+          __syncthreads();
+          dw_first3_valu<TL, NG>(lds, RS, xw, L0.M, slab + L0.gw_off, slab + L0.gb_off, first, tid);
         } else {
           BSrcX bs{a.x, row0, a.B, L0.K};
           for (int it = w; it < 2 * L0.Kblk; it += NW) {
@@ -556,7 +680,9 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
 
 template <int NB, int INMODE, int HACT, int MODE>
 inline hipError_t launch_mlp_wide(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int grid, hipStream_t st) {
-  const size_t lds_bytes = ((size_t)2 * NB * 32 * INR_LDS_LD + (INMODE == IN_GAUSS ? 3 * (size_t)nd.E : 0)) * sizeof(float);
+  constexpr bool eager = HACT == ACT_GABOR || HACT == ACT_GABOR2D;  // + last-layer fragments and the pair exchange buffer
+  const size_t lds_bytes = ((size_t)2 * NB * 32 * INR_LDS_LD + (INMODE == IN_GAUSS ? ((3 * (size_t)nd.E + 3) & ~(size_t)3) : 0) +
+                            (eager ? (size_t)NB * 4 * 8 * 4 + 2 * 4 * 32 : 0)) * sizeof(float);
   auto k = inr_mlp_wide_kernel<NB, INMODE, HACT, MODE>;
   if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
   // backward has no dW passes for the hidden-width layers: the caller runs the batch GEMM on the stash
