@@ -69,6 +69,25 @@ def test_bf16_step_close_to_fp32(dev, B, width, depth):
     assert torch.equal(g1, e16.grads)
 
 
+@pytest.mark.parametrize("B", [25000, 65536])
+def test_bf16_run_to_run_determinism(dev, B):
+    """Six launches of the bf16 fused step on the same inputs at the benchmark batch sizes (one and two 128-row tiles
+    per half workgroup): gradients and loss bit-identical.  The weight ring (LDS-DMA + vmcnt waits + barriers) is
+    where a timing-dependent result would come from (tools/debug_bf16_det.py prints the tensors that differ)."""
+    import inr_mi355x as M
+    from inr_mi355x import _lib as L
+    enc, m32, m16, e32, e16 = _pair(dev, B, 256, 5)
+    g = torch.Generator().manual_seed(B)
+    coords = (torch.rand(B, 3, generator=g) * 2 - 1).to(dev)
+    gt = (torch.randn(B, 2, generator=g) * 0.2).to(dev)
+    spec, encB = M.LossSpec(L.LOSS_L2_HALF), enc.B.contiguous()
+    l0 = float(e16.train_step(coords, encB, gt, spec))
+    g0 = e16.grads.clone()
+    for _ in range(5):
+        assert float(e16.train_step(coords, encB, gt, spec)) == l0
+        assert torch.equal(e16.grads, g0)
+
+
 def test_bf16_training_tracks_fp32(dev):
     """300 Adam steps on a synthetic k-space: the bf16 path's loss curve stays within a few percent of fp32's and
     the master weights stay fp32 (the packed bf16 images are refreshed by every Adam step)."""
