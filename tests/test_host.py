@@ -44,6 +44,23 @@ def test_adam_schedule_table():
     assert lib.inr_adam_schedule(lr, b1, b2, 4, None) != 0
 
 
+def test_bf16_kernel_asm_loads_untouched_in_flight():
+    """The bf16 fused kernel's stash loads are inline assembly with hand-placed vmcnt waits: the compiler does not know
+    their registers are written asynchronously, so a copy or spill it puts between load and wait would read stale data
+    (what register allocation does there depends on unrelated code -- an edit elsewhere in the kernel once made the
+    gradients timing-dependent).  tools/check_inflight_regs.py walks the built kernel with the in-order vmcnt model and
+    must find no instruction touching a register in flight."""
+    import subprocess
+    import sys
+    obj = os.path.join(ROOT, "mri-implicit-neural-representations_amd", "build", "inr_siren_bf16.o")
+    if not os.path.exists(obj) or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("needs the built object and llvm-objdump")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_inflight_regs.py"), obj,
+                        "inr_siren_bf16_kernel"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert " 0 touch a register in flight" in r.stdout
+
+
 def test_plan_validation_and_sizes():
     from inr_mi355x import _lib as L
     lib = L.load()
