@@ -146,6 +146,16 @@ __device__ __forceinline__ unsigned w2_load_asm(const u32x4& rsrc, int voff, int
   asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(v) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
   return v;
 }
+// The first load of a batch: five wait states in front.  gfx9 needs them between a VALU instruction that writes an SGPR
+// (v_readlane: how the compiler reloads a spilled SGPR) and a vector-memory instruction that reads it; the compiler pads
+// its own memory instructions but does not look inside inline assembly, and one build reloaded this load's offset SGPR
+// right in front of it -- the load then read a stale offset and the gradients differed from launch to launch
+// (tools/check_inflight_regs.py checks every built kernel for the pattern; tests/test_host.py runs it).
+__device__ __forceinline__ unsigned w2_load_asm_first(const u32x4& rsrc, int voff, int soff) {
+  unsigned v;
+  asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, %3 offen" : "=v"(v) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+  return v;
+}
 // at most N vector-memory operations outstanding; the eight registers are operands so that no use moves above the wait
 template <int N>
 __device__ __forceinline__ void w2_wait_rows(unsigned (&z)[8]) {
@@ -391,7 +401,7 @@ __global__ __launch_bounds__(512, 2) void inr_siren_bf16_kernel(const NetDesc nd
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
           const int so = (16 * m + 4 * gq) * TL * 4;
-          zall[m][2 * gq] = w2_load_asm(rz4, voff, so);
+          zall[m][2 * gq] = (m == 0 && gq == 0) ? w2_load_asm_first(rz4, voff, so) : w2_load_asm(rz4, voff, so);
           zall[m][2 * gq + 1] = w2_load_asm(rz4, voff, so + TL * 4);
         }
 #pragma unroll

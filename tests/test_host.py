@@ -44,12 +44,14 @@ def test_adam_schedule_table():
     assert lib.inr_adam_schedule(lr, b1, b2, 4, None) != 0
 
 
-def test_bf16_kernel_asm_loads_untouched_in_flight():
-    """The bf16 fused kernel's stash loads are inline assembly with hand-placed vmcnt waits: the compiler does not know
-    their registers are written asynchronously, so a copy or spill it puts between load and wait would read stale data
-    (what register allocation does there depends on unrelated code -- an edit elsewhere in the kernel once made the
-    gradients timing-dependent).  tools/check_inflight_regs.py walks the built kernel with the in-order vmcnt model and
-    must find no instruction touching a register in flight."""
+def test_bf16_kernel_inline_asm_memory_hazards():
+    """The bf16 fused kernel's stash loads are inline assembly with hand-placed vmcnt waits; the compiler neither knows
+    that their registers are written asynchronously nor pads hardware hazards inside assembly text.  One build reloaded
+    a spilled SGPR (v_readlane) right in front of the first such load -- gfx9 needs 5 wait states between a VALU write
+    of an SGPR and a vector-memory read of it -- so the load read a stale offset and the gradients became
+    timing-dependent (the load now carries its own s_nop).  tools/check_inflight_regs.py walks the built kernel:
+    no instruction may touch a register of a load still in flight (in-order vmcnt model), and no vector-memory
+    instruction may read an SGPR a VALU instruction wrote fewer than 5 wait states earlier."""
     import subprocess
     import sys
     obj = os.path.join(ROOT, "mri-implicit-neural-representations_amd", "build", "inr_siren_bf16.o")
@@ -58,7 +60,7 @@ def test_bf16_kernel_asm_loads_untouched_in_flight():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_inflight_regs.py"), obj,
                         "inr_siren_bf16_kernel"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert " 0 touch a register in flight" in r.stdout
+    assert " 0 touch a register in flight" in r.stdout and " 0 vector-memory instructions read an SGPR" in r.stdout
 
 
 def test_plan_validation_and_sizes():

@@ -78,6 +78,46 @@ def check(lines):
     return bad
 
 
+def sregs(tok):
+    out = set()
+    for a, b in re.findall(r"\bs\[(\d+):(\d+)\]", tok):
+        out.update(range(int(a), int(b) + 1))
+    for a in re.findall(r"\bs(\d+)\b", tok):
+        out.add(int(a))
+    return out
+
+
+def check_sgpr_hazard(lines):
+    """gfx9: an SGPR written by a VALU instruction (v_readlane, v_readfirstlane, v_cmp ...) must not be read by a
+    vector-memory instruction within the next 5 wait states.  The compiler's hazard recognizer pads its own memory
+    instructions; it does not look inside inline assembly -- an SGPR-spill reload (v_readlane) right in front of an
+    inline-assembly load made that load read a stale offset (timing-dependent)."""
+    bad = []
+    for i, l in enumerate(lines):
+        op = l.split()[0] if l else ""
+        if not VMEM.match(op) or len(l.split(None, 1)) < 2:
+            continue
+        need = sregs(l.split(None, 1)[1])
+        if not need:
+            continue
+        states, j = 0, i - 1
+        while j >= 0 and states < 5:
+            p = lines[j]
+            pop = p.split()[0] if p else ""
+            if pop.startswith("s_cbranch") or pop.startswith("s_branch") or pop == "s_barrier":
+                break  # (another path: not followed)
+            if pop.startswith("v_") and len(p.split(None, 1)) > 1:
+                dst = p.split(None, 1)[1].split(",")[0]
+                hit = sregs(dst) & need
+                if hit:
+                    bad.append((i, l, sorted(hit), p))
+                    break
+            m = re.match(r"s_nop (\d+)", p)
+            states += int(m.group(1)) + 1 if m else 1
+            j -= 1
+    return bad
+
+
 if __name__ == "__main__":
     found = kernel_lines(sys.argv[1], sys.argv[2])
     rc = 0
@@ -86,5 +126,9 @@ if __name__ == "__main__":
         print("%s: %d instructions, %d touch a register in flight" % (name[:80], len(lines), len(bad)))
         for i, l, hit, src in bad[:20]:
             print("   line %d: %s   <- v%s of: %s" % (i, l[:90], hit, src[:70]))
-        rc |= 1 if bad else 0
+        haz = check_sgpr_hazard(lines)
+        print("%s: %d vector-memory instructions read an SGPR a VALU wrote < 5 wait states earlier" % (name[:40], len(haz)))
+        for i, l, hit, src in haz[:20]:
+            print("   line %d: %s   <- s%s written by: %s" % (i, l[:80], hit, src[:60]))
+        rc |= 1 if bad or haz else 0
     sys.exit(rc)
