@@ -282,6 +282,16 @@ int inr_adam_step(const inr_plan* plan, float* params, const float* grads, float
                   float* exp_avg_sq, float* packed, double lr, double beta1, double beta2, double eps,
                   double weight_decay, double l1, double l2, int32_t step, void* stream);
 
+/* inr_train_step and inr_adam_step as ONE call for single-rank steps (nothing sits between the reduction and the
+ * update): the Adam update and the re-pack ride in the slab reduction's launch (flat-layout plans: SIREN / FFN, fp32 and
+ * bf16; two launches otherwise) -- one launch and one pass over the gradient less per step.  Bit-identical to the two
+ * calls; `grads` still receives the gradient. */
+int inr_train_adam_step(const inr_plan* plan, const inr_loss_desc* loss, float* params, float* packed,
+                        const float* x, const float* enc_B, const float* gt, const uint8_t* mask, int64_t B,
+                        const inr_workspace* ws, float* grads, float* loss_out, float* exp_avg,
+                        float* exp_avg_sq, double lr, double beta1, double beta2, double eps,
+                        double weight_decay, double l1, double l2, int32_t step, void* stream);
+
 /* The same update with the step count in DEVICE memory, so that the launch carries no argument that changes from
  * one step to the next and a whole step (inr_train_step + this) can be captured once in a HIP graph and replayed:
  * `step_dev` holds the number of steps taken so far (t); the kernel reads (step_size, bc2_sqrt) from

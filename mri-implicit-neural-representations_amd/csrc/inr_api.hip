@@ -784,10 +784,25 @@ int inr_forward(const inr_plan* plan, const float* params, const float* packed, 
   return launch(plan, ld, a, 0, (int)nb, (hipStream_t)stream);
 }
 
+// the Adam update folded into the slab reduction's launch (inr_train_adam_step)
+struct AdamFuse {
+  float *params, *m1, *m2, *packed;
+  inr::AdamArgs aa;
+};
+
+static hipError_t reduce_stage(const inr_plan* plan, const float* slabs, int nb, float* grads, float* loss_out,
+                               const float* params, const float* packed, hipStream_t st, const inr::SlabSplit& split,
+                               const AdamFuse* af) {
+  if (af != nullptr)
+    return inr::launch_reduce_slabs_adam(plan->nd, slabs, nb, grads, loss_out, af->params, af->m1, af->m2, af->packed,
+                                         af->aa, st, split);
+  return inr::launch_reduce_slabs(plan->nd, slabs, nb, grads, loss_out, params, packed, st, split);
+}
+
 // dW GEMM (plans that use it) + deterministic slab reduction into flat gradients
 static int finish_gradients(const inr_plan* plan, const inr::MlpArgs& a, int64_t nt, int64_t nb, float* grads,
                             float* loss_out, const float* params, const float* packed, hipStream_t st,
-                            const char* who) {
+                            const char* who, const AdamFuse* af = nullptr) {
   inr::SlabSplit split{0, 0, 0, 0};
   if (a.dw_gemm == 2) {  // bf16 fused step: all of dW / db from the bf16 batch GEMM, summed over its chunk slabs
     inr::DwGemmBf16Args g;
@@ -808,7 +823,7 @@ static int finish_gradients(const inr_plan* plan, const inr::MlpArgs& a, int64_t
     hipError_t e = inr::launch_dw_gemm(g, st);
     if (e != hipSuccess) return hip_fail(e, (std::string(who) + ": weight-gradient GEMM").c_str());
   }
-  hipError_t e = inr::launch_reduce_slabs(plan->nd, a.slabs, (int)nb, grads, loss_out, params, packed, st, split);
+  hipError_t e = reduce_stage(plan, a.slabs, (int)nb, grads, loss_out, params, packed, st, split, af);
   if (e != hipSuccess) return hip_fail(e, (std::string(who) + ": slab reduction").c_str());
   return INR_OK;
 }
@@ -852,7 +867,7 @@ int inr_backward(const inr_plan* plan, const float* params, const float* packed,
 // fused step (mode 2) + weight gradients + reduction, split over two streams where step_schedule says so
 static int run_fused_step(const inr_plan* plan, const LossDesc& ld, const inr::MlpArgs& a, int64_t nt, int64_t nb,
                           float* grads, float* loss_out, const float* params, const float* packed, hipStream_t st,
-                          const char* who) {
+                          const char* who, const AdamFuse* af = nullptr) {
   StepSchedule sc;
   hipStream_t side = nullptr;
   if (grads != nullptr && a.dw_gemm == 1 && step_schedule(plan, nt, nb, &sc) && sc.split) side = side_stream(plan);
@@ -860,7 +875,7 @@ static int run_fused_step(const inr_plan* plan, const LossDesc& ld, const inr::M
     int rc = launch(plan, ld, a, 2, (int)nb, st);
     if (rc != INR_OK) return rc;
     if (grads == nullptr) return INR_OK;  // profiling: leave the per-block slabs unreduced
-    return finish_gradients(plan, a, nt, nb, grads, loss_out, params, packed, st, who);
+    return finish_gradients(plan, a, nt, nb, grads, loss_out, params, packed, st, who, af);
   }
   hipEvent_t fork = nullptr, join = nullptr;
   if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess ||
@@ -885,7 +900,7 @@ static int run_fused_step(const inr_plan* plan, const LossDesc& ld, const inr::M
   if (rc == INR_OK && e == hipSuccess) e = hipStreamWaitEvent(st, join, 0);
   if (rc == INR_OK && e == hipSuccess) e = inr::launch_dw_gemm(sc.gB, st);
   if (rc == INR_OK && e == hipSuccess)
-    e = inr::launch_reduce_slabs(plan->nd, a.slabs, (int)nb, grads, loss_out, params, packed, st, sc.red);
+    e = reduce_stage(plan, a.slabs, (int)nb, grads, loss_out, params, packed, st, sc.red, af);
   (void)hipEventDestroy(fork);
   (void)hipEventDestroy(join);
   if (rc != INR_OK) return rc;
@@ -966,9 +981,9 @@ int inr_center_pairs_grad(const float* out, const float* gt, const int64_t* idx_
   return INR_OK;
 }
 
-int inr_train_step(const inr_plan* plan, const inr_loss_desc* loss, const float* params, const float* packed,
-                   const float* x, const float* enc_B, const float* gt, const uint8_t* mask, int64_t B,
-                   const inr_workspace* ws, float* grads, float* loss_out, void* stream) {
+static int train_step_impl(const inr_plan* plan, const inr_loss_desc* loss, const float* params, const float* packed,
+                           const float* x, const float* enc_B, const float* gt, const uint8_t* mask, int64_t B,
+                           const inr_workspace* ws, float* grads, float* loss_out, void* stream, const AdamFuse* af) {
   if (plan == nullptr || loss == nullptr || params == nullptr || packed == nullptr || x == nullptr ||
       gt == nullptr || ws == nullptr || loss_out == nullptr)
     return fail(INR_ERR_INVALID, "inr_train_step: null argument");
@@ -1007,7 +1022,13 @@ int inr_train_step(const inr_plan* plan, const inr_loss_desc* loss, const float*
 #endif
   LossDesc ld;
   to_loss_desc(loss, &ld);
-  return run_fused_step(plan, ld, a, nt, nb, grads, loss_out, params, packed, (hipStream_t)stream, "inr_train_step");
+  return run_fused_step(plan, ld, a, nt, nb, grads, loss_out, params, packed, (hipStream_t)stream, "inr_train_step", af);
+}
+
+int inr_train_step(const inr_plan* plan, const inr_loss_desc* loss, const float* params, const float* packed,
+                   const float* x, const float* enc_B, const float* gt, const uint8_t* mask, int64_t B,
+                   const inr_workspace* ws, float* grads, float* loss_out, void* stream) {
+  return train_step_impl(plan, loss, params, packed, x, enc_B, gt, mask, B, ws, grads, loss_out, stream, nullptr);
 }
 
 int inr_plan_set_bounds(inr_plan* plan, const float* lo, const float* hi, int32_t n) {
@@ -1208,6 +1229,29 @@ int inr_adam_step(const inr_plan* plan, float* params, const float* grads, float
   hipError_t e = inr::launch_adam_pack(plan->nd, params, grads, exp_avg, exp_avg_sq, packed, aa, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "inr_adam_step");
   return INR_OK;
+}
+
+int inr_train_adam_step(const inr_plan* plan, const inr_loss_desc* loss, float* params, float* packed, const float* x,
+                        const float* enc_B, const float* gt, const uint8_t* mask, int64_t B, const inr_workspace* ws,
+                        float* grads, float* loss_out, float* exp_avg, float* exp_avg_sq, double lr, double beta1,
+                        double beta2, double eps, double weight_decay, double l1, double l2, int32_t step,
+                        void* stream) {
+  if (grads == nullptr || exp_avg == nullptr || exp_avg_sq == nullptr)
+    return fail(INR_ERR_INVALID, "inr_train_adam_step: null argument");
+  if (step < 1) return fail(INR_ERR_INVALID, "inr_train_adam_step: step %d (counts from 1)", step);
+  AdamFuse af;
+  af.params = params, af.m1 = exp_avg, af.m2 = exp_avg_sq, af.packed = packed;
+  memset(&af.aa, 0, sizeof(af.aa));
+  af.aa.do_update = 1;
+  adam_bias_terms(lr, beta1, beta2, step, &af.aa.step_size, &af.aa.bc2_sqrt);
+  af.aa.omb1 = (float)(1.0 - beta1);
+  af.aa.beta2 = (float)beta2;
+  af.aa.omb2 = (float)(1.0 - beta2);
+  af.aa.eps = (float)eps;
+  af.aa.weight_decay = (float)weight_decay;
+  af.aa.l1 = (float)l1;
+  af.aa.l2 = (float)l2;
+  return train_step_impl(plan, loss, params, packed, x, enc_B, gt, mask, B, ws, grads, loss_out, stream, &af);
 }
 
 #ifdef INR_STAMPS

@@ -370,12 +370,10 @@ __device__ __forceinline__ void put_w2(const NetDesc& nd, int l, float* packed, 
   }
 }
 
-__global__ __launch_bounds__(256) void adam_pack_kernel(const NetDesc nd, float* __restrict__ params,
-                                                        const float* __restrict__ grads, float* __restrict__ m1,
-                                                        float* __restrict__ m2, float* __restrict__ packed,
-                                                        AdamArgs aa) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= nd.P) return;
+// one flat entry: Adam update from gradient `g` (do_update), then its image entries
+__device__ __forceinline__ void adam_pack_entry(const NetDesc& nd, int i, float g, float* __restrict__ params,
+                                                float* __restrict__ m1, float* __restrict__ m2,
+                                                float* __restrict__ packed, const AdamArgs& aa) {
   float p = params[i];
   bool live = true;
   if (aa.has_dead) {
@@ -385,7 +383,6 @@ __global__ __launch_bounds__(256) void adam_pack_kernel(const NetDesc nd, float*
     }
   }
   if (aa.do_update && live) {
-    float g = grads[i];
     if (aa.weight_decay != 0.f) g = fmaf(aa.weight_decay, p, g);
     if (aa.l1 != 0.f) g += aa.l1 * (p > 0.f ? 1.f : (p < 0.f ? -1.f : 0.f));  // d/dp lambda*sum|p|
     if (aa.l2 != 0.f) g = fmaf(2.f * aa.l2, p, g);                             // d/dp lambda*|sum p^2|
@@ -438,6 +435,57 @@ __global__ __launch_bounds__(256) void adam_pack_kernel(const NetDesc nd, float*
   if (vp.bias_row >= 0) packed[L.pbias_off + vp.bias_row] = p;
 }
 
+__global__ __launch_bounds__(256) void adam_pack_kernel(const NetDesc nd, float* __restrict__ params,
+                                                        const float* __restrict__ grads, float* __restrict__ m1,
+                                                        float* __restrict__ m2, float* __restrict__ packed,
+                                                        AdamArgs aa) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nd.P) return;
+  adam_pack_entry(nd, i, aa.do_update ? grads[i] : 0.f, params, m1, m2, packed, aa);
+}
+
+// reduce_slabs_real_kernel + adam_pack_kernel in one launch (single-rank steps: nothing sits between the reduction and
+// the update).  Same summation tree, same update arithmetic: bit-identical to the two launches; the gradient is still
+// written (callers read it).  The four waves of a workgroup each take one of a lane's four entries for the update.
+__global__ __launch_bounds__(256) void reduce_adam_real_kernel(const NetDesc nd, const float* __restrict__ slabs_all,
+                                                               int n_blocks_all, float* __restrict__ grads,
+                                                               float* __restrict__ loss_out, SlabSplit split,
+                                                               float* __restrict__ params, float* __restrict__ m1,
+                                                               float* __restrict__ m2, float* __restrict__ packed,
+                                                               AdamArgs aa) {
+  __shared__ f32x4 part[4][64];
+  const int slab_floats = nd.slab_floats, P = nd.P;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i4 = (blockIdx.x * 64 + lane) * 4;
+  const bool second = split.n2 > 0 && i4 >= split.lo && i4 < split.hi;
+  const float* __restrict__ slabs = second ? slabs_all + (size_t)n_blocks_all * slab_floats : slabs_all;
+  const int n_blocks = second ? split.n2 : n_blocks_all;
+  const int per = (n_blocks + 3) / 4;
+  const int b0 = w * per, b1 = (b0 + per < n_blocks) ? b0 + per : n_blocks;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (i4 < P) {
+    int b = b0;
+    for (; b + 8 <= b1; b += 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(slabs + (size_t)(b + u) * slab_floats + i4);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; b < b1; ++b) s += *reinterpret_cast<const f32x4*>(slabs + (size_t)b * slab_floats + i4);
+  }
+  part[w][lane] = s;
+  __syncthreads();
+  if (i4 < P) {
+    const f32x4 t = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+    if (w == 0)
+      for (int j = 0; j < 4 && i4 + j < P; ++j) grads[i4 + j] = t[j];
+    if (i4 + w < P) adam_pack_entry(nd, i4 + w, t[w], params, m1, m2, packed, aa);
+  }
+  if (loss_out != nullptr && blockIdx.x == gridDim.x - 1)
+    loss_words_sum(slabs_all, n_blocks_all, (size_t)slab_floats, nd.slab_loss_off, loss_out);
+}
+
 __global__ void step_advance_kernel(int* step_dev) { *step_dev += 1; }
 
 hipError_t launch_step_advance(int* step_dev, hipStream_t st) {
@@ -460,6 +508,28 @@ hipError_t launch_adam_pack(const NetDesc& nd, float* params, const float* grads
     hipLaunchKernelGGL(gabor_m2_kernel, dim3(nd.L[nd.mu0].M, nd.mfn_n + 1), dim3(64), 0, st, nd, params, packed);
   return hipGetLastError();
 }
+
+// reduction (+ the Adam update when `adam` is given: one launch on the flat-layout fast path, two otherwise)
+hipError_t launch_reduce_slabs_adam(const NetDesc& nd, const float* slabs, int n_blocks, float* grads, float* loss_out,
+                                    float* params, float* m1, float* m2, float* packed, const AdamArgs& aa_in,
+                                    hipStream_t st, SlabSplit split) {
+  bool flat = !(nd.bf16 && split.n2 == 0) && ((split.lo | split.hi) & 3) == 0 && split.mask == 0 && !nd.gabor;
+  for (int l = 0; l < nd.ND; ++l) flat = flat && nd.L[l].ltype == LT_REAL && nd.L[l].gw_off == nd.L[l].w_off;
+  if (!flat) {
+    hipError_t e = launch_reduce_slabs(nd, slabs, n_blocks, grads, loss_out, params, packed, st, split);
+    if (e != hipSuccess) return e;
+    return launch_adam_pack(nd, params, grads, m1, m2, packed, aa_in, st);
+  }
+  AdamArgs aa = aa_in;
+  aa.all_real = 1;
+  aa.has_dead = 0;
+  for (int l = 0; l < nd.ND; ++l) aa.has_dead = aa.has_dead || nd.L[l].live == 0;
+  const int grid = (nd.P + 255) / 256;
+  hipLaunchKernelGGL(reduce_adam_real_kernel, dim3(grid + 1), dim3(256), 0, st, nd, slabs, n_blocks, grads, loss_out, split,
+                     params, m1, m2, packed, aa);
+  return hipGetLastError();
+}
+
 
 // ---------------------------------------------------------------------------------------------
 // Positional_Encoder.embedding 'gauss' (networks.py:30-33): out[r] = [sin(p) | cos(p)],

@@ -265,6 +265,27 @@ class MLPEngine:
                                         _ptr(self.grads, "grads"), self._loss_word.data_ptr(), self._stream()))
         return self._loss_word[0]
 
+    def train_adam_step(self, x: torch.Tensor, enc_B: Optional[torch.Tensor], gt: torch.Tensor, spec: LossSpec,
+                        lr: float, count: Optional[int] = None, mask: Optional[torch.Tensor] = None,
+                        hdr_A: float = 0.0, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,
+                        weight_decay: float = 0.0, l1: float = 0.0, l2: float = 0.0):
+        """train_step + adam_step as one call (single-rank steps): the Adam update rides in the slab reduction's launch.
+        Bit-identical to the two calls; self.grads still receives the gradient.  Returns the loss scalar (device)."""
+        B = self._check_input(x, enc_B)
+        _shape(gt, "gt", B, self.out_features)
+        _shape(mask, "mask", B)
+        self._stash_rows = None
+        ws = self._ws(*self.workspace(B))
+        ld = self.loss_desc(spec, B if count is None else count, hdr_A)
+        self.step += 1
+        L.check(self.lib.inr_train_adam_step(self.plan, C.byref(ld), _ptr(self.params, "params"),
+                                             _ptr(self.packed, "packed"), _ptr(x, "x"), _ptr(enc_B, "enc_B"),
+                                             _ptr(gt, "gt"), _ptr(mask, "mask", torch.uint8), B, C.byref(ws),
+                                             _ptr(self.grads, "grads"), self._loss_word.data_ptr(),
+                                             _ptr(self.exp_avg, "exp_avg"), _ptr(self.exp_avg_sq, "exp_avg_sq"), lr,
+                                             beta1, beta2, eps, weight_decay, l1, l2, self.step, self._stream()))
+        return self._loss_word[0]
+
     def adam_step(self, lr: float, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,
                   weight_decay: float = 0.0, l1: float = 0.0, l2: float = 0.0) -> None:
         """torch.optim.Adam.step (train.py:190) on the flat buffers + weight re-pack."""

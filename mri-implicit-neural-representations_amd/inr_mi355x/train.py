@@ -196,6 +196,9 @@ class INRTrainer:
         self.graph_steps = bool(graph_steps) and world == 1 and not self.use_tv and \
             self.loss.kind != L.LOSS_CENTER and (self.enc_B is not None or emb == "none")
         self._graphs = {}
+        # plain single-rank steps of the MLP engines go through inr_train_adam_step (INR_ONE_CALL_STEPS=0: two calls)
+        self.one_call_steps = (os.environ.get("INR_ONE_CALL_STEPS", "1") != "0" and not self.is_mfn and not self.use_tv
+                               and self.loss.kind != L.LOSS_CENTER)
         if "pretrain" in config:  # train.py:117-121
             self.load_checkpoint(torch.load(config["pretrain"], map_location=self.device))
 
@@ -226,6 +229,21 @@ class INRTrainer:
         A = self._batch_hdr_A(it, lo, hi)
         if self.graph_steps:
             return self._graph_step(epoch, it, lo, hi, count, A)
+        if self.world == 1 and self.one_call_steps and hi > lo:
+            # single rank: nothing sits between the reduction and the update -- one call, one launch less
+            cfg = self.config
+            penalty = None  # value of the penalty at the parameters the step starts from, as below
+            if self.l1:
+                penalty = self.l1 * self.engine.params.abs().sum()
+            if self.l2:
+                penalty = self.l2 * (self.engine.params * self.engine.params).sum()
+            m = self.mask[lo:hi] if self.mask is not None else None
+            loss = self.engine.train_adam_step(self._inputs(lo, hi), self.enc_B, self.image[lo:hi], self.loss,
+                                               cfg["lr"] * lr_factor(epoch, cfg["max_epoch"]), count=count, mask=m,
+                                               hdr_A=A, beta1=cfg["beta1"], beta2=cfg["beta2"], eps=1e-8,
+                                               weight_decay=cfg["weight_decay"], l1=self.l1, l2=self.l2)
+            self.global_step += 1
+            return loss if penalty is None else loss + penalty
         if self.use_tv:
             loss = self._tv_step(lo, count, A)
         elif self.loss.kind == L.LOSS_CENTER:

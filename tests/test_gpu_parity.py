@@ -399,6 +399,48 @@ def test_split_step_overlap_matches_plain_schedule(dev, model, B):
         assert torch.equal(g1[-n_last:], g0[-n_last:])
 
 
+@pytest.mark.parametrize("case", ["siren", "siren_reg", "siren_bf16", "wire", "siren_mask"])
+def test_one_call_step_matches_two_calls(dev, case):
+    """inr_train_adam_step (the Adam update inside the slab reduction's launch; two launches behind the same entry for
+    plans whose slabs do not have the flat layout, e.g. WIRE) against inr_train_step + inr_adam_step: parameters,
+    moments, packed images and logged losses bit-identical over eight steps with two learning-rate changes."""
+    from inr_mi355x.synthetic import make_kspace
+    from inr_mi355x.train import INRTrainer
+    image, kc, shape = make_kspace(2, 16, 12)  # 384 rows: batches of 150, 150, 84
+    enc = dict(embedding="gauss", scale=2, embedding_size=32, coordinates_size=3)
+    cfg = dict(model="SIREN", loss="L2", lr=1e-3, batch_size=150, max_epoch=3, weight_decay=0.0, beta1=0.9, beta2=0.999,
+               net=dict(network_input_size=64, network_output_size=2, network_depth=3, network_width=64), encoder=enc)
+    if case == "siren_reg":
+        cfg.update(regularization=dict(type="L1", strenght=1e-6), weight_decay=1e-5)
+    if case == "siren_bf16":
+        cfg.update(precision="bf16", net=dict(network_input_size=64, network_output_size=2, network_depth=4,
+                                              network_width=256, last_tanh=True))
+    if case == "siren_mask":
+        cfg.update(undersampling="grid-2*1", loss="HDR", loss_opts=dict(hdr_eps=1e-2, hdr_ff_sigma=1.0, hdr_ff_factor=0.1))
+    if case == "wire":
+        cfg.update(model="WIRE", encoder=dict(embedding="none", scale=1, embedding_size=3, coordinates_size=3),
+                   net=dict(network_input_size=3, network_output_size=2, network_depth=2, network_width=64,
+                            first_omega_0=10, hidden_omega_0=10, scale=5))
+    fits, old = [], os.environ.get("INR_ONE_CALL_STEPS")
+    try:
+        for flag in ("0", "1"):
+            os.environ["INR_ONE_CALL_STEPS"] = flag
+            tr = INRTrainer(cfg, image, kc, shape, dev, seed=3)
+            assert tr.one_call_steps == (flag == "1")
+            losses = [s_[1] for s_ in tr.fit(8, log_every=1)]
+            e = tr.engine
+            fits.append((losses, e.params.clone(), e.exp_avg.clone(), e.exp_avg_sq.clone(), e.packed.clone(), e.grads.clone()))
+            assert e.step == 8
+    finally:
+        if old is None:
+            os.environ.pop("INR_ONE_CALL_STEPS", None)
+        else:
+            os.environ["INR_ONE_CALL_STEPS"] = old
+    assert fits[0][0] == fits[1][0]
+    for a, b in zip(fits[0][1:], fits[1][1:]):
+        assert torch.equal(a, b)
+
+
 def test_center_loss_vs_reference_vectors(dev):
     """CenterLoss through inr_loss_grad(INR_LOSS_CENTER) + inr_center_pairs_grad against value and gradient of the
     reference class (tests/golden/center.npz, pairs from torch.randperm under the fixture's seed)."""
