@@ -5,9 +5,6 @@ if len(sys.argv) > 1 and sys.argv[1].endswith(".csv"):
     rows = list(csv.DictReader(open(sys.argv[1])))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     names = [r["Kernel_Name"] for r in rows]
-    # last fused-kernel launch with the full grid = start of the last complete step
-    idx = [i for i, r in enumerate(rows) if "inr_mlp_wide_kernel" in r["Kernel_Name"] or "inr_mfn_wide_kernel" in r["Kernel_Name"]]
-    big = [i for i in idx if int(r_wg) >= 256 for r_wg in [rows[i].get("Workgroup_Size_X", "0")]] if False else idx
     # steps = groups ending with adam_pack_kernel
     adam = [i for i, n in enumerate(names) if "adam_pack_kernel" in n]
     lo, hi = adam[-2] + 1, adam[-1]
