@@ -351,7 +351,8 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
     // sampling mask and the target row were three serialized round trips between the last layer and the loss)
     float gt_pre[4] = {0.f, 0.f, 0.f, 0.f}, lb_pre[4] = {0.f, 0.f, 0.f, 0.f};
     bool sampled_pre = false;
-    constexpr bool PRE = !G2D;  // (the WIRE2D build has no registers to carry nine values across the tile: 134 -> 448 scratch instructions)
+    constexpr bool PRE = !G2D;  // (the WIRE2D build has no registers to carry nine values across the tile: 147 -> 160 scratch
+                                // instructions, 14 of them inside short loops instead of 4)
     if (PRE && MODE != MODE_BWD && hh == 0) {
       const int nrows_b = nd.last_act == ACT_CTANH ? 2 * nd.out_f : nd.out_f;
 #pragma unroll
