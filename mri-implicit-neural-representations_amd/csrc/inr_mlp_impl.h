@@ -457,7 +457,9 @@ __device__ __forceinline__ void load_oq(float (&zo)[4], float (&zq)[4], const fl
 }
 
 // SAVE: 0 nothing, 1 h and the activation's derivative terms, 2 the derivative terms only (the fused step's last hidden
-// layer: its h is only ever read by the last layer's dW, which re-activates z from the LDS images -- dw_rows4_valu)
+// layer: its h is only ever read by the last layer's dW, which re-activates z from the LDS images -- dw_rows4_valu).
+// fwd_layer also takes 3 / 4: everything, but only for the even / odd groups of 8 rows -- the two waves of a pair
+// (inr_mlp_wide_impl.h) both form the whole lazy activation and share the stash: each writes half of it
 template <int NBOUT, int TL, int HACT, int SAVE, bool ALDS = false, bool ZSTASH = false, class AP = AFragPtr>
 __device__ __forceinline__ void fwd_group(f32x16 (&acc)[NBOUT], const f32x4 (&a_use)[NBOUT],
                                           f32x4 (&a_load)[NBOUT], const AP& p_next, float (&z_buf)[4],
@@ -549,9 +551,11 @@ __device__ __forceinline__ void fwd_layer(f32x16 (&acc)[NBOUT], const float* R, 
   for (int s4 = 0; s4 < n4; s4 += 2) {
     const int n2 = (s4 + 2 < n4) ? (s4 + 2) : s4;
     const int n3 = (s4 + 3 < n4) ? (s4 + 3) : s4;
-    fwd_group<NBOUT, TL, HACT, SAVE, ALDS, ZSTASH, decltype(p)>(acc, A0, A1, p + (size_t)(s4 + 1) * gstride, Z, ZP, ZO, ZQ, Rcol, n2, s4, ap,
+    constexpr int SA = SAVE <= 2 ? SAVE : (SAVE == 3 ? 1 : 0);  // group s4 (even)
+    constexpr int SB = SAVE <= 2 ? SAVE : (SAVE == 4 ? 1 : 0);  // group s4 + 1 (odd)
+    fwd_group<NBOUT, TL, HACT, SA, ALDS, ZSTASH, decltype(p)>(acc, A0, A1, p + (size_t)(s4 + 1) * gstride, Z, ZP, ZO, ZQ, Rcol, n2, s4, ap,
                                            half, svl, hsz, rs, voff, H0, D0, E0, F0, G0, H1, D1, E1, F1, G1);
-    fwd_group<NBOUT, TL, HACT, SAVE, ALDS, ZSTASH, decltype(p)>(acc, A1, A0, p + (size_t)n2 * gstride, Z, ZP, ZO, ZQ, Rcol, n3, s4 + 1, ap,
+    fwd_group<NBOUT, TL, HACT, SB, ALDS, ZSTASH, decltype(p)>(acc, A1, A0, p + (size_t)n2 * gstride, Z, ZP, ZO, ZQ, Rcol, n3, s4 + 1, ap,
                                            half, svl, hsz, rs, voff, H1, D1, E1, F1, G1, H0, D0, E0, F0, G0);
   }
 }

@@ -422,6 +422,10 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
         f32x16 acc2[G2D ? MT : 1];
         if (EAGER)  // plain GEMM on the activations in the image
           bwd_dx<MT, TL, false, false, NB>(acc, R, a.packed + Ll.pf_off + aoff, NB * 32, nullptr, wcol, lane);
+        else if (saving && !G2D && hh == 0)  // both waves of the pair form every activation: each stashes half the groups
+          fwd_layer<NB, MT, TL, HACT, 3, NB>(acc, R, a.packed + Ll.pf_off + aoff, ap, sh, wcol, lane);
+        else if (saving && !G2D)
+          fwd_layer<NB, MT, TL, HACT, 4, NB>(acc, R, a.packed + Ll.pf_off + aoff, ap, sh, wcol, lane);
         else if (stash)
           fwd_layer<NB, MT, TL, HACT, true, NB>(acc, R, a.packed + Ll.pf_off + aoff, ap, sh, wcol, lane);
         else
