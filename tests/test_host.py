@@ -63,6 +63,21 @@ def test_bf16_kernel_inline_asm_memory_hazards():
     assert " 0 touch a register in flight" in r.stdout and " 0 vector-memory instructions read an SGPR" in r.stdout
 
 
+def test_no_valu_sgpr_to_vmem_hazard_in_any_kernel():
+    """The same SGPR hazard check over every built kernel object (compiler-generated memory instructions are padded by
+    the compiler; this guards the ones it cannot see and costs ten seconds)."""
+    import glob
+    import subprocess
+    import sys
+    objs = sorted(glob.glob(os.path.join(ROOT, "mri-implicit-neural-representations_amd", "build", "inr_*.o")))
+    if not objs or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("needs the built objects and llvm-objdump")
+    for obj in objs:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_inflight_regs.py"), obj, "kernel",
+                            "--sgpr-only"], capture_output=True, text=True)
+        assert r.returncode == 0, os.path.basename(obj) + "\n" + r.stdout + r.stderr
+
+
 def test_plan_validation_and_sizes():
     from inr_mi355x import _lib as L
     lib = L.load()
