@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define INR_ABI_VERSION 4
+#define INR_ABI_VERSION 5
 
 /* error codes */
 #define INR_OK 0
@@ -178,6 +178,14 @@ int inr_plan_launch_dims(const inr_plan* plan, int64_t B, int64_t* n_tiles, int6
  * (inr_sizes.step_save_by_tile), n_blocks otherwise -- and the number of slabs (of slab_floats) behind `slabs` for
  * the step and backward entry points: n_blocks, plus one per K-chunk of that GEMM. */
 int inr_plan_workspace(const inr_plan* plan, int64_t B, int64_t* step_save_slots, int64_t* n_slabs);
+/* INR_PRECISION_BF16 plans (v5).  Their backward pass stashes dZ in 8 bits under a power-of-two scale that follows the
+ * gradient's magnitude from step to step; the eight words of that state live on the device with the plan (layout:
+ * csrc/inr_w2.h -- [0..3] fused steps, [4..7] split steps: next scale, bits of the last step's largest scaled |dZ|, the
+ * factor the last step multiplied d(loss)/d(out) by, the scale inside it).  This call waits for the work queued on
+ * `stream` and copies them to host_out[8]: for tests and diagnostics (no reference counterpart).  Because of this state a
+ * bf16 plan is to be stepped from one stream at a time; the plan's first step of a kind, and a step whose loss or batch
+ * size makes the remembered scale meaningless, runs the kernel twice (once to find the scale). */
+int inr_plan_grad_scale_state(const inr_plan* plan, float* host_out, void* stream);
 
 /* Re-orders flat params into the MFMA A-fragment image the kernels stream (no reference
  * counterpart: it is what `model.to(device)` + ATen's GEMM packing do implicitly). */

@@ -61,7 +61,52 @@ struct inr_plan {
   mutable std::mutex side_mu;
   mutable hipStream_t side = nullptr;
   mutable int side_dev = -1;
+  // bf16 plans: the gradient-scale state of the 8-bit stash (inr_w2.h), W2_STATE_FLOATS floats on the device, allocated
+  // with the plan; what the host remembers about it: whether a kind of step (0 fused, 1 split) has been calibrated, and
+  // for which batch size / loss.  One stream at a time may step a bf16 plan.
+  mutable float* dz_state = nullptr;
+  mutable int dz_dev = -1;
+  mutable bool dz_ready[2] = {false, false};
+  mutable int64_t dz_rows[2] = {0, 0};
+  mutable int dz_loss[2] = {-1, -1};
 };
+
+// gradient-scale state of a bf16 plan on the current device (inr_w2.h): S = mult = S_used = 1, amax = 0 for both kinds of
+// step.  Allocated with the plan; moved if the plan is later driven on another device.
+static float* dz_state_alloc(const inr_plan* p) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  if (p->dz_state != nullptr && p->dz_dev == dev) return p->dz_state;
+  if (p->dz_state != nullptr) (void)hipFree(p->dz_state);
+  p->dz_state = nullptr;
+  p->dz_ready[0] = p->dz_ready[1] = false;
+  const float init[W2_STATE_FLOATS] = {1.f, 0.f, 1.f, 1.f, 1.f, 0.f, 1.f, 1.f};
+  if (hipMalloc(reinterpret_cast<void**>(&p->dz_state), sizeof(init)) != hipSuccess) {
+    p->dz_state = nullptr;
+    return nullptr;
+  }
+  if (hipMemcpy(p->dz_state, init, sizeof(init), hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipFree(p->dz_state);
+    p->dz_state = nullptr;
+    return nullptr;
+  }
+  p->dz_dev = dev;
+  return p->dz_state;
+}
+
+// Does this call have to find its gradient scale first (a pass of the kernel whose stash nobody reads, then the roll)?
+// Yes for a plan's first step of a kind, and when what the remembered scale was derived from no longer applies: another
+// loss (fused steps normalise the batch size away, not the loss), or -- split steps, whose d(loss)/d(out) carries the
+// 1 / count -- a batch more than twice or less than half as large.  From then on the scale follows the gradient from step
+// to step (dz_state_roll) with 2^7.8 of headroom.
+static bool dz_needs_calibration(const inr_plan* p, int kind, int64_t rows, int loss_kind) {
+  const bool need = !p->dz_ready[kind] || (kind == 0 ? p->dz_loss[0] != loss_kind
+                                                      : (rows > 2 * p->dz_rows[1] || 2 * rows < p->dz_rows[1]));
+  p->dz_ready[kind] = true;
+  p->dz_rows[kind] = rows;
+  p->dz_loss[kind] = loss_kind;
+  return need;
+}
 
 // Multiplicative filter networks (models/mfn.py).  L[] = filters 0..n | linears 0..n-1 | heads; flat
 // parameters keep the state_dict order  linear.* , output_linear(.k).* , filters.*  (SURVEY Appendix B).
@@ -290,9 +335,11 @@ int inr_plan_create(const inr_net_desc* d, inr_plan** out) {
   if (d->precision != INR_PRECISION_F32 && d->precision != INR_PRECISION_BF16)
     return fail(INR_ERR_INVALID, "inr_plan_create: precision %d", d->precision);
   if (d->precision == INR_PRECISION_BF16 &&
-      (d->kind != INR_KIND_SIREN || d->input != INR_INPUT_GAUSS || NB != 8 || (d->enc_size % 8) != 0))
-    return fail(INR_ERR_UNSUPPORTED, "inr_plan_create: the bf16 path is built for SIREN with the fused gauss encoder "
-                "and hidden width 129..256 (got kind %d, input %d, width %d)", d->kind, d->input, d->width);
+      (d->kind != INR_KIND_SIREN || d->input != INR_INPUT_GAUSS || NB != 8 || (d->enc_size % 32) != 0 || D < 3 || D > 8 ||
+       d->enc_size > 512))
+    return fail(INR_ERR_UNSUPPORTED, "inr_plan_create: the bf16 path is built for SIREN with the fused gauss encoder, "
+                "hidden width 129..256, 3 to 8 layers and an encoder size that is a multiple of 32 up to 512 (got kind %d, input "
+                "%d, width %d, depth %d, enc_size %d)", d->kind, d->input, d->width, d->depth, d->enc_size);
 
   inr_plan* p = new (std::nothrow) inr_plan();
   if (p == nullptr) return fail(INR_ERR_INVALID, "inr_plan_create: out of host memory");
@@ -363,34 +410,42 @@ int inr_plan_create(const inr_net_desc* d, inr_plan** out) {
     goff += (last ? L.M : NB * 32) * L.K;
     L.gb_off = goff;
     goff += last ? L.M : NB * 32;
-    L.pf_off = (int)pk;
-    pk += (int64_t)L.Kpad8 * L.Mblk * 32;  // (Kpad8/8 groups) x Mblk x 64 lanes x 4
-    if (l >= 1) {
-      L.pb_off = (int)pk;
-      pk += (int64_t)L.Mpad8 * L.Kblk * 32;
+    if (nd.bf16) {  // bf16 plans keep one image set only: the panel stream behind the layers (below)
+      L.pf_off = L.pb_off = L.pbias_off = -1;
     } else {
-      L.pb_off = -1;
+      L.pf_off = (int)pk;
+      pk += (int64_t)L.Kpad8 * L.Mblk * 32;  // (Kpad8/8 groups) x Mblk x 64 lanes x 4
+      if (l >= 1) {
+        L.pb_off = (int)pk;
+        pk += (int64_t)L.Mpad8 * L.Kblk * 32;
+      } else {
+        L.pb_off = -1;
+      }
+      L.pbias_off = (int)pk;
+      pk += L.Mblk * 32;
     }
-    L.pbias_off = (int)pk;
-    pk += L.Mblk * 32;
     L.live = 1;
     L.korder = (first && d->input == INR_INPUT_GAUSS) ? 1 : 0;
   }
   nd.P = poff;
   nd.slab_loss_off = goff;
   nd.slab_floats = round_up(goff + 4, 64);
-  const int ns = wire2d ? 7 : (wire ? 3 : (nd.bf16 ? 1 : 2));  // bf16: z only (act / act' are recomputed)
+  const int ns = wire2d ? 7 : (wire ? 3 : 2);
   nd.save_floats_per_tile = ns * (D - 1) * NB * 32 * TL + 4 * TL +
                             (d->input == INR_INPUT_GAUSS ? nd.L[0].Kblk * 32 * TL : 0) +
                             (wire2d ? NB * 32 * TL : 0);  // WIRE2D: copy of a layer's output gradient
   nd.w2_off = nd.w2_bias_off = -1;
-  if (nd.bf16 && (d->enc_size % 32) == 0 && D <= 8) {
-    // second image set of the bf16 plans: the "weights in LDS" chunk stream of the fused step (inr_w2.h) + fp32 biases
-    pk = (pk + 3) & ~(int64_t)3;  // 16-byte aligned: the chunks are read by 16-byte LDS-DMA pieces
-    nd.w2_off = (int)pk;
-    pk += (int64_t)w2_nq(D, d->enc_size) * W2_CHUNK_FLOATS;
+  if (nd.bf16) {
+    // the images of the bf16 plans: the "weight panels in LDS" stream (inr_w2.h) + fp32 biases; 8-bit stash
+    nd.w2_off = (int)pk;  // (0: 16-byte aligned, the panels are read by 16-byte LDS-DMA pieces)
+    pk += (int64_t)w2_np(D, d->enc_size) * W2_PANEL_FLOATS;
     nd.w2_bias_off = (int)pk;
     pk += (int64_t)D * 256;
+    nd.save_floats_per_tile = w2_stash_dwords(D);
+    if (dz_state_alloc(p) == nullptr) {
+      delete p;
+      return fail(INR_ERR_HIP, "inr_plan_create: no device memory for the gradient-scale state");
+    }
   }
   p->packed_floats = pk;
   *out = p;
@@ -399,6 +454,7 @@ int inr_plan_create(const inr_net_desc* d, inr_plan** out) {
 
 int inr_plan_destroy(inr_plan* plan) {
   if (plan != nullptr && plan->side != nullptr) (void)hipStreamDestroy(plan->side);
+  if (plan != nullptr && plan->dz_state != nullptr) (void)hipFree(plan->dz_state);
   delete plan;
   return INR_OK;
 }
@@ -489,30 +545,28 @@ static bool dw_gemm_setup(const inr_plan* plan, int64_t nt, inr::DwGemmArgs* g, 
 }
 
 // bf16 plans with the "weights in LDS" fused kernel: every weight gradient comes from inr_dw_gemm_bf16.hip
-static bool w2_plan(const inr_plan* plan) { return plan->nd.bf16 && plan->nd.w2_off >= 0; }
+static bool w2_plan(const inr_plan* plan) { return plan->nd.bf16 != 0; }
 
 static void dw_gemm_bf16_setup(const inr_plan* plan, int64_t nt, inr::DwGemmBf16Args* g) {
   const NetDesc& nd = plan->nd;
   memset(g, 0, sizeof(*g));
-  const int D = nd.D, T = 256 * 128 / 2;  // dwords per stashed 2-byte tensor [256 rows][128 coordinates]
-  const float inv2pi = 0.15915494309189535f;
+  const int D = nd.D;
   int k = 0;
   for (int n0 = 0; n0 < nd.L[0].K; n0 += 256) {  // first layer: B = encoder features, 2E columns
     inr::DwGemmBf16Unit& u = g->unit[k++];
-    u.dz_off = (D - 1) * T, u.z_off = -1, u.krev = 0.f;
+    u.dz_off = w2_stash_G(0, D), u.z_off = -1;
     u.gw_off = nd.L[0].gw_off, u.gb_off = nd.L[0].gb_off, u.M = 256, u.K = nd.L[0].K, u.n0 = n0;
   }
   for (int l = 1; l <= D - 1; ++l) {
     inr::DwGemmBf16Unit& u = g->unit[k++];
     const bool last = l == D - 1;
-    u.dz_off = last ? 2 * (D - 1) * T : (D - 1 + l) * T;
-    u.z_off = (l - 1) * T;
-    u.krev = nd.L[l - 1].omega * inv2pi;
+    u.dz_off = last ? w2_stash_dzl(D) : w2_stash_G(l, D);
+    u.z_off = w2_stash_P(l - 1);
     u.gw_off = nd.L[l].gw_off, u.gb_off = nd.L[l].gb_off;
     u.M = last ? nd.L[l].M : 256, u.K = nd.L[l].K, u.n0 = 0;
   }
   g->n_units = k;
-  g->TL = 128, g->E = nd.E;
+  g->TL = W2_TL, g->E = nd.E;
   g->save_floats_per_tile = nd.save_floats_per_tile, g->slab_floats = nd.slab_floats, g->n_tiles = (int)nt;
   const int target = std::max(1, 256 / k);  // about one workgroup per CU
   g->tiles_per_chunk = (int)((nt + target - 1) / target);
@@ -667,6 +721,16 @@ int inr_plan_workspace(const inr_plan* plan, int64_t B, int64_t* step_save_slots
   return INR_OK;
 }
 
+int inr_plan_grad_scale_state(const inr_plan* plan, float* host_out, void* stream) {
+  if (plan == nullptr || host_out == nullptr) return fail(INR_ERR_INVALID, "inr_plan_grad_scale_state: null argument");
+  if (!plan->nd.bf16 || plan->dz_state == nullptr)
+    return fail(INR_ERR_INVALID, "inr_plan_grad_scale_state: not an INR_PRECISION_BF16 plan");
+  hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+  if (e == hipSuccess) e = hipMemcpy(host_out, plan->dz_state, W2_STATE_FLOATS * sizeof(float), hipMemcpyDeviceToHost);
+  if (e != hipSuccess) return hip_fail(e, "inr_plan_grad_scale_state");
+  return INR_OK;
+}
+
 int inr_plan_launch_dims(const inr_plan* plan, int64_t B, int64_t* n_tiles, int64_t* n_blocks) {
   if (plan == nullptr || n_tiles == nullptr || n_blocks == nullptr)
     return fail(INR_ERR_INVALID, "inr_plan_launch_dims: null argument");
@@ -674,7 +738,7 @@ int inr_plan_launch_dims(const inr_plan* plan, int64_t B, int64_t* n_tiles, int6
   const int tl = 32 * plan->nd.NW;
   *n_tiles = (B + tl - 1) / tl;
   *n_blocks = *n_tiles < kMaxBlocks ? *n_tiles : kMaxBlocks;
-  if (plan->nd.bf16 && plan->nd.w2_off >= 0) {  // the fused bf16 kernel's workgroups take two 128-coordinate tiles each
+  if (plan->nd.bf16) {  // the bf16 kernel's workgroups take two 128-coordinate tiles each
     const int64_t wt = *n_tiles > kMaxBlocks ? (*n_tiles + 1) / 2 : *n_tiles;  // (one each while that fills fewer CUs)
     *n_blocks = wt < kMaxBlocks ? wt : kMaxBlocks;
   }
@@ -706,10 +770,8 @@ static int launch(const inr_plan* plan, const LossDesc& ld, const inr::MlpArgs& 
       case 8: e = inr::launch_wire_nb8(nd, ld, a, mode, grid, st); break;
       default: e = inr::launch_wire_nb12(nd, ld, a, mode, grid, st); break;
     }
-  else if (nd.bf16 && mode == 2 && nd.w2_off >= 0)
-    e = inr::launch_siren_bf16(nd, ld, a, grid, st);  // fused step: weights in LDS, dW by inr_dw_gemm_bf16.hip
   else if (nd.bf16)
-    e = inr::launch_mlp_nb8_bf16(nd, ld, a, mode, grid, st);
+    e = inr::launch_siren_bf16(nd, ld, a, mode, grid, st);  // weight panels in LDS, dW by inr_dw_gemm_bf16.hip
   else
     switch (nd.NB) {
       case 1: e = inr::launch_mlp_nb1(nd, ld, a, mode, grid, st); break;
@@ -758,9 +820,8 @@ int inr_forward(const inr_plan* plan, const float* params, const float* packed, 
   if (plan->nd.mfn_n > 0) return fail(INR_ERR_INVALID, "inr_forward: multiplicative-filter plans use inr_forward_multi");
   if (plan->nd.input == IN_GAUSS && enc_B == nullptr) return fail(INR_ERR_INVALID, "inr_forward: enc_B is null");
   float* save = ws != nullptr ? ws->save : nullptr;
-  if ((plan->nd.hact == ACT_GABOR2D || plan->nd.bf16) && save == nullptr)
-    return fail(INR_ERR_INVALID, "inr_forward: WIRE2D and bf16 plans need a save buffer (n_tiles * "
-                "save_floats_per_tile floats)");
+  if (plan->nd.hact == ACT_GABOR2D && save == nullptr)
+    return fail(INR_ERR_INVALID, "inr_forward: WIRE2D plans need a save buffer (n_tiles * save_floats_per_tile floats)");
   if (B <= 0) return fail(INR_ERR_INVALID, "inr_forward: B = %lld", (long long)B);
   int64_t nt, nb;
   inr_plan_launch_dims(plan, B, &nt, &nb);
@@ -812,6 +873,7 @@ static int finish_gradients(const inr_plan* plan, const inr::MlpArgs& a, int64_t
     g.coords = a.x;
     g.encB = a.encB;
     g.B = a.B;
+    g.dz_state = a.dz_state + (a.dout != nullptr ? 4 : 0);  // split steps keep their own scale
     hipError_t e = inr::launch_dw_gemm_bf16(g, st);
     if (e != hipSuccess) return hip_fail(e, (std::string(who) + ": bf16 weight-gradient GEMM").c_str());
     split.lo = 0, split.hi = (plan->nd.P + 3) & ~3, split.n2 = g.n_chunks;  // (a multiple of 4: the fast reduction works on float4)
@@ -856,9 +918,19 @@ int inr_backward(const inr_plan* plan, const float* params, const float* packed,
   a.B = B;
   a.n_tiles = (int)nt;
   a.save_by_block = 0;
-  a.dw_gemm = dw_gemm_plan(plan) ? 1 : 0;
+  a.dw_gemm = w2_plan(plan) ? 2 : (dw_gemm_plan(plan) ? 1 : 0);
   LossDesc ld;
   memset(&ld, 0, sizeof(ld));
+  if (w2_plan(plan)) {
+    a.dz_state = dz_state_alloc(plan);
+    if (a.dz_state == nullptr) return fail(INR_ERR_HIP, "inr_backward: no gradient-scale state on this device");
+    if (dz_needs_calibration(plan, 1, B, 0)) {  // a pass for the scale (the forward half's stash is not touched)
+      int rc = launch(plan, ld, a, 1, (int)nb, (hipStream_t)stream);
+      if (rc != INR_OK) return rc;
+      hipError_t e = inr::launch_dz_roll(a.dz_state + 4, (hipStream_t)stream);
+      if (e != hipSuccess) return hip_fail(e, "inr_backward: gradient-scale calibration");
+    }
+  }
   int rc = launch(plan, ld, a, 1, (int)nb, (hipStream_t)stream);
   if (rc != INR_OK) return rc;
   return finish_gradients(plan, a, nt, nb, grads, nullptr, params, packed, (hipStream_t)stream, "inr_backward");
@@ -871,6 +943,12 @@ static int run_fused_step(const inr_plan* plan, const LossDesc& ld, const inr::M
   StepSchedule sc;
   hipStream_t side = nullptr;
   if (grads != nullptr && a.dw_gemm == 1 && step_schedule(plan, nt, nb, &sc) && sc.split) side = side_stream(plan);
+  if (a.dw_gemm == 2 && dz_needs_calibration(plan, 0, a.B, ld.kind)) {  // bf16: a pass of the kernel for the scale
+    int rc = launch(plan, ld, a, 2, (int)nb, st);
+    if (rc != INR_OK) return rc;
+    hipError_t e = inr::launch_dz_roll(a.dz_state, st);
+    if (e != hipSuccess) return hip_fail(e, (std::string(who) + ": gradient-scale calibration").c_str());
+  }
   if (side == nullptr) {
     int rc = launch(plan, ld, a, 2, (int)nb, st);
     if (rc != INR_OK) return rc;
@@ -1016,6 +1094,10 @@ static int train_step_impl(const inr_plan* plan, const inr_loss_desc* loss, cons
   a.n_tiles = (int)nt;
   a.dw_gemm = w2_plan(plan) ? 2 : (dw_gemm_plan(plan) ? 1 : 0);
   a.save_by_block = a.dw_gemm ? 0 : 1;
+  if (a.dw_gemm == 2) {
+    a.dz_state = dz_state_alloc(plan);
+    if (a.dz_state == nullptr) return fail(INR_ERR_HIP, "inr_train_step: no gradient-scale state on this device");
+  }
 #ifdef INR_STAMPS
   a.dbg = g_stamp_buf;
   a.dbg_cap = g_stamp_cap;

@@ -214,83 +214,8 @@ __global__ __launch_bounds__(64) void gabor_m2_kernel(const NetDesc nd, const fl
   if (lane == 0) packed[L.pbias_off + nd.NB * 32 + j] = s;
 }
 
-// bf16 plans: slab entries are bf16 at the fp32 layout's element offsets (inr_mlp_bf16_impl.h); sums in fp32,
-// 4 entries (8 bytes) per lane per slab and 8 slabs in flight, fixed tree as above (the kernel is latency-bound:
-// it needs as many workgroups and outstanding loads as the fp32 one to reach the same bytes per second).
-__global__ __launch_bounds__(256) void reduce_slabs_bf16_kernel(const float* __restrict__ slabs, int n_blocks,
-                                                                int slab_floats, int P, int loss_off,
-                                                                float* __restrict__ grads,
-                                                                float* __restrict__ loss_out) {
-  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-  __shared__ f32x4 part[4][64];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int i4 = (blockIdx.x * 64 + lane) * 4;
-  const int per = (n_blocks + 3) / 4;
-  const int b0 = w * per, b1 = (b0 + per < n_blocks) ? b0 + per : n_blocks;
-  f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  if (i4 < P) {
-    int b = b0;
-    for (; b + 8 <= b1; b += 8) {
-      bf16x4 v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        v[u] = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(slabs + (size_t)(b + u) * slab_floats) + i4);
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) s[j] += (float)v[u][j];
-    }
-    for (; b < b1; ++b) {
-      const bf16x4 v = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(slabs + (size_t)b * slab_floats) + i4);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) s[j] += (float)v[j];
-    }
-  }
-  part[w][lane] = s;
-  __syncthreads();
-  if (w == 0 && i4 < P) {
-    const f32x4 t = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
-    for (int j = 0; j < 4 && i4 + j < P; ++j) grads[i4 + j] = t[j];
-  }
-  if (loss_out != nullptr && blockIdx.x == gridDim.x - 1) loss_words_sum(slabs, n_blocks, (size_t)slab_floats, loss_off, loss_out);
-}
-
-// same for zero-padded widths (slab rows are whole 32-row blocks, so element offsets differ from flat offsets)
-__global__ __launch_bounds__(256) void reduce_slabs_bf16_any_kernel(const NetDesc nd, const float* __restrict__ slabs,
-                                                                    int n_blocks, float* __restrict__ grads,
-                                                                    float* __restrict__ loss_out) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  const int sf = nd.slab_floats;
-  if (i < nd.P) {
-    int l;
-    VirtualPos vp;
-    float s = 0.f;
-    if (locate(nd, i, l, vp)) {
-      const LayerDesc& L = nd.L[l];
-      const size_t o = vp.n >= 1 ? (size_t)L.gw_off + (size_t)vp.row[0] * L.K + vp.col[0] : (size_t)L.gb_off + vp.bias_row;
-      for (int b = 0; b < n_blocks; ++b) s += (float)reinterpret_cast<const __bf16*>(slabs + (size_t)b * sf)[o];
-    }
-    grads[i] = s;
-  }
-  if (loss_out != nullptr && blockIdx.x == gridDim.x - 1) loss_words_sum(slabs, n_blocks, (size_t)sf, nd.slab_loss_off, loss_out);
-}
-
 hipError_t launch_reduce_slabs(const NetDesc& nd, const float* slabs, int n_blocks, float* grads, float* loss_out,
                                const float* params, const float* packed, hipStream_t st, SlabSplit split) {
-  if (nd.bf16 && split.n2 == 0) {  // unfused bf16 backward: bf16 slabs of the first bf16 kernel
-    bool same = true;  // slab element offsets == flat offsets (hidden width = whole row blocks, e.g. 256)
-    for (int l = 0; l < nd.ND; ++l) same = same && nd.L[l].gw_off == nd.L[l].w_off && nd.L[l].gb_off == nd.L[l].b_off;
-    if (same) {
-      const int grid = (nd.P + 255) / 256;
-      hipLaunchKernelGGL(reduce_slabs_bf16_kernel, dim3(grid + 1), dim3(256), 0, st, slabs, n_blocks, nd.slab_floats, nd.P,
-                         nd.slab_loss_off, grads, loss_out);
-    } else {
-      const int grid = (nd.P + 255) / 256;
-      hipLaunchKernelGGL(reduce_slabs_bf16_any_kernel, dim3(grid + 1), dim3(256), 0, st, nd, slabs, n_blocks, grads,
-                         loss_out);
-    }
-    return hipGetLastError();
-  }
   bool all_real = true;  // ... and slab layout == flat layout (not the case for MFN: L[] order != flat order)
   for (int l = 0; l < nd.ND; ++l) all_real = all_real && nd.L[l].ltype == LT_REAL && nd.L[l].gw_off == nd.L[l].w_off;
   if (all_real && ((split.lo | split.hi) & 3) == 0 && split.mask == 0) {  // slab offsets == flat offsets; slab_floats % 64 == 0 keeps every slab 16-byte aligned
@@ -312,13 +237,6 @@ hipError_t launch_reduce_slabs(const NetDesc& nd, const float* slabs, int n_bloc
 // re-pack of every weight into the two MFMA A-fragment images and of every bias into its padded
 // bias image.  do_update == 0: pack only.
 // ---------------------------------------------------------------------------------------------
-// bf16 images (nd.bf16): same (k-step s, lane-half h) decomposition, eight k-steps per fragment:
-// element ((s>>3) * blocks + block) * 64 + h*32 + lane_row) * 8 + (s & 7) of a bf16 array that starts where
-// the layer's fp32 image would (it needs at most the same bytes).
-__device__ __forceinline__ void put_bf16(float* packed, int off_floats, size_t idx, float v) {
-  reinterpret_cast<__bf16*>(packed + off_floats)[idx] = (__bf16)v;
-}
-
 __device__ __forceinline__ void put_fwd(const NetDesc& nd, const LayerDesc& L, int l, float* packed, int row, int k,
                                         float v) {
   int h, s;
@@ -329,10 +247,6 @@ __device__ __forceinline__ void put_fwd(const NetDesc& nd, const LayerDesc& L, i
     h = k & 1;
     s = k >> 1;
   }
-  if (nd.bf16) {
-    put_bf16(packed, L.pf_off, ((size_t)((s >> 3) * L.Mblk + (row >> 5)) * 64 + h * 32 + (row & 31)) * 8 + (s & 7), v);
-    return;
-  }
   packed[L.pf_off + ((size_t)((s >> 2) * L.Mblk + (row >> 5)) * 64 + h * 32 + (row & 31)) * 4 + (s & 3)] = v;
 }
 
@@ -341,32 +255,36 @@ __device__ __forceinline__ void put_tr(const LayerDesc& L, float* packed, int ro
   packed[L.pb_off + ((size_t)((s >> 2) * L.Kblk + (k >> 5)) * 64 + h * 32 + (k & 31)) * 4 + (s & 3)] = v;
 }
 
-__device__ __forceinline__ void put_tr_bf16(const LayerDesc& L, float* packed, int row, int k, float v) {
-  const int h = row & 1, s = row >> 1;
-  put_bf16(packed, L.pb_off, ((size_t)((s >> 3) * L.Kblk + (k >> 5)) * 64 + h * 32 + (k & 31)) * 8 + (s & 7), v);
+// "Weight panels in LDS" images of the bf16 path (inr_siren_bf16_impl.h; layout and the constant factors that ride in the
+// images: inr_w2.h): weight W_l[row][k] goes into the forward panels of layer l -- times w0 / 2 pi for the sine layers, so
+// that their accumulators are phases in revolutions -- and, for l >= 1, into the transposed panels (out index = k,
+// contraction index = row) times the w0 of the layer below; biases into the fp32 table, scaled like their weights.
+// Plain SIREN plans only (every layer LT_REAL, hidden rows = 256 padded).
+__device__ __forceinline__ float w2_krev(const NetDesc& nd, int l) {
+  return l < nd.D - 1 ? nd.L[l].omega * 0.15915494309189535f : 1.0f;
 }
-
-// "weights in LDS" images of the bf16 fused step (inr_siren_bf16_impl.h; layout: inr_w2.h): weight W_l[row][k] goes
-// into the forward chunk image of layer l and, for l >= 1, into the transposed image (out index = k, contraction
-// index = row); biases into the fp32 table.  Plain SIREN plans only (every layer LT_REAL, hidden rows = 256 padded).
 __device__ __forceinline__ void put_w2(const NetDesc& nd, int l, float* packed, int row, int k, float v) {
   __bf16* img = reinterpret_cast<__bf16*>(packed + nd.w2_off);
+  const int D = nd.D, E = nd.E;
   int t, h, j;
-  if (l == 0) {  // gauss features: K-step t = sines (half 0) / cosines (half 1) of features 8t .. 8t+7
-    h = k >= nd.E;
-    const int kk = h ? k - nd.E : k;
+  if (l == 0) {  // gauss features: K-step t = sines (half 0) / cosines (half 1) of features 8t .. 8t+7; two K-steps per panel
+    h = k >= E;
+    const int kk = h ? k - E : k;
     t = kk >> 3;
     j = kk & 7;
+    img[w2_index(t >> 1, (t & 1) * 8 + (row >> 5), h * 32 + (row & 31), j)] = (__bf16)(v * w2_krev(nd, 0));
   } else {
     w2_kperm_inv(k, t, h, j);
-  }
-  if (l == nd.D - 1)  // last layer (rows < 32): its 16 K-steps x 1 row block in one chunk
-    img[w2_index_last(w2_qf(l, nd.D, nd.E), t, h * 32 + row, j)] = (__bf16)v;
-  else
-    img[w2_index(w2_qf(l, nd.D, nd.E) + (t >> 2), t & 3, row >> 5, h * 32 + (row & 31), j)] = (__bf16)v;
-  if (l >= 1) {
+    if (l == D - 1)  // last layer (rows < 32): one panel, its 16 K-steps
+      img[w2_index(w2_p_last(D, E), t, h * 32 + row, j)] = (__bf16)v;
+    else
+      img[w2_index(w2_p_fwd(l, E) + (row >> 5), t, h * 32 + (row & 31), j)] = (__bf16)(v * w2_krev(nd, l));
     w2_kperm_inv(row, t, h, j);
-    img[w2_index(w2_qt(l, nd.D, nd.E) + (t >> 2), t & 3, k >> 5, h * 32 + (k & 31), j)] = (__bf16)v;
+    const float vt = v * nd.L[l - 1].omega;
+    if (l == D - 1)  // one K-step (rows < 4: t = 0), eight row blocks
+      img[w2_index(w2_p_lastT(D, E), k >> 5, h * 32 + (k & 31), j)] = (__bf16)vt;
+    else
+      img[w2_index(w2_p_T(l, D, E) + (k >> 5), t, h * 32 + (k & 31), j)] = (__bf16)vt;
   }
 }
 
@@ -407,18 +325,20 @@ __device__ __forceinline__ void adam_pack_entry(const NetDesc& nd, int i, float 
       const int off = i - L.w_off;
       if (off >= 0 && off < L.wn) {
         const int row = off / L.K, k = off - row * L.K;
-        put_fwd(nd, L, l, packed, row, k, p);
-        if (L.pb_off >= 0) {
-          if (nd.bf16) put_tr_bf16(L, packed, row, k, p);
-          else put_tr(L, packed, row, k, p);
+        if (nd.bf16) {  // bf16 plans keep the panel stream only
+          put_w2(nd, l, packed, row, k, p);
+          return;
         }
-        if (nd.bf16 && nd.w2_off >= 0) put_w2(nd, l, packed, row, k, p);
+        put_fwd(nd, L, l, packed, row, k, p);
+        if (L.pb_off >= 0) put_tr(L, packed, row, k, p);
         return;
       }
       const int ob = i - L.b_off;
       if (ob >= 0 && ob < L.bn) {
-        packed[L.pbias_off + ob] = p;
-        if (nd.bf16 && nd.w2_off >= 0) packed[nd.w2_bias_off + l * 256 + ob] = p;
+        if (nd.bf16)
+          packed[nd.w2_bias_off + l * 256 + ob] = p * w2_krev(nd, l);
+        else
+          packed[L.pbias_off + ob] = p;
         return;
       }
     }
@@ -513,7 +433,7 @@ hipError_t launch_adam_pack(const NetDesc& nd, float* params, const float* grads
 hipError_t launch_reduce_slabs_adam(const NetDesc& nd, const float* slabs, int n_blocks, float* grads, float* loss_out,
                                     float* params, float* m1, float* m2, float* packed, const AdamArgs& aa_in,
                                     hipStream_t st, SlabSplit split) {
-  bool flat = !(nd.bf16 && split.n2 == 0) && ((split.lo | split.hi) & 3) == 0 && split.mask == 0 && !nd.gabor;
+  bool flat = ((split.lo | split.hi) & 3) == 0 && split.mask == 0 && !nd.gabor;
   for (int l = 0; l < nd.ND; ++l) flat = flat && nd.L[l].ltype == LT_REAL && nd.L[l].gw_off == nd.L[l].w_off;
   if (!flat) {
     hipError_t e = launch_reduce_slabs(nd, slabs, n_blocks, grads, loss_out, params, packed, st, split);

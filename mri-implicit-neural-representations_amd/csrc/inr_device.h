@@ -64,8 +64,8 @@ struct NetDesc {
   int D;             // number of Linear layers the network chains (MFN: all descriptors)
   int ND;            // number of LayerDesc entries in L[] (== D except WIRE2D: D + D - 1)
   int orth0;         // WIRE2D: L[orth0 + l] = scale_orth of layer l (0 <= l < D - 1)
-  int bf16;          // 1: packed weight images are bf16 fragments for v_mfma_f32_32x32x16_bf16 (inr_mlp_bf16_impl.h)
-  int w2_off;        // bf16 plans: offset (floats) into packed of the "weights in LDS" chunk image (inr_w2.h); -1: none
+  int bf16;          // 1: bf16 throughput path: the packed images are the panel stream of inr_siren_bf16_impl.h
+  int w2_off;        // bf16 plans: offset (floats) into packed of the "weight panels in LDS" stream (inr_w2.h); -1: none
   int w2_bias_off;   // ... and of its fp32 bias table [D][256]
   int NB;            // hidden width / 32
   int hact;          // hidden activation (ACT_SIN / ACT_RELU)

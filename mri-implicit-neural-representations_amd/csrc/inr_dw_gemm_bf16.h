@@ -1,4 +1,4 @@
-// inr_dw_gemm_bf16.h -- arguments of the bf16 batch-level weight-gradient GEMM (inr_dw_gemm_bf16.hip)
+// inr_dw_gemm_bf16.h -- arguments of the bf16 path's batch-level weight-gradient GEMM (inr_dw_gemm_bf16.hip)
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -6,12 +6,11 @@ namespace inr {
 
 #define INR_DWGB_MAX_UNITS 48
 
-// one 256-row x 256-column block of one layer's dW.  Offsets into a tile's stash are in DWORDS (= row pairs x
-// coordinates: rows (2p, 2p+1) of coordinate c share the dword at p * TL + c).
+// one 256-row x 256-column block of one layer's dW.  Offsets into a tile's stash are in DWORDS (inr_w2.h: 8-bit tensors
+// in row-quad layout, rows 4q .. 4q+3 of coordinate c in the dword at q * TL + c; dZ_last as fp16 row pairs).
 struct DwGemmBf16Unit {
-  int dz_off;          // dwords from the start of a tile's stash to dZ_l (bf16 pairs)
-  int z_off;           // ... to z_{l-1} (fp16 pairs); < 0: first layer, h = gauss encoder features of the coordinates
-  float krev;          // w0 / (2 pi) of the layer that produced z_{l-1}
+  int dz_off;          // dwords from the start of a tile's stash to dZ_l (bf8 quads; last layer: fp16 pairs)
+  int z_off;           // ... to the phase bytes of z_{l-1}; < 0: first layer, h = gauss encoder features of the coordinates
   int gw_off, gb_off;  // slab offsets (floats) of dW [M x K] and db [M]
   int M;               // rows of dW stored (256 for the hidden layers' padded slabs, out_features for the last layer)
   int K;               // columns of dW
@@ -23,6 +22,7 @@ struct DwGemmBf16Args {
   float* slabs;        // n_chunks slabs of slab_floats floats
   const float* coords; // [B,3] (first-layer units)
   const float* encB;   // [E,3]
+  float* dz_state;     // the 4 gradient-scale words of this kind of step (inr_w2.h); nullptr: sums leave as they are
   long long B;
   long long save_floats_per_tile;
   int slab_floats;
@@ -32,5 +32,25 @@ struct DwGemmBf16Args {
 };
 
 hipError_t launch_dw_gemm_bf16(const DwGemmBf16Args& a, hipStream_t st);
+// the roll alone (after a calibration pass of the fused kernel: inr_api.hip)
+hipError_t launch_dz_roll(float* st, hipStream_t stream);
+
+#if defined(__HIPCC__)
+// Next step's gradient scale from what this step saw: st[1] = bits of max |dZ * mult|, st[3] = the power of two S inside
+// mult.  amax / S is the step's largest |dZ| in units of the loss gradient's own normalisation (fused steps: of
+// d(loss)/d(out) * count); the next S puts it into [2^7, 2^8): 2^7.8 of headroom below bf8's largest finite value
+// (57 344; an overflow would become an infinity in the GEMM), 2^23 above its smallest subnormal.  A step whose gradient
+// is exactly zero keeps the scale.
+__device__ __forceinline__ void dz_state_roll(float* st) {
+  const float amax = __builtin_bit_cast(float, reinterpret_cast<unsigned*>(st)[1]);
+  if (amax > 0.f && amax < 3.0e38f) {
+    int ex;
+    (void)frexpf(amax / st[3], &ex);  // amax / S = f * 2^ex, f in [0.5, 1)
+    ex = ex < -100 ? -100 : (ex > 100 ? 100 : ex);
+    st[0] = ldexpf(1.0f, 8 - ex);
+  }
+  reinterpret_cast<unsigned*>(st)[1] = 0u;
+}
+#endif
 
 }  // namespace inr

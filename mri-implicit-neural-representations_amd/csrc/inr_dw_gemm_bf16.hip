@@ -1,38 +1,37 @@
 // inr_dw_gemm_bf16.hip -- batch-level weight gradients of the bf16 throughput path:  dW_l = dZ_l^T h_{l-1},
-// db_l = sum_c dZ_l  over all coordinates of a chunk of tiles, on v_mfma_f32_32x32x16_bf16 (fp32 accumulate),
-// split-K over chunks of tiles; inr_siren_bf16_impl.h leaves the operands behind.
+// db_l = sum_c dZ_l  over all coordinates of a chunk of tiles, on v_mfma_f32_32x32x16_f16 (fp32 accumulate), split-K over
+// chunks of tiles; inr_siren_bf16_impl.h leaves the operands behind.
 //
-// Why it exists: with the matrix pipe 16x faster than on the fp32 path the first fused bf16 kernel was paced by what
-// it WROTE -- one private 0.66 MB gradient slab per 128-coordinate tile (196 of them at 25 000 rows: 129 MB per
-// launch, in 2-byte stores) -- and spent half its cycles in the in-kernel dW passes.  Here ~40 workgroups per layer
-// each keep a 256 x 256 block of dW in registers across ~13 tiles: the slab stream is (chunks x 1.3 MB), written once
-// in fp32.
+// Why it exists: with the matrix pipe 16x faster than on the fp32 path a fused kernel that forms dW itself is paced by
+// the per-tile gradient slabs it writes.  Here ~40 workgroups per layer each keep a 256 x 256 block of dW in registers
+// across ~13 tiles: the slab stream is (chunks x 1.3 MB), written once in fp32.
 //
-// Operands (stash of inr_siren_bf16_kernel, per tile of TL coordinates, ROW-PAIR layout: rows (2p, 2p+1) of
-// coordinate c share the dword at p * TL + c):  A = dZ_l, bf16;  B = h_{l-1} = sin(w0 z_{l-1}) RECOMPUTED here from
-// the stashed fp16 z_{l-1} with the hardware sine (the fused kernel never stores h), or, for the first layer, the gauss
-// encoder features regenerated from the tile's coordinates exactly as the forward pass formed them (sine of x.B_j
-// revolutions, + 1/4 turn for the cosine half).  A thread stages (row pair, 8 coordinates) items: two 16-byte loads,
-// de-interleaved into one 16-byte LDS piece per row (v_perm_b32 for dZ; for z the sine pass unpacks anyway); the row
-// sums db come from the same registers (bf16 -> fp32 on the integer bits, fp32 adds), reduced over the 8 threads
-// of a row at the end.
+// Operands (8-bit stash of inr_siren_bf16_kernel, inr_w2.h; per tile of TL coordinates, ROW-QUAD layout: rows 4q .. 4q+3
+// of coordinate c share the dword at q * TL + c):  A = dZ_l as bf8 under the step's gradient scale -- a bf8 byte is the
+// high byte of the fp16 of the same value, so "conversion" is the byte transposition the staging does anyway, and the
+// product runs on the fp16 MFMA;  B = h_{l-1} = sin(2 pi phase / 256) from the stashed phase bytes (the fused kernel never
+// stores h), or, for the first layer, the gauss encoder features regenerated from the tile's coordinates exactly as the
+// forward pass formed them (sine of x.B_j revolutions, + 1/4 turn for the cosine half).  A thread stages one (row quad,
+// 8 coordinates) item per operand and stage: two 16-byte loads, v_perm_b32 into four 16-byte LDS pieces (one per row);
+// the row sums db come from the same registers (v_dot2c_f32_f16 against ones), reduced over the 8 threads of a quad at the
+// end.  Sums are divided by the factor the fused kernel multiplied the loss gradient with (state word 2) on the way out;
+// the first thread of the launch then derives the next step's power-of-two scale from the largest |dZ| the step saw.
 //
 // Workgroup = one 256 x 256 block of one layer's dW over one chunk of tiles; EIGHT waves 4 x 2 (two per SIMD), 2 x 4
-// MFMA blocks each (128 accumulator registers): the staging of the next stage -- as many VALU cycles as the stage has
-// MFMA cycles -- runs in one wave of a SIMD while the other multiplies.  K-steps of 64 coordinates staged through two
-// LDS stages, rows pitched 144 B so that the 16-byte fragment reads of 16 consecutive rows hit 16 distinct 4-bank slots.
+// MFMA blocks each (128 accumulator registers): the staging of the next stage runs in one wave of a SIMD while the other
+// multiplies.  K-steps of 64 coordinates staged through two LDS stages, rows pitched 144 B so that the 16-byte fragment
+// reads of 16 consecutive rows hit 16 distinct 4-bank slots.
 #include <hip/hip_runtime.h>
 
 #include "inr_dw_gemm_bf16.h"
 #include "inr_launch.h"
+#include "inr_w2.h"
 
 namespace inr {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -41,14 +40,13 @@ constexpr int GB_PITCH = 72;              // LDS row pitch in 2-byte elements: 6
 constexpr int GB_TILE = 256 * GB_PITCH;   // one operand tile (elements)
 constexpr int GB_STAGE = 2 * GB_TILE;     // A tile + B tile
 constexpr int GB_NT = 512;                // threads: eight waves, two per SIMD (staging of one hides under MFMAs of the other)
-constexpr int GB_NI = 2;                  // (row pair, 8 coordinates) items per thread, operand and stage
 
-__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+__device__ __forceinline__ unsigned pk_f16(float a, float b) {
   f32x2 v = {a, b};
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
 }
 
-// 8 dwords (coordinates c .. c+7, each = rows (2p, 2p+1)) -> the two rows as 8 bf16 each
+// 8 dwords (coordinates c .. c+7, each = rows (2p, 2p+1) as fp16) -> the two rows as 8 fp16 each  (dZ_last)
 __device__ __forceinline__ void split_rows(const u32x4& a, const u32x4& b, u32x4& even, u32x4& odd) {
   even[0] = __builtin_amdgcn_perm(a[1], a[0], 0x05040100u);
   even[1] = __builtin_amdgcn_perm(a[3], a[2], 0x05040100u);
@@ -60,30 +58,42 @@ __device__ __forceinline__ void split_rows(const u32x4& a, const u32x4& b, u32x4
   odd[3] = __builtin_amdgcn_perm(b[3], b[2], 0x07060302u);
 }
 
-// sum of 8 bf16 (4 dwords) into acc: v_dot2c_f32_bf16 against a pair of ones (fp32 accumulate, one instruction per
-// dword).  Written as inline assembly: through the builtin hipcc 7.2 selected the FIRST dword for all four dot products of
-// the unrolled loop -- the row sums came out as 4 x the first coordinate pair.
+// 8 dwords (coordinates c .. c+7, byte R of each = row 4q + R as bf8) -> row R as 8 fp16: byte R of coordinates (2i, 2i+1)
+// into the HIGH bytes of the two halves of dword i, zeros below (selector 0x0c)
+template <int R>
+__device__ __forceinline__ u32x4 bf8_row(const u32x4& a, const u32x4& b) {
+  constexpr unsigned sel = ((4u + R) << 24) | (0x0cu << 16) | ((unsigned)R << 8) | 0x0cu;
+  u32x4 o;
+  o[0] = __builtin_amdgcn_perm(a[1], a[0], sel);
+  o[1] = __builtin_amdgcn_perm(a[3], a[2], sel);
+  o[2] = __builtin_amdgcn_perm(b[1], b[0], sel);
+  o[3] = __builtin_amdgcn_perm(b[3], b[2], sel);
+  return o;
+}
+
+// sum of 8 fp16 (4 dwords) into acc: v_dot2c_f32_f16 against a pair of ones (fp32 accumulate, one instruction per
+// dword).  Inline assembly: through the builtin hipcc 7.2 selected the FIRST dword for all four dot products of an
+// unrolled loop (round 2, bf16 form) -- the row sums came out as 4 x the first coordinate pair.
 __device__ __forceinline__ float sum8(const u32x4& v, float acc) {
-  const unsigned ones = 0x3f803f80u;
+  const unsigned ones = 0x3c003c00u;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acc) : "v"(v[i]), "v"(ones));
+  for (int i = 0; i < 4; ++i) asm volatile("v_dot2c_f32_f16 %0, %1, %2" : "+v"(acc) : "v"(v[i]), "v"(ones));
   return acc;
 }
 
-// 8 fp16 pairs (rows 2p, 2p+1 of 8 coordinates) -> sin(w0 z) of each row as 8 bf16
-__device__ __forceinline__ void sin_rows(const u32x4& a, const u32x4& b, float krev, u32x4& even, u32x4& odd) {
-  float e[8], o[8];
+// 8 dwords (byte R of each = phase of row 4q + R at coordinates c .. c+7) -> sin(2 pi phase / 256) of that row as 8 fp16
+template <int R>
+__device__ __forceinline__ u32x4 sin_row(const u32x4& a, const u32x4& b) {
+  float s[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    const f16x2 z = __builtin_bit_cast(f16x2, i < 4 ? a[i] : b[i - 4]);
-    e[i] = __builtin_amdgcn_sinf((float)z[0] * krev);  // |w0 z / 2 pi| <= 256: the instruction's own range (see the fused kernel)
-    o[i] = __builtin_amdgcn_sinf((float)z[1] * krev);
+    const unsigned d = i < 4 ? a[i] : b[i - 4];
+    s[i] = __builtin_amdgcn_sinf((float)((d >> (8 * R)) & 255u) * 0.00390625f);
   }
+  u32x4 o;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    even[i] = pk_bf16(e[2 * i], e[2 * i + 1]);
-    odd[i] = pk_bf16(o[2 * i], o[2 * i + 1]);
-  }
+  for (int i = 0; i < 4; ++i) o[i] = pk_f16(s[2 * i], s[2 * i + 1]);
+  return o;
 }
 
 // feature `row` (< E: sine, >= E: cosine of the same phase) of 8 consecutive coordinates whose (x0,x1,x2) sit in xs
@@ -98,15 +108,15 @@ __device__ __forceinline__ u32x4 gauss_features(const float* xs, const float* en
     f[j] = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(fmaf(xs[3 * j + 2], b2, fmaf(xs[3 * j + 1], b1, fmaf(xs[3 * j], b0, quarter)))));
   u32x4 o;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) o[i] = pk_bf16(f[2 * i], f[2 * i + 1]);
+  for (int i = 0; i < 4; ++i) o[i] = pk_f16(f[2 * i], f[2 * i + 1]);
   return o;
 }
 
 // ENC: B = encoder features (first layer); BIAS: this column block also produces db; LASTROWS: dZ has only its first
-// two row pairs (the out_features <= 4 rows of the last layer): the rest of the A tile stays zero
+// four rows (the out_features <= 4 rows of the last layer, fp16 row pairs): the rest of the A tile stays zero
 template <int TL, bool ENC, bool BIAS, bool LASTROWS>
 __device__ __forceinline__ void dwgb_body(const DwGemmBf16Args& a, const DwGemmBf16Unit& it, int kc, char* lds_raw) {
-  __bf16* lds = reinterpret_cast<__bf16*>(lds_raw);
+  _Float16* lds = reinterpret_cast<_Float16*>(lds_raw);
   float* xs_lds = reinterpret_cast<float*>(lds_raw + (size_t)2 * GB_STAGE * 2);  // [2 stages][64 coords][3]
   float* encB_lds = xs_lds + 2 * GB_KS * 3;                                      // [E][3]
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -134,26 +144,21 @@ __device__ __forceinline__ void dwgb_body(const DwGemmBf16Args& a, const DwGemmB
       *reinterpret_cast<u32x4*>(lds + (size_t)st * GB_STAGE + row * GB_PITCH + 8 * piece) = z4;
     }
   }
-  // loader: item k of thread t = row pair (t >> 3) + 64 k, coordinates 8 (t & 7) .. + 7 of the stage
-  const int seg = t & 7, pair0 = t >> 3;
+  // loader: the thread's item = row quad t >> 3 (rows 4q .. 4q+3), coordinates 8 (t & 7) .. + 7 of the stage
+  const int seg = t & 7, quad = t >> 3;
   const unsigned* sv = reinterpret_cast<const unsigned*>(a.save);
   const size_t tile_dwords = (size_t)a.save_floats_per_tile;
   // two register sets: while stage s multiplies, set (s+1)&1 -- fetched a whole stage earlier -- is staged into LDS and
   // then refilled with stage s+3 (global latency is several microseconds under load; a stage is ~1)
-  u32x4 ra[2][GB_NI][2], rb[2][GB_NI][2];
-  float bsum[GB_NI][2];
-#pragma unroll
-  for (int k = 0; k < GB_NI; ++k) bsum[k][0] = bsum[k][1] = 0.f;
+  u32x4 ra[2][LASTROWS ? 4 : 2], rb[2][2];
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
 
   // (through a buffer descriptor on the tile's wave-uniform base: the thread's part of an address is the byte offset of its
-  // (row pair, segment), formed once; tensor and K-step offsets are scalar -- no 64-bit vector adds in the loop)
-  int voffA[GB_NI], voffB[GB_NI];
-#pragma unroll
-  for (int k = 0; k < GB_NI; ++k) {
-    voffA[k] = ((pair0 + 64 * k) * TL + 8 * seg) * 4;
-    voffB[k] = ((it.n0 / 2 + pair0 + 64 * k) * TL + 8 * seg) * 4;
-  }
-  auto fetch = [&](int s, u32x4 (&A)[GB_NI][2], u32x4 (&B)[GB_NI][2]) {
+  // (row quad, segment), formed once; tensor and K-step offsets are scalar -- no 64-bit vector adds in the loop)
+  const int voffA = (quad * TL + 8 * seg) * 4;
+  const int voffB = ((it.n0 / 4 + quad) * TL + 8 * seg) * 4;
+  const int voffL = 8 * seg * 4;  // LASTROWS: row pair p at p * TL dwords
+  auto fetch = [&](int s, u32x4 (&A)[LASTROWS ? 4 : 2], u32x4 (&B)[2]) {
     if (s >= n_steps) s = n_steps - 1;  // past the end: the last stage again (loaded, never multiplied)
     const int tile = t0 + s / KS_PER_TILE, c0 = (s % KS_PER_TILE) * GB_KS;
     const unsigned long long ba = reinterpret_cast<unsigned long long>(sv + (size_t)tile * tile_dwords + c0);
@@ -161,17 +166,20 @@ __device__ __forceinline__ void dwgb_body(const DwGemmBf16Args& a, const DwGemmB
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, 0x7ffffff0, 0x00020000);
     const int soA = it.dz_off * 4, soB = it.z_off * 4;
-#pragma unroll
-    for (int k = 0; k < GB_NI; ++k) {
-      const int pair = pair0 + 64 * k;
-      if (!LASTROWS || pair < 2) {
-        A[k][0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voffA[k], soA, 0));
-        A[k][1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voffA[k], soA + 16, 0));
+    if (LASTROWS) {
+      if (quad == 0) {
+        A[0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voffL, soA, 0));
+        A[1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voffL, soA + 16, 0));
+        A[2] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voffL, soA + TL * 4, 0));
+        A[3] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voffL, soA + TL * 4 + 16, 0));
       }
-      if (!ENC) {
-        B[k][0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voffB[k], soB, 0));
-        B[k][1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voffB[k], soB + 16, 0));
-      }
+    } else {
+      A[0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voffA, soA, 0));
+      A[1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voffA, soA + 16, 0));
+    }
+    if (!ENC) {
+      B[0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voffB, soB, 0));
+      B[1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voffB, soB + 16, 0));
     }
   };
   // the coordinates of stage s (first-layer units: the encoder features are regenerated from them): 64 coordinates =
@@ -189,63 +197,63 @@ __device__ __forceinline__ void dwgb_body(const DwGemmBf16Args& a, const DwGemmB
   auto xs_put = [&](int s, float v) {
     if (ENC && t < GB_KS * 3) xs_lds[(s & 1) * GB_KS * 3 + t] = v;
   };
-  // staging of item `k` of stage s: A rows as they are (and into the row sums, once: `count`), B rows through the sine
-  auto stash_item = [&](int s, int k, bool count, const u32x4 (&A)[GB_NI][2], const u32x4 (&B)[GB_NI][2]) {
-    __bf16* st = lds + (size_t)(s & 1) * GB_STAGE;
-    const int pair = pair0 + 64 * k;
-    if (!LASTROWS || pair < 2) {
-      u32x4 ev, od;
-      split_rows(A[k][0], A[k][1], ev, od);
-      *reinterpret_cast<u32x4*>(st + (2 * pair) * GB_PITCH + 8 * seg) = ev;
-      *reinterpret_cast<u32x4*>(st + (2 * pair + 1) * GB_PITCH + 8 * seg) = od;
-#ifndef GB_EXP_NOSUM
-      if (BIAS && count) {
-        bsum[k][0] = sum8(ev, bsum[k][0]);
-        bsum[k][1] = sum8(od, bsum[k][1]);
-      }
-#endif
-    }
-    u32x4 ev, od;
-#ifdef GB_EXP_NOENC
-    if (ENC) { ev = u32x4{1u,2u,3u,(unsigned)pair}; od = ev; } else
-#endif
-    if (ENC) {
-      ev = gauss_features(xs_lds + (s & 1) * GB_KS * 3 + 24 * seg, encB_lds, a.E, it.n0 + 2 * pair);
-      od = gauss_features(xs_lds + (s & 1) * GB_KS * 3 + 24 * seg, encB_lds, a.E, it.n0 + 2 * pair + 1);
+  // staging of the A item of stage s: rows as fp16 (and into the row sums, once: `count`)
+  auto stage_a = [&](int s, bool count, const u32x4 (&A)[LASTROWS ? 4 : 2]) {
+    _Float16* st = lds + (size_t)(s & 1) * GB_STAGE + (4 * quad) * GB_PITCH + 8 * seg;
+    u32x4 row[4];
+    if (LASTROWS) {
+      if (quad != 0) return;
+      split_rows(A[0], A[1], row[0], row[1]);
+      split_rows(A[2], A[3], row[2], row[3]);
     } else {
-#ifdef GB_EXP_NOSIN
-      split_rows(B[k][0], B[k][1], ev, od);
-#else
-      sin_rows(B[k][0], B[k][1], it.krev, ev, od);
-#endif
+      row[0] = bf8_row<0>(A[0], A[1]);
+      row[1] = bf8_row<1>(A[0], A[1]);
+      row[2] = bf8_row<2>(A[0], A[1]);
+      row[3] = bf8_row<3>(A[0], A[1]);
     }
-    *reinterpret_cast<u32x4*>(st + GB_TILE + (2 * pair) * GB_PITCH + 8 * seg) = ev;
-    *reinterpret_cast<u32x4*>(st + GB_TILE + (2 * pair + 1) * GB_PITCH + 8 * seg) = od;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      *reinterpret_cast<u32x4*>(st + r * GB_PITCH) = row[r];
+      if (BIAS && count) bsum[r] = sum8(row[r], bsum[r]);
+    }
   };
-  const __bf16* As = lds + (wm * 64 + li) * GB_PITCH + 8 * half;
-  const __bf16* Bs = lds + GB_TILE + (wn * 128 + li) * GB_PITCH + 8 * half;
+  // ... and of the B item: rows through the sine (or the encoder)
+  auto stage_b = [&](int s, const u32x4 (&B)[2]) {
+    _Float16* st = lds + (size_t)(s & 1) * GB_STAGE + GB_TILE + (4 * quad) * GB_PITCH + 8 * seg;
+    u32x4 row[4];
+    if (ENC) {
+      const float* xs = xs_lds + (s & 1) * GB_KS * 3 + 24 * seg;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) row[r] = gauss_features(xs, encB_lds, a.E, it.n0 + 4 * quad + r);
+    } else {
+      row[0] = sin_row<0>(B[0], B[1]);
+      row[1] = sin_row<1>(B[0], B[1]);
+      row[2] = sin_row<2>(B[0], B[1]);
+      row[3] = sin_row<3>(B[0], B[1]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) *reinterpret_cast<u32x4*>(st + r * GB_PITCH) = row[r];
+  };
+  const _Float16* As = lds + (wm * 64 + li) * GB_PITCH + 8 * half;
+  const _Float16* Bs = lds + GB_TILE + (wn * 128 + li) * GB_PITCH + 8 * half;
   // stage s multiplies out of LDS stage s & 1 while register set `N` (stage s+1) is staged into the other one
-  auto compute = [&](int s, u32x4 (&NA)[GB_NI][2], u32x4 (&NB)[GB_NI][2]) {
+  auto compute = [&](int s, u32x4 (&NA)[LASTROWS ? 4 : 2], u32x4 (&NB)[2]) {
     const bool more = s + 1 < n_steps;
-    const __bf16* Ab = As + (size_t)(s & 1) * GB_STAGE;
-    const __bf16* Bb = Bs + (size_t)(s & 1) * GB_STAGE;
+    const _Float16* Ab = As + (size_t)(s & 1) * GB_STAGE;
+    const _Float16* Bb = Bs + (size_t)(s & 1) * GB_STAGE;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {  // four K = 16 sub-steps of the stage's 64 coordinates
-      bf16x8 A[2], B[4];
+      f16x8 A[2], B[4];
 #pragma unroll
-      for (int i = 0; i < (LASTROWS ? 1 : 2); ++i) A[i] = *reinterpret_cast<const bf16x8*>(Ab + i * 32 * GB_PITCH + 16 * q);
+      for (int i = 0; i < (LASTROWS ? 1 : 2); ++i) A[i] = *reinterpret_cast<const f16x8*>(Ab + i * 32 * GB_PITCH + 16 * q);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) B[j] = *reinterpret_cast<const bf16x8*>(Bb + j * 32 * GB_PITCH + 16 * q);
+      for (int j = 0; j < 4; ++j) B[j] = *reinterpret_cast<const f16x8*>(Bb + j * 32 * GB_PITCH + 16 * q);
 #pragma unroll
       for (int i = 0; i < (LASTROWS ? 1 : 2); ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-#ifdef GB_EXP_NOMFMA
-          acc[i][j][q] += (float)A[i][0] + (float)B[j][0];
-#else
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i], B[j], acc[i][j], 0, 0, 0);
-#endif
-      if (q < GB_NI) stash_item(s + 1, q, more, NA, NB);  // half of the next stage's staging per sub-step
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[i], B[j], acc[i][j], 0, 0, 0);
+      if (q == 0) stage_a(s + 1, more, NA);  // the next stage's staging behind the first two sub-steps
+      if (q == 1) stage_b(s + 1, NB);
     }
   };
 
@@ -256,8 +264,8 @@ __device__ __forceinline__ void dwgb_body(const DwGemmBf16Args& a, const DwGemmB
     xs_next = xs_get(1);
     fetch(1, ra[1], rb[1]);
     if (ENC || LASTROWS) __syncthreads();  // xs of stage 0, the encoder matrix, the zeroed A tiles
-#pragma unroll
-    for (int k = 0; k < GB_NI; ++k) stash_item(0, k, true, ra[0], rb[0]);
+    stage_a(0, true, ra[0]);
+    stage_b(0, rb[0]);
     fetch(2, ra[0], rb[0]);
     xs_put(1, xs_next);
     xs_next = xs_get(2);
@@ -276,7 +284,9 @@ __device__ __forceinline__ void dwgb_body(const DwGemmBf16Args& a, const DwGemmB
     xs_next = xs_get(s + 4);
     __syncthreads();
   }
-  // ---- chunk slab: dW rows follow the MFMA C layout (register r of lane (li, half): row (r&3)+8(r>>2)+4 half, col li)
+  // ---- chunk slab: dW rows follow the MFMA C layout (register r of lane (li, half): row (r&3)+8(r>>2)+4 half, col li);
+  // the gradient scale comes off here
+  const float unscale = a.dz_state != nullptr ? 1.0f / a.dz_state[2] : 1.0f;
   float* slab = a.slabs + (size_t)kc * a.slab_floats;
 #pragma unroll
   for (int i = 0; i < (LASTROWS ? 1 : 2); ++i) {
@@ -288,23 +298,20 @@ __device__ __forceinline__ void dwgb_body(const DwGemmBf16Args& a, const DwGemmB
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = rb0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          if (row < it.M) slab[it.gw_off + (size_t)row * it.K + col] = acc[i][j][r];
+          if (row < it.M) slab[it.gw_off + (size_t)row * it.K + col] = acc[i][j][r] * unscale;
         }
       }
     }
   }
-  if (BIAS) {  // the 8 threads of a row pair (consecutive lanes) each hold the sum of their 8-coordinate segments
+  if (BIAS) {  // the 8 threads of a row quad (consecutive lanes) each hold the sums of their 8-coordinate segments
 #pragma unroll
-    for (int k = 0; k < GB_NI; ++k) {
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        float v = bsum[k][e];
-        v += __shfl_xor(v, 1);
-        v += __shfl_xor(v, 2);
-        v += __shfl_xor(v, 4);
-        const int row = 2 * (pair0 + 64 * k) + e;
-        if (seg == 0 && row < it.M) slab[it.gb_off + row] = v;
-      }
+    for (int r = 0; r < 4; ++r) {
+      float v = bsum[r];
+      v += __shfl_xor(v, 1);
+      v += __shfl_xor(v, 2);
+      v += __shfl_xor(v, 4);
+      const int row = 4 * quad + r;
+      if (seg == 0 && row < it.M) slab[it.gb_off + row] = v * unscale;
     }
   }
 }
@@ -324,6 +331,15 @@ __global__ __launch_bounds__(GB_NT, 2) void dw_gemm_bf16_kernel(const DwGemmBf16
   } else {
     dwgb_body<TL, false, true, false>(a, it, kc, lds_raw);  // hidden layers: one column tile (K <= 256), always with db
   }
+  // the next step's gradient scale (inr_w2.h): nothing in this launch reads words 0 and 1
+  if (a.dz_state != nullptr && blockIdx.x == 0 && threadIdx.x == 0) dz_state_roll(a.dz_state);
+}
+
+__global__ void dz_roll_kernel(float* st) { dz_state_roll(st); }
+
+hipError_t launch_dz_roll(float* st, hipStream_t stream) {
+  hipLaunchKernelGGL(dz_roll_kernel, dim3(1), dim3(1), 0, stream, st);
+  return hipGetLastError();
 }
 
 hipError_t launch_dw_gemm_bf16(const DwGemmBf16Args& a, hipStream_t st) {

@@ -28,6 +28,7 @@ struct MlpArgs {
   long long dbg_cap;   // entries behind dbg (a stamp past it is dropped)
   int ll_lds;          // inr_mlp_kernel: the last layer's live A fragments (rows 0..3) sit in LDS (set by launch_mlp)
   int dz_lds;    // set by the launcher: dZ_last has its own LDS image (fused step; inr_mlp_impl.h)
+  float* dz_state;     // bf16 plans: the plan's gradient-scale state (inr_w2.h), W2_STATE_FLOATS floats on the device
   int tile0;           // first tile of this launch (tiles [tile0, n_tiles)); accumulate: the workgroups' slabs and loss
   int accumulate;      // words already hold an earlier launch's sums of the same step -- add to them
 };

@@ -1,12 +1,16 @@
-// fused SIREN training step of the bf16 throughput path, "weights in LDS" design (inr_siren_bf16_impl.h)
+// SIREN on the bf16 matrix pipe, "weight panels in LDS" design (inr_siren_bf16_impl.h): fused step and the two halves
+// of a split step
 #include "inr_siren_bf16_impl.h"
 #include "inr_aux.h"
 
 namespace inr {
 
-hipError_t launch_siren_bf16(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int grid, hipStream_t st) {
-  if (nd.input != IN_GAUSS || nd.hact != ACT_SIN || nd.NB != 8 || nd.w2_off < 0) return hipErrorInvalidValue;
-  return launch_siren_bf16_fused(nd, ld, a, grid, st);
+hipError_t launch_siren_bf16(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int mode, int grid, hipStream_t st) {
+  if (nd.input != IN_GAUSS || nd.hact != ACT_SIN || nd.NB != 8 || nd.w2_off < 0 || nd.D < 3 || (nd.E % 32) != 0)
+    return hipErrorInvalidValue;
+  if (mode == MODE_FWD) return launch_siren_bf16_mode<MODE_FWD>(nd, ld, a, grid, st);
+  if (mode == MODE_BWD) return launch_siren_bf16_mode<MODE_BWD>(nd, ld, a, grid, st);
+  return launch_siren_bf16_mode<MODE_FUSED>(nd, ld, a, grid, st);
 }
 
 }  // namespace inr

@@ -1,35 +1,30 @@
-// inr_siren_bf16_impl.h -- fused SIREN training step on the bf16 matrix pipe, second design ("weights in LDS,
-// activations in registers"): forward + pointwise loss + backward-to-inputs for tiles of 256 coordinates; the weight
-// gradients are left to inr_dw_gemm_bf16.hip, which reads the operands this kernel stashes.
+// inr_siren_bf16_impl.h -- SIREN on the bf16 matrix pipe, third design: "weight panels in LDS, activations in registers,
+// one row block at a time, two staggered wave groups".  Forward + pointwise loss + backward-to-inputs for tiles of 256
+// coordinates (MODE_FUSED), or the two halves of a split step (MODE_FWD: outputs + stash; MODE_BWD: from d(loss)/d(out));
+// the weight gradients are left to inr_dw_gemm_bf16.hip, which reads the 8-bit operands this kernel stashes.
 //
-// Why a second design.  The first bf16 kernel (inr_mlp_bf16_impl.h, still used for the unfused forward / backward
-// entry points) kept the fp32 kernel's mapping: every wave streams every weight fragment from L2 for its own 32
-// coordinates.  At fp32 MFMA rates that stream is hidden; at bf16 rates (8 MFMAs = 256 cycles per 8 KB of fragments
-// per wave) it is the bound -- phase stamps show its GEMM loops at 5-6x their MFMA time -- and half of the kernel
-// went into per-tile weight-gradient slabs.  Here:
-//   * the layer's weights travel HBM/L2 -> LDS ONCE per workgroup and K-chunk (LDS-DMA, global_load_lds_dwordx4, no
-//     VGPRs, no VALU), as pre-packed MFMA A fragments: a chunk = 64 input features x 256 output rows = 32 fragments
-//     of 1 KB = 32 KB; a 4-slot ring (128 KB) keeps three chunks in flight ahead of the one being multiplied; the eight
-//     waves of the workgroup read the same fragments (conflict-free ds_read_b128: lane l reads bytes [16 l, 16 l + 16));
-//   * activations never touch LDS: the fp32 accumulator of layer l (features in registers, coordinates on lanes),
-//     after bias + sin + v_cvt_pk_bf16_f32, IS the B operand of layer l+1 (cdna_hip_programming.md section 3, "An
-//     accumulator tile as the next MFMA's operand"): element j of lane-half h of K-step (m, s) is feature
-//     32 m + 16 s + 8 (j >> 2) + 4 h + (j & 3), and the weight fragments are packed with the same k order
-//     (adam_pack_kernel, put_w2);
-//   * sin / cos of the hidden layers: v_sin_f32 / v_cos_f32 on w0 z / 2 pi directly -- the instruction reduces its
-//     argument itself for |revolutions| <= 256, i.e. |z| <= 53 at w0 = 30, an order of magnitude beyond what a SIREN's
-//     pre-activations reach (the encoder phases, which scale with the configured embedding scale, keep their v_fract);
-//   * backward mirrors it with the transposed images: dZ_l = dH_l * w0 cos(w0 z_l) is formed in registers from the
-//     accumulator of the previous dX GEMM and the stashed z_l, and is the B operand of dH_{l-1} = W_l^T dZ_l;
-//   * the stash holds z_l (fp16) and dZ_l (bf16), 4 KB per coordinate, in "row-pair" layout: element (row 2p + e,
-//     coordinate c) of a tile at dword p * TL + c, half e -- registers (4g, 4g+1) of an accumulator are rows
-//     (2p, 2p+1) of the lane's coordinate, so one v_cvt_pk + one dword store per pair, 128 contiguous bytes per
-//     half-wave; the GEMM kernel de-interleaves while staging.
-// Chunk stream: the packed image (NetDesc::w2_off) holds the chunks in the order a tile consumes them -- forward
-// layers 0 .. D-1, then the transposed images of layers D-1 .. 1 -- so chunk q of the stream is base + 32 KB * q.
+// What the second design (round 2) measured, and what changed:
+//   * its stash -- z_l as fp16, dZ_l as bf16, 4 KB per coordinate, ~690 MB of HBM traffic per step at 65 536 rows --
+//     was the bound (backward epilogues at the CU's share of HBM bandwidth).  Now 8 bits per element (inr_w2.h): the
+//     PHASE of the sine, round(256 frac(w0 z / 2 pi)) -- all that sin and cos need, good to 2 pi / 256 --, and dZ as bf8
+//     (e5m2) under a power-of-two scale that follows the gradient's magnitude from step to step.  2 KB per coordinate,
+//     one dword store per four rows;
+//   * every GEMM phase ended in an epilogue that all eight waves ran at the same time (vector work and memory traffic
+//     with the matrix pipe idle; 18.5 k cycles per layer for 8.2 k of MFMAs).  Now the hidden layers run OUTPUT ROW
+//     BLOCK outermost: a panel = the 16 K-steps of one 32-row block, so a block's accumulator (16 registers instead of
+//     128) is final after 16 MFMAs and its epilogue -- bias, sine, phase byte, stash, conversion into the next layer's B
+//     operand -- runs while the next block multiplies.  Waves 0-3 (role A) do [MFMAs of block m][epilogue of block m],
+//     waves 4-7 (role B, the SIMD partners) [epilogue of block m-1][MFMAs of block m] between the same barriers: at
+//     any time one wave of a SIMD is on the matrix pipe and the other on the vector ALUs;
+//   * weights still travel HBM/L2 -> LDS once per workgroup by LDS-DMA, now as 16 KB panels through an 8-slot ring with
+//     seven panels in flight ahead of the one being multiplied.
+// Activations never touch LDS: the fp32 accumulator of layer l (features in registers, coordinates on lanes), after
+// bias + v_sin_f32 + v_cvt_pk_bf16_f32, IS the B operand of layer l+1 (element j of lane-half h of K-step (m, s) is
+// feature 32 m + 16 s + 8 (j >> 2) + 4 h + (j & 3); the fragments are packed in the same k order, inr_w2.h).
 #pragma once
 #include "inr_mlp_impl.h"
 #include "inr_w2.h"
+#include <type_traits>
 
 namespace inr {
 
@@ -37,13 +32,26 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int W2_SLOTS = 4;  // ring slots of W2_CHUNK_BYTES
+// compile-time loop: f(std::integral_constant<int, I>) for I in [0, N) -- wait counts and register indices that depend on
+// the row block are template arguments
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+constexpr int PN_SLOTS = 7;   // ring slots of W2_PANEL_BYTES: six panels in flight ahead of the one being multiplied
+constexpr int PN_WAVES = 8;   // waves per workgroup; each issues 16 / 8 = 2 of a panel's 1 KB LDS-DMA pieces
+constexpr int PN_PD = 3;      // backward epilogues whose phase loads are in flight ahead of the one being computed
+constexpr int PN_PHASE_BYTES = PN_WAVES * 4 * 1024;  // their landing zone in LDS: per wave four sets of 4 dwords per lane
 
 __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
-
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
   f32x2 v = {a, b};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
@@ -52,430 +60,536 @@ __device__ __forceinline__ unsigned pack_f16(float a, float b) {
   f32x2 v = {a, b};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
 }
-__device__ __forceinline__ bf16x8 pack8(const float (&v)[8]) {
-  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 pack8(const float* v) {
   u32x4 u = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
   return __builtin_bit_cast(bf16x8, u);
 }
 
-// ---- the weight-chunk ring ------------------------------------------------------------------------------------
-// A workgroup is EIGHT waves = two per SIMD: while one wave of a SIMD issues LDS-DMA pieces (~60-100 cycles of issue
-// each), runs an epilogue (VALU + stash traffic) or sits in a wait, its partner keeps the matrix pipe busy.  (With one
-// wave per SIMD the phase stamps showed the GEMM phases at 3x their MFMA time: 8 DMA issues + 32 fragment reads + a
-// barrier per 32 MFMAs, all in one in-order stream.)  Hence <= 256 registers per wave.
-constexpr int W2_WAVES = 8;
-constexpr int W2_FPW = 32 / W2_WAVES;  // fragments (1 KB LDS-DMA pieces) per wave and chunk
+// Phase byte of t revolutions into byte N of `word`: t + 1.5 * 2^15 has its unit in the last place at 2^-8, so the low
+// 8 bits of the sum's encoding are round-to-nearest-even(256 t) mod 256 (two's complement for t < 0), and an SDWA
+// destination select writes exactly those bits (tools/probes/fmt8_probe.hip checks both on the device).
+template <int N>
+__device__ __forceinline__ void phase_byte(unsigned& word, float t, float magic) {
+  static_assert(N >= 0 && N < 4, "byte");
+  if (N == 0)
+    asm("v_add_f32_sdwa %0, %1, %2 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(word) : "v"(t), "v"(magic));
+  else if (N == 1)
+    asm("v_add_f32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(word) : "v"(t), "v"(magic));
+  else if (N == 2)
+    asm("v_add_f32_sdwa %0, %1, %2 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(word) : "v"(t), "v"(magic));
+  else
+    asm("v_add_f32_sdwa %0, %1, %2 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(word) : "v"(t), "v"(magic));
+}
 
-// issue: this wave's share of chunk image `img` into ring slot `slot`
-__device__ __forceinline__ void w2_issue(const char* __restrict__ gbase, int img, int slot, char* ring, int w, int lane) {
-  const char* src = gbase + (size_t)img * W2_CHUNK_BYTES + (size_t)(W2_FPW * w) * 1024 + lane * 16;
-  char* dst = ring + slot * W2_CHUNK_BYTES + (W2_FPW * w) * 1024;
+// ---- the panel ring ---------------------------------------------------------------------------------------------
+// Stream position p lives in slot p mod 7.  An INTERVAL consumes c panels (two per layer-0 chunk, one everywhere else):
+//   pn_begin<N>():  s_waitcnt vmcnt(N) -- this wave's pieces of the interval's panels have landed --, s_barrier --
+//   everybody's have, and everybody is done with the panels of the previous interval --, then requests up to position
+//   p + 6 into the slots just freed.
+// N: the vector-memory counter retires IN ORDER, so "at most N operations outstanding" covers a panel when at least N
+// operations were issued after its pieces.  Behind the pieces of the interval's last panel lie the requests of the
+// panels after it: two pieces each, 7 - c_prev - c panels (c_prev: what the previous interval consumed) -- N0 =
+// 2 (7 - c_prev - c).  On top, where the preceding intervals are known to have issued S stash operations each (the
+// steady state of the hidden layers: 4 stores forward, 4 phase fetches + 4 stores backward, instructions that are
+// issued unconditionally), N = N0 + S h for the h <= 6 such intervals directly in front.  A smaller N only waits longer.
+struct PnRing {
+  const char* gbase;  // panel 0 of the image
+  char* ring;
+  int first, len;     // the stream cycles through images [first, first + len)
+  int p, slot;        // next position to consume, its slot
+  int req, req_img, req_slot;  // next position to request, its image (relative to first), its slot
+  int w, lane;
+};
+
+__device__ __forceinline__ int pn_next(int slot) { return slot + 1 == PN_SLOTS ? 0 : slot + 1; }
+__device__ __forceinline__ void pn_issue(const PnRing& r, int img, int slot) {
+  const char* src = r.gbase + (size_t)img * W2_PANEL_BYTES + (size_t)(2 * r.w) * 1024 + r.lane * 16;
+  char* dst = r.ring + slot * W2_PANEL_BYTES + (2 * r.w) * 1024;
 #pragma unroll
-  for (int n = 0; n < W2_FPW; ++n)
+  for (int n = 0; n < 2; ++n)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + n * 1024),
                                      (__attribute__((address_space(3))) void*)(dst + n * 1024), 16, 0, 0);
 }
-
-// Ring protocol.  The GEMMs come in PHASES (one layer's chunks) with an epilogue between them, and an epilogue is 64
-// stash stores per wave -- 128 KB per workgroup, a whole GEMM phase's worth of the CU's share of HBM write bandwidth.
-// The vector-memory counter retires IN ORDER, so a DMA issued behind those stores cannot be waited for without
-// draining them.  Hence every DMA a phase needs is issued BEFORE the epilogue in front of it:
-//   * chunk stream position p lives in slot p & 3; four chunks are in flight or in use at any time;
-//   * w2_chunk<WAIT>(): wait for this wave's pieces of chunk p, barrier (all pieces landed; everyone is done with
-//     chunk p - 1); then -- except for the first chunk of a phase, whose predecessor's slot was refilled by
-//     w2_phase_end -- w2_request(p): chunk p + 3 into the slot chunk p - 1 just left;
-//   * w2_phase_end(p_next): barrier (everyone is done with the phase's last chunk p_next - 1), request chunk
-//     p_next + 3 into its slot: the one request that would otherwise sit behind the epilogue's stores.
-// WAIT is the s_waitcnt vmcnt operand: "at most WAIT operations outstanding" covers chunk p when at least WAIT
-// vector-memory operations were issued after its DMAs.  Chunk p was requested when chunk p - 4 was done, so for the
-// first four chunks after a 64-store epilogue that is >= 64 (the field's maximum, 63, then retires only the oldest
-// few of those stores, a GEMM phase old); otherwise only the requests of chunks p + 1, p + 2 are guaranteed: 8.
-// Stream position p holds chunk image p mod NQ (a tile's chunk sequence repeats); past the end of the launch the extra
-// requests are harmless and keep the number of operations in flight what the waits assume.
-// The request of chunk p + 3 is issued by the caller a K-step into chunk p's MFMAs (w2_chunk_mma<true>), not here: four
-// LDS-DMA instructions take a few hundred cycles to issue, and right behind the barrier both waves of a SIMD would
-// spend them with the matrix pipe empty.
-template <int WAIT>
-__device__ __forceinline__ void w2_chunk() {
-  static_assert(W2_FPW == 4 && W2_SLOTS == 4 && WAIT >= 0 && WAIT <= 63, "the counts assume 4 DMA pieces per wave and chunk, 4 slots");
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT) : "memory");
-  __builtin_amdgcn_s_barrier();
-}
-__device__ __forceinline__ void w2_request(const char* __restrict__ gbase, int p, int NQ, char* ring, int w, int lane) {
-  w2_issue(gbase, (p + 3) % NQ, (p + 3) & (W2_SLOTS - 1), ring, w, lane);
-}
-__device__ __forceinline__ void w2_phase_end(const char* __restrict__ gbase, int p_next, int NQ, char* ring, int w, int lane) {
-  __builtin_amdgcn_s_barrier();
-  w2_issue(gbase, (p_next + 3) % NQ, (p_next + 3) & (W2_SLOTS - 1), ring, w, lane);
-}
-// a whole phase of n chunks for a wave that only feeds the ring (small batches: the half of the workgroup without a tile)
-__device__ __forceinline__ void w2_phase_loader_only(const char* __restrict__ gbase, int& p, int n, bool drain, int NQ, char* ring,
-                                                     int w, int lane) {
-  for (int c = 0; c < n; ++c) {
-    if (c == 0) {
-      if (drain)
-        w2_chunk<0>();
-      else
-        w2_chunk<8>();
-    } else {
-      w2_chunk<8>();
-      w2_request(gbase, p, NQ, ring, w, lane);
-    }
-    ++p;
+__device__ __forceinline__ void pn_request(PnRing& r) {
+  while (r.req < r.p + PN_SLOTS) {
+    pn_issue(r, r.first + r.req_img, r.req_slot);
+    ++r.req;
+    r.req_slot = pn_next(r.req_slot);
+    if (++r.req_img == r.len) r.req_img = 0;
   }
-  w2_phase_end(gbase, p, NQ, ring, w, lane);
 }
-
-__device__ __forceinline__ bf16x8 w2_frag(const char* ring, int q, int s_l, int mo, int lane) {
-  return *reinterpret_cast<const bf16x8*>(ring + (q & (W2_SLOTS - 1)) * W2_CHUNK_BYTES + ((s_l * 8 + mo) * 64 + lane) * 16);
-}
-
-// ---- vector loads the compiler does not see (see the backward epilogue) ------------------------------------------
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ u32x4 w2_rsrc_words(const void* p, int bytes) {  // the descriptor uniform_rsrc() builds, as SGPR words
-  const unsigned long long a = reinterpret_cast<unsigned long long>(p);
-  u32x4 r;
-  r[0] = __builtin_amdgcn_readfirstlane((unsigned)a);
-  r[1] = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-  r[2] = (unsigned)bytes;
-  r[3] = 0x00020000u;
-  return r;
-}
-__device__ __forceinline__ unsigned w2_load_asm(const u32x4& rsrc, int voff, int soff) {
-  unsigned v;
-  asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(v) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
-  return v;
-}
-// The first load of a batch: five wait states in front.  gfx9 needs them between a VALU instruction that writes an SGPR
-// (v_readlane: how the compiler reloads a spilled SGPR) and a vector-memory instruction that reads it; the compiler pads
-// its own memory instructions but does not look inside inline assembly, and one build reloaded this load's offset SGPR
-// right in front of it -- the load then read a stale offset and the gradients differed from launch to launch
-// (tools/check_inflight_regs.py checks every built kernel for the pattern; tests/test_host.py runs it).
-__device__ __forceinline__ unsigned w2_load_asm_first(const u32x4& rsrc, int voff, int soff) {
-  unsigned v;
-  asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, %3 offen" : "=v"(v) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
-  return v;
-}
-// at most N vector-memory operations outstanding; the eight registers are operands so that no use moves above the wait
 template <int N>
-__device__ __forceinline__ void w2_wait_rows(unsigned (&z)[8]) {
-  asm volatile("s_waitcnt vmcnt(%8)"
-               : "+v"(z[0]), "+v"(z[1]), "+v"(z[2]), "+v"(z[3]), "+v"(z[4]), "+v"(z[5]), "+v"(z[6]), "+v"(z[7])
-               : "n"(N)
-               : "memory");
+__device__ __forceinline__ void pn_begin(PnRing& r) {
+  static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit field");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+  __builtin_amdgcn_s_barrier();
+  pn_request(r);
+}
+// the interval is over: its c panels are consumed
+__device__ __forceinline__ void pn_advance(PnRing& r, int c) {
+  r.p += c;
+  for (int i = 0; i < c; ++i) r.slot = pn_next(r.slot);
+}
+__device__ __forceinline__ bf16x8 pn_frag(const PnRing& r, int slot, int f) {
+  return *reinterpret_cast<const bf16x8*>(r.ring + slot * W2_PANEL_BYTES + (f * 64 + r.lane) * 16);
+}
+// one row block: 16 K-steps of the panel in `slot` against the 16 B operands
+__device__ __forceinline__ f32x16 pn_mma_block(const PnRing& r, int slot, const bf16x8 (&b)[16]) {
+  f32x16 acc = zero16();
+#pragma unroll
+  for (int t = 0; t < 16; ++t) acc = mfma_bf16(pn_frag(r, slot, t), b[t], acc);
+  return acc;
 }
 
-// one chunk = four K = 16 steps against B fragments b[0..3], 8 row blocks (the partner wave hides the LDS latency)
-// REQUEST: chunk q is not the first of its phase -- the slot chunk q - 1 left takes chunk q + 3, behind the first K-step
-template <bool REQUEST>
-__device__ __forceinline__ void w2_chunk_mma(f32x16 (&acc)[8], char* ring, int q, const bf16x8 (&b)[4], int lane,
-                                             const char* __restrict__ gbase, int NQ, int w) {
+// ---- phase fetches ------------------------------------------------------------------------------------------------
+// The phase bytes of a backward epilogue are fetched PN_PD epilogues ahead and waited for with a counted vmcnt: hipcc's own
+// wait insertion answers a load that is pending together with stores (and LDS-DMA) with vmcnt(0), which would drain the
+// six weight panels in flight at every row block.  They travel by LDS-DMA into a landing zone of the wave (four sets of
+// 4 x 64 dwords) and are read back with plain LDS loads behind the wait.  Not into registers: a load whose wait the
+// compiler does not know about stays in flight across whatever the register allocator puts in between -- round 2 found a
+// spill there, this round's first build a loop-carried copy (at the back edge of the layer loop the loads of the next
+// layer's first row blocks were "moved" to where the next iteration expected them before they had landed), and
+// amdgpu_num_vgpr does not keep the allocator out of a register range on this compiler.  An LDS destination has no
+// allocator.
+
+// ---- one tile group (four waves, 128 coordinates = one stash tile) ----------------------------------------------
+// RB: role B (waves 4-7).  ACTIVE = false: the group has no tile in this launch shape (small batches run one stash
+// tile per workgroup): it takes part in every barrier and issues its share of the DMA pieces, nothing else.
+template <int MODE, bool RB, bool ACTIVE>
+struct SirenTile {
+  static constexpr int TL = W2_TL;
+  const NetDesc& nd;
+  const LossDesc& ld;
+  const MlpArgs& a;
+  PnRing& r;
+  const float* bias_lds;
+  const float* encB_lds;
+  unsigned* phz;  // this wave's landing zone for phase fetches: [4 sets][4][64 lanes] dwords
+  int lane, half, col, wcol, w;
+  float mult;        // what the loss gradient is multiplied by (inr_w2.h: gradient-scale state)
+  float amax = 0.f;  // max |dZ * mult| this wave has stashed
+  float loss_acc = 0.f;
+
+  // per tile
+  unsigned* sv;
+  int ts_bytes, voff;
+  long long crow;
+  bool valid, tile_ok;
+  __amdgpu_buffer_rsrc_t rs_tile;
+  bf16x8 hIn[16], hOut[16];
+
+  __device__ __forceinline__ SirenTile(const NetDesc& nd_, const LossDesc& ld_, const MlpArgs& a_, PnRing& r_,
+                                       const float* bias, const float* encB, unsigned* phz_, int lane_, int w_, float mult_)
+      : nd(nd_), ld(ld_), a(a_), r(r_), bias_lds(bias), encB_lds(encB), phz(phz_), lane(lane_), half(lane_ >> 5), col(lane_ & 31),
+        wcol((w_ & 3) * 32 + (lane_ & 31)), w(w_), mult(mult_) {}
+
+  // -------- forward epilogue of row block mm of hidden layer l: t = acc + bias (revolutions) -> phase bytes to the
+  // stash, h = sin(2 pi t) -> B operands 2 mm, 2 mm + 1 of the next layer
+  __device__ __forceinline__ void epi_fwd(int l, int mm, const f32x16& acc, bf16x8 (&out)[16], int slot) {
+    const float* bl = bias_lds + l * 256 + 32 * mm + 4 * half;
+    const float magic = 49152.0f;
+    const int so0 = (w2_stash_P(l) + 8 * mm * TL) * 4;
+    float hv[16];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    bf16x8 A[8];
-#pragma unroll
-    for (int m = 0; m < 8; ++m) A[m] = w2_frag(ring, q, s, m, lane);
-#pragma unroll
-    for (int m = 0; m < 8; ++m) acc[m] = mfma_bf16(A[m], b[s], acc[m]);
-    if (REQUEST && s == 0) w2_request(gbase, q, NQ, ring, w, lane);
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(bl + 8 * g);
+      unsigned pk = 0;
+      const float t0 = acc[4 * g + 0] + b4[0], t1 = acc[4 * g + 1] + b4[1], t2 = acc[4 * g + 2] + b4[2],
+                  t3 = acc[4 * g + 3] + b4[3];
+      hv[4 * g + 0] = __builtin_amdgcn_sinf(t0);
+      hv[4 * g + 1] = __builtin_amdgcn_sinf(t1);
+      hv[4 * g + 2] = __builtin_amdgcn_sinf(t2);
+      hv[4 * g + 3] = __builtin_amdgcn_sinf(t3);
+      phase_byte<0>(pk, t0, magic);
+      phase_byte<1>(pk, t1, magic);
+      phase_byte<2>(pk, t2, magic);
+      phase_byte<3>(pk, t3, magic);
+      __builtin_amdgcn_raw_buffer_store_b32(pk, rs_tile, voff, so0 + 2 * g * TL * 4, 0);  // quad 8 mm + 2 g (+ half in voff)
+    }
+    out[slot] = pack8(hv);
+    out[slot + 1] = pack8(hv + 8);
   }
-}
+
+  // -------- backward epilogues: sequence e = 0, 1, ...: row block e & 7 of dZ_lz, lz = D-2 - (e >> 3)
+  // fetch the four phase dwords of row block mm of layer lz (quads 8 mm + 2 g + half, g = 0..3) into set SET (= row block
+  // & 3) of the landing zone.  lz < 0: past the tile's last epilogue -- the fetches are issued all the same, from layer 0,
+  // so that the counted waits see a uniform sequence (tiles past the batch point at tile 0: the reads are always valid)
+  template <int SET>
+  __device__ __forceinline__ void bwd_loads(int lz, int mm) {
+    const unsigned* src = sv + w2_stash_P(lz < 0 ? 0 : lz) + (8 * mm + half) * TL + wcol;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 2 * g * TL),
+                                       (__attribute__((address_space(3))) void*)(phz + (SET * 4 + g) * 64), 4, 0, 0);
+  }
+  // dZ = acc * cos(2 pi phase) (the transposed image carries w0): bf8 to the stash, bf16 into the next B operands.
+  // WAIT: vector-memory operations issued since the set's fetches
+  template <int SET, int WAIT>
+  __device__ __forceinline__ void epi_bwd(int lz, int mm, const f32x16& acc, bf16x8 (&out)[16], int slot) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT) : "memory");
+    const int so0 = (w2_stash_G(lz, nd.D) + 8 * mm * TL) * 4;
+    float dz[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const unsigned pw = phz[(SET * 4 + g) * 64 + lane];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float c = __builtin_amdgcn_cosf((float)((pw >> (8 * j)) & 255u) * 0.00390625f);
+        dz[4 * g + j] = acc[4 * g + j] * c;
+      }
+      amax = fmaxf(amax, fmaxf(fabsf(dz[4 * g]), fabsf(dz[4 * g + 1])));
+      amax = fmaxf(amax, fmaxf(fabsf(dz[4 * g + 2]), fabsf(dz[4 * g + 3])));
+      int pk = __builtin_amdgcn_cvt_pk_bf8_f32(dz[4 * g], dz[4 * g + 1], 0, false);
+      pk = __builtin_amdgcn_cvt_pk_bf8_f32(dz[4 * g + 2], dz[4 * g + 3], pk, true);
+      __builtin_amdgcn_raw_buffer_store_b32((unsigned)pk, rs_tile, voff, so0 + 2 * g * TL * 4, 0);
+    }
+    out[slot] = pack8(dz);
+    out[slot + 1] = pack8(dz + 8);
+  }
+
+  __device__ __forceinline__ void copy_out_to_in() {
+#pragma unroll
+    for (int t = 0; t < 16; ++t) hIn[t] = hOut[t];
+  }
+
+  // -------- the tile ------------------------------------------------------------------------------------------------
+  // stile: this group's stash tile (may be past the batch: then every stash access is a no-op and the lanes compute on
+  // zeros).  Returns with every epilogue of the tile done.
+  __device__ __forceinline__ void run(int stile) {
+    const int D = nd.D, E = nd.E;
+    const int nq0 = E / 32;  // layer-0 chunks of 64 encoder features (two panels each)
+    constexpr bool FWD = MODE != MODE_BWD, BWD = MODE != MODE_FWD;
+    float x0 = 0.f, x1 = 0.f, x2 = 0.f, gtv[4] = {0.f, 0.f, 0.f, 0.f};
+    bool sampled = false;
+    if (ACTIVE) {
+      tile_ok = stile < a.n_tiles;
+      crow = (long long)stile * TL + wcol;
+      valid = tile_ok && crow < a.B;
+      sv = reinterpret_cast<unsigned*>(a.save) + (size_t)(tile_ok ? stile : 0) * nd.save_floats_per_tile;
+      ts_bytes = (tile_ok && a.save != nullptr) ? w2_stash_dwords(D) * 4 : 0;  // 0: every stash access is a no-op
+      voff = (half * TL + wcol) * 4;  // the lane's byte offset inside a quad pair: quad parity = lane half, own coordinate
+      rs_tile = uniform_rsrc(sv, ts_bytes);
+      if (FWD) {  // coordinates, sampling mask and target row in one batch of loads (row 0 where the lane has none)
+        const long long cr = valid ? crow : 0;
+        x0 = a.x[3 * cr + 0];
+        x1 = a.x[3 * cr + 1];
+        x2 = a.x[3 * cr + 2];
+        unsigned char mk = 1;
+        if (MODE == MODE_FUSED) {
+          if (a.mask != nullptr) mk = a.mask[cr];
+#pragma unroll
+          for (int o = 0; o < 4; ++o)
+            if (o < nd.out_f) gtv[o] = a.gt[cr * nd.out_f + o];
+        }
+        if (!valid) x0 = x1 = x2 = 0.f;
+        sampled = valid && half == 0 && mk != 0;
+      }
+    }
+    const float quarter = half ? 0.25f : 0.f;
+    int si = 0;  // diagnostic builds: phase stamps 0, 1, 2, ... in program order (tools/stamps.py)
+    constexpr int NW = PN_WAVES;
+    (void)si;
+    (void)NW;
+    INR_STAMP(si); ++si;
+
+    float dzl[4] = {0.f, 0.f, 0.f, 0.f};
+    if (FWD) {
+      // ================================ layer 0 ================================
+      // 2E encoder features per coordinate, generated per K-step on the vector ALUs (half 0: sines, half 1: cosines of
+      // features 8t .. 8t+7), contraction outermost: eight accumulator blocks.  Role A forms the features of chunk
+      // ch + 1 behind the MFMAs of chunk ch, role B those of chunk ch in front of them.
+      f32x16 acc8[8];
+      bf16x8 bq[4];
+      auto gen = [&](int ch) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int t = 4 * ch + s;
+          float f[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float* bj = encB_lds + 3 * (8 * t + j);
+            f[j] = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(fmaf(x2, bj[2], fmaf(x1, bj[1], fmaf(x0, bj[0], quarter)))));
+          }
+          bq[s] = pack8(f);
+        }
+      };
+      auto mma_chunk = [&]() {  // panels r.p (K-steps 0, 1 of the chunk) and r.p + 1 (K-steps 2, 3)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          bf16x8 A[8];
+#pragma unroll
+          for (int m = 0; m < 8; ++m) A[m] = pn_frag(r, (s >> 1) ? pn_next(r.slot) : r.slot, (s & 1) * 8 + m);
+#pragma unroll
+          for (int m = 0; m < 8; ++m) acc8[m] = mfma_bf16(A[m], bq[s], acc8[m]);
+        }
+      };
+      if (ACTIVE) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) acc8[m] = zero16();
+        if (!RB) gen(0);
+      }
+      for (int ch = 0; ch < nq0; ++ch) {
+        if (ch == 0)
+          pn_begin<8>(r);  // c = 2 behind c_prev <= 1
+        else
+          pn_begin<6>(r);  // c = 2 behind c_prev = 2
+        if (ACTIVE) {
+          if (RB) gen(ch);
+          mma_chunk();
+          if (!RB && ch + 1 < nq0) gen(ch + 1);
+        }
+        pn_advance(r, 2);
+      }
+      INR_STAMP(si); ++si;
+      // epilogue of layer 0, all eight row blocks (both roles: the 128 accumulator registers are free before the hidden
+      // layers, whose loop keeps two sets of B operands)
+      if (ACTIVE) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) epi_fwd(0, m, acc8[m], hIn, 2 * m);
+      }
+      INR_STAMP(si); ++si;
+
+      // ================================ hidden layers 1 .. D-2 ================================
+      f32x16 acc = zero16();
+      for (int l = 1; l < D - 1; ++l) {
+        const bool first = l == 1;
+        static_for<0, 8>([&](auto mc) {
+          constexpr int m = decltype(mc)::value;
+          // requests: 10 operations behind the panel's pieces (8 behind a layer-0 chunk); + 4 stores per hidden interval (at
+          // most the six in front), counted from the layer's second interval in the first layer (role B's first has no epilogue)
+          constexpr int N0 = m == 0 ? 8 : 10, NF = N0 + 4 * (m > 0 ? (m - 1 > 6 ? 6 : m - 1) : 0), NS = 34;
+          if (!ACTIVE) {
+            if (first) pn_begin<N0>(r); else pn_begin<10>(r);
+          } else if (first) {
+            pn_begin<NF>(r);
+          } else {
+            pn_begin<NS>(r);
+          }
+          if (ACTIVE) {
+            if (RB) {
+              if (m == 0) {
+                if (!first) {
+                  epi_fwd(l - 1, 7, acc, hOut, 14);
+                  copy_out_to_in();
+                }
+              } else {
+                epi_fwd(l, m - 1, acc, hOut, 2 * (m > 0 ? m - 1 : 0));
+              }
+              acc = pn_mma_block(r, r.slot, hIn);
+            } else {
+              acc = pn_mma_block(r, r.slot, hIn);
+              epi_fwd(l, m, acc, hOut, 2 * m);
+              if (m == 7) copy_out_to_in();
+            }
+          }
+          pn_advance(r, 1);
+        });
+        INR_STAMP(si); ++si;
+      }
+
+      // ================================ last layer: one row block (rows 0 .. out_f-1 live) ================================
+      if (ACTIVE) pn_begin<34>(r); else pn_begin<10>(r);
+      if (ACTIVE) {
+        if (RB) {
+          epi_fwd(D - 2, 7, acc, hOut, 14);
+          copy_out_to_in();
+        }
+        const f32x16 accL = pn_mma_block(r, r.slot, hIn);
+        float y[4], dy[4], g[4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+          float z = accL[o];  // half 0: rows 0..3
+          if (o < nd.out_f) z += bias_lds[(D - 1) * 256 + o];
+          act_fwd_rt(nd.last_act, z, nd.w0, y[o], dy[o]);
+          g[o] = 0.f;
+          if (half == 0 && valid && o < nd.out_f && a.out != nullptr) a.out[crow * nd.out_f + o] = y[o];
+        }
+        if (MODE == MODE_FUSED) {
+          if (sampled) loss_acc += loss_row(ld, nd.out_f, y, gtv, g);
+#pragma unroll
+          for (int o = 0; o < 4; ++o) dzl[o] = (half == 0 && o < nd.out_f) ? g[o] * dy[o] * mult : 0.f;
+        } else if (half == 0 && ts_bytes != 0) {  // split step: act'(z_last) for the backward half
+          f32x4 d4 = {dy[0], dy[1], dy[2], dy[3]};
+          *reinterpret_cast<f32x4*>(sv + w2_stash_dy(D) + 4 * wcol) = d4;
+        }
+      }
+      pn_advance(r, 1);
+      INR_STAMP(si); ++si;
+    }
+
+    if (BWD) {
+      if (MODE == MODE_BWD && ACTIVE) {  // d(loss)/d(out) from the caller, act'(z_last) from the forward half
+        if (valid && half == 0) {
+          const f32x4 d4 = *reinterpret_cast<const f32x4*>(sv + w2_stash_dy(D) + 4 * wcol);
+#pragma unroll
+          for (int o = 0; o < 4; ++o)
+            if (o < nd.out_f) dzl[o] = a.dout[crow * nd.out_f + o] * d4[o] * mult;
+        }
+      }
+      // ================================ dH_{D-2} = W_last^T dZ_last: one K-step, eight row blocks ================================
+      pn_begin<10>(r);
+      f32x16 acc = zero16();
+      if (ACTIVE) {
+        // dZ_last rows (0,1), (2,3) of this coordinate as fp16 pairs: two dwords behind the 8-bit tensors
+        if (half == 0 && ts_bytes != 0) {
+          unsigned* dzL = sv + w2_stash_dzl(D);
+          dzL[wcol] = pack_f16(dzl[0], dzl[1]);
+          dzL[TL + wcol] = pack_f16(dzl[2], dzl[3]);
+        }
+        float v[8] = {dzl[0], dzl[1], dzl[2], dzl[3], 0.f, 0.f, 0.f, 0.f};
+        const bf16x8 b0 = pack8(v);  // k = output row: element j of half 0 is row j for j < 4
+        static_for<0, PN_PD>([&](auto ec) { bwd_loads<decltype(ec)::value & 3>(D - 2, decltype(ec)::value); });
+        static_for<0, 8>([&](auto mc) {
+          constexpr int m = decltype(mc)::value;
+          bwd_loads<(m + PN_PD) & 3>(D - 2 - ((m + PN_PD) >> 3), (m + PN_PD) & 7);
+          const f32x16 a1 = mfma_bf16(pn_frag(r, r.slot, m), b0, zero16());
+          // behind these loads: 4 (PD + e) operations for the first PD epilogues, then 8 PD
+          epi_bwd<m & 3, (m < PN_PD ? 4 * (PN_PD + m) : 8 * PN_PD)>(D - 2, m, a1, hOut, 2 * m);
+        });
+        copy_out_to_in();
+      }
+      pn_advance(r, 1);
+      INR_STAMP(si); ++si;
+
+      // ================================ dH_{l-1} = W_l^T dZ_l, l = D-2 .. 1 ================================
+      for (int l = D - 2; l >= 1; --l) {
+        const bool first = l == D - 2;
+        static_for<0, 8>([&](auto mc) {
+          constexpr int m = decltype(mc)::value;
+          // + 8 stash operations per interval (at most the six in front), counted from the second interval of the first layer
+          // (role B's first has none)
+          constexpr int NF = 10 + 8 * (m > 0 ? (m - 1 > 6 ? 6 : m - 1) : 0), NS = 58;
+          if (!ACTIVE) {
+            pn_begin<10>(r);
+          } else if (first) {
+            pn_begin<NF>(r);
+          } else {
+            pn_begin<NS>(r);
+          }
+          if (ACTIVE) {
+            // epilogue e = 8 (D-1-l) + m produces row block m of dZ_{l-1}; its loads were issued PD epilogues ago
+            if (RB) {
+              if (m == 0) {
+                if (!first) {  // row block 7 of dZ_l, then the layer's B operands are complete
+                  bwd_loads<(7 + PN_PD) & 3>(l - ((7 + PN_PD) >> 3), (7 + PN_PD) & 7);
+                  epi_bwd<3, 8 * PN_PD>(l, 7, acc, hOut, 14);
+                  copy_out_to_in();
+                }
+              } else {
+                constexpr int mp = m > 0 ? m - 1 : 0;
+                bwd_loads<(mp + PN_PD) & 3>(l - 1 - ((mp + PN_PD) >> 3), (mp + PN_PD) & 7);
+                epi_bwd<mp & 3, 8 * PN_PD>(l - 1, mp, acc, hOut, 2 * mp);
+              }
+              acc = pn_mma_block(r, r.slot, hIn);
+            } else {
+              acc = pn_mma_block(r, r.slot, hIn);
+              bwd_loads<(m + PN_PD) & 3>(l - 1 - ((m + PN_PD) >> 3), (m + PN_PD) & 7);
+              epi_bwd<m & 3, 8 * PN_PD>(l - 1, m, acc, hOut, 2 * m);
+              if (m == 7 && l > 1) copy_out_to_in();
+            }
+          }
+          pn_advance(r, 1);
+        });
+        INR_STAMP(si); ++si;
+      }
+      if (ACTIVE && RB) {  // role B's last epilogue: row block 7 of dZ_0
+        bwd_loads<(7 + PN_PD) & 3>(-1, (7 + PN_PD) & 7);
+        epi_bwd<3, 8 * PN_PD>(0, 7, acc, hOut, 14);
+      }
+      INR_STAMP(si); ++si;
+    }
+  }
+};
 
 // ---- the kernel ---------------------------------------------------------------------------------------------------
-// Workgroup tile = 256 coordinates = two stash tiles of TL = 128 (what the GEMM kernel and the host count in); wave w
-// owns coordinates [32 (w & 3), + 32) of stash tile 2 * (workgroup tile) + (w >> 2): lane (col, half).  MODE_FUSED only.
+// Workgroup = eight waves = two tile groups; group g = waves 4g .. 4g+3 works on stash tile tpw * (workgroup tile) + g;
+// wave w owns coordinates [32 (w & 3), + 32) of it: lane (col, half).
+template <int MODE>
 __global__ __launch_bounds__(512, 2) void inr_siren_bf16_kernel(const NetDesc nd, const LossDesc ld, const MlpArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
-  constexpr int TL = 128, NB = 8, NW = W2_WAVES;
-  constexpr int HSZ2 = NB * 32 * TL;  // 2-byte elements per stashed tensor
+  constexpr int NW = PN_WAVES;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: LDS-DMA destinations go through M0
-  const int half = lane >> 5, col = lane & 31;
-  const int wcol = (w & 3) * 32 + col;
-  char* ring = lds_raw;
-  float* bias_lds = reinterpret_cast<float*>(lds_raw + W2_SLOTS * W2_CHUNK_BYTES);  // [D][256]
+  unsigned* phz = reinterpret_cast<unsigned*>(lds_raw + PN_SLOTS * W2_PANEL_BYTES) + w * 1024;  // [8 waves][4 sets][4][64]
+  float* bias_lds = reinterpret_cast<float*>(lds_raw + PN_SLOTS * W2_PANEL_BYTES + PN_PHASE_BYTES);  // [D][256]
   float* encB_lds = bias_lds + nd.D * 256;                                          // [E][3]
   float* red_lds = encB_lds + 3 * nd.E;                                             // [8]
   const int D = nd.D, E = nd.E;
-  const char* gbase = reinterpret_cast<const char*>(a.packed + nd.w2_off);
   for (int i = tid; i < D * 256; i += 64 * NW) bias_lds[i] = a.packed[nd.w2_bias_off + i];
-  for (int i = tid; i < 3 * E; i += 64 * NW) encB_lds[i] = a.encB[i];
-  const int nq0 = w2_nq0(E), NQ = w2_nq(D, E);
-  // prime the ring: stream positions 0 .. 3 (the first chunk of a phase requests nothing)
-  w2_issue(gbase, 0, 0, ring, w, lane);
-  w2_issue(gbase, 1 % NQ, 1, ring, w, lane);
-  w2_issue(gbase, 2 % NQ, 2, ring, w, lane);
-  w2_issue(gbase, 3 % NQ, 3, ring, w, lane);
-  __syncthreads();  // tables in LDS (the DMAs are waited for by the first acquire)
-  float loss_acc = 0.f;
-  int qs = 0;  // stream position (chunks consumed so far by this workgroup); chunk image = qs % NQ
-  const float w0 = nd.w0, krev = nd.w0 * 0.15915494309189535f;
-  // two stash tiles per workgroup tile -- unless the batch is too small to fill the chip that way (25 000 rows = 196
-  // tiles: 98 workgroups on 256 CUs): then one, and waves 4..7 only help with the weight stream
+  for (int i = tid; i < 3 * E; i += 64 * NW) encB_lds[i] = a.encB != nullptr ? a.encB[i] : 0.f;
+  PnRing r;
+  r.gbase = reinterpret_cast<const char*>(a.packed + nd.w2_off);
+  r.ring = lds_raw;
+  r.first = MODE == MODE_BWD ? w2_n_fwd(D, E) : 0;
+  r.len = MODE == MODE_FUSED ? w2_np(D, E) : (MODE == MODE_FWD ? w2_n_fwd(D, E) : w2_np(D, E) - w2_n_fwd(D, E));
+  r.p = 0, r.slot = 0, r.req = 0, r.req_img = 0, r.req_slot = 0;
+  r.w = w, r.lane = lane;
+  pn_request(r);    // prime the ring: positions 0 .. 6
+  __syncthreads();  // tables in LDS (the DMAs are waited for by the first interval)
+
+  // gradient-scale state (inr_w2.h): fused steps and split steps keep their own
+  float* st = a.dz_state != nullptr ? a.dz_state + (MODE == MODE_BWD ? 4 : 0) : nullptr;
+  float mult = 1.f;
+  if (MODE != MODE_FWD && st != nullptr) {
+    const float S = st[0];
+    mult = MODE == MODE_FUSED ? S / ld.inv_count : S;
+  }
+  // two stash tiles per workgroup -- unless the batch is too small to fill the chip that way (25 000 rows = 196 tiles:
+  // 98 workgroups on 256 CUs): then one, and waves 4..7 only help with the weight stream
   const int tpw = a.n_tiles > 256 ? 2 : 1;
   const int n_wtiles = (a.n_tiles + tpw - 1) / tpw;
-
-  for (int wtile = blockIdx.x; wtile < n_wtiles; wtile += gridDim.x) {
-    const int stile = tpw * wtile + (w >> 2);     // this wave's stash tile
-    const bool tile_ok = (w >> 2) < tpw && stile < a.n_tiles;  // (odd tile counts: the last workgroup tile is half empty)
-    if ((w >> 2) >= tpw) {  // small batches: this half of the workgroup has no tile -- it only feeds the ring
-      // the working half's phases: layer 0, hidden layers, last layer, dX of the last layer, dX of the hidden layers
-      w2_phase_loader_only(gbase, qs, nq0, true, NQ, ring, w, lane);
-      for (int l = 1; l < D - 1; ++l) w2_phase_loader_only(gbase, qs, 4, false, NQ, ring, w, lane);
-      w2_phase_loader_only(gbase, qs, 1, false, NQ, ring, w, lane);
-      w2_phase_loader_only(gbase, qs, 1, false, NQ, ring, w, lane);
-      for (int l = D - 2; l >= 1; --l) w2_phase_loader_only(gbase, qs, 4, false, NQ, ring, w, lane);
-      continue;
-    }
-    const long long crow = (long long)stile * TL + wcol;
-    const bool valid = tile_ok && crow < a.B;
-    unsigned* sv = reinterpret_cast<unsigned*>(a.save + (size_t)(tile_ok ? stile : 0) * nd.save_floats_per_tile);
-    const int ts_bytes = tile_ok ? HSZ2 * 2 : 0;  // extent of a stashed tensor: 0 makes every buffer access a no-op
-    // per-lane byte offset inside a stashed tensor: pair (2 half) of block 0 group 0, own coordinate
-    const int voff = (2 * half * TL + wcol) * 4;
-    // coordinates, sampling mask and target row in ONE batch of loads (from row 0 where the lane has no coordinate): nested
-    // under `if (valid) ... if (mask[crow])` they were three serialized round trips at the start of every tile
-    float x0, x1, x2, gtv[4] = {0.f, 0.f, 0.f, 0.f};
-    bool sampled;
-    {
-      const long long cr = valid ? crow : 0;
-      x0 = a.x[3 * cr + 0];
-      x1 = a.x[3 * cr + 1];
-      x2 = a.x[3 * cr + 2];
-      const unsigned char mk = a.mask != nullptr ? a.mask[cr] : (unsigned char)1;
-#pragma unroll
-      for (int o = 0; o < 4; ++o)
-        if (o < nd.out_f) gtv[o] = a.gt[cr * nd.out_f + o];
-      if (!valid) x0 = x1 = x2 = 0.f;
-      sampled = valid && half == 0 && mk != 0;
-    }
-    const float quarter = half ? 0.25f : 0.f;
-    bf16x8 hB[16];  // B operands of the next GEMM: K-step t = 2 m + s  <-  registers 8s .. 8s+7 of accumulator block m
-    f32x16 acc[NB];
-    int si = 0;  // diagnostic builds: phase stamps 0, 1, 2, ... in program order (tools/stamps.py bf16)
-
-    // epilogue of a forward hidden layer l: z = acc + bias -> stash (fp16 pairs), h = sin(w0 z) -> hB
-    auto fwd_epilogue = [&](int l) {
-      const __amdgpu_buffer_rsrc_t rs = uniform_rsrc(sv + (size_t)l * (HSZ2 / 2), ts_bytes);
-      const float* bl = bias_lds + l * 256 + 4 * half;
-#pragma unroll
-      for (int m = 0; m < NB; ++m) {
-        float hv[16];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x4 b4 = *reinterpret_cast<const f32x4*>(bl + 32 * m + 8 * g);
-          float z[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            z[j] = acc[m][4 * g + j] + b4[j];
-            hv[4 * g + j] = __builtin_amdgcn_sinf(z[j] * krev);
-          }
-          const int so = (16 * m + 4 * g) * TL * 4;  // pair 16 m + 4 g (+ 2 half in voff), then the next pair
-          __builtin_amdgcn_raw_buffer_store_b32(pack_f16(z[0], z[1]), rs, voff, so, 0);
-          __builtin_amdgcn_raw_buffer_store_b32(pack_f16(z[2], z[3]), rs, voff, so + TL * 4, 0);
-        }
-        float lo[8], hi[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          lo[j] = hv[j];
-          hi[j] = hv[8 + j];
-        }
-        hB[2 * m] = pack8(lo);
-        hB[2 * m + 1] = pack8(hi);
-      }
-    };
-
-    // ================================ forward =================================
-    INR_STAMP(si); ++si;
-    // ---- layer 0: 2E encoder features generated per K-step (half 0: sines, half 1: cosines of features 8t .. 8t+7)
-#pragma unroll
-    for (int m = 0; m < NB; ++m) acc[m] = zero16();
-    for (int ch = 0; ch < nq0; ++ch) {
-      if (ch == 0)
-        w2_chunk<0>();  // tile start: drain (the previous tile's last epilogue, the x loads)
-      else
-        w2_chunk<8>();
-      bf16x8 b[4];
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int t = 4 * ch + s;
-        float f[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float* bj = encB_lds + 3 * (8 * t + j);
-          f[j] = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(fmaf(x2, bj[2], fmaf(x1, bj[1], fmaf(x0, bj[0], quarter)))));
-        }
-        b[s] = pack8(f);
-      }
-      if (ch == 0)
-        w2_chunk_mma<false>(acc, ring, qs, b, lane, gbase, NQ, w);
-      else
-        w2_chunk_mma<true>(acc, ring, qs, b, lane, gbase, NQ, w);
-      ++qs;
-    }
-    w2_phase_end(gbase, qs, NQ, ring, w, lane);
-    INR_STAMP(si); ++si;
-    fwd_epilogue(0);
-    INR_STAMP(si); ++si;
-    // ---- hidden layers 1 .. D-2
-    for (int l = 1; l < D - 1; ++l) {
-#pragma unroll
-      for (int m = 0; m < NB; ++m) acc[m] = zero16();
-#pragma unroll
-      for (int ch = 0; ch < 4; ++ch) {
-        // the four chunks behind fwd_epilogue(l - 1)'s 64 stores
-        w2_chunk<63>();
-        const bf16x8 b[4] = {hB[4 * ch], hB[4 * ch + 1], hB[4 * ch + 2], hB[4 * ch + 3]};
-        if (ch == 0)
-          w2_chunk_mma<false>(acc, ring, qs, b, lane, gbase, NQ, w);
-        else
-          w2_chunk_mma<true>(acc, ring, qs, b, lane, gbase, NQ, w);
-        ++qs;
-      }
-      w2_phase_end(gbase, qs, NQ, ring, w, lane);
-      INR_STAMP(si); ++si;
-      fwd_epilogue(l);
-      INR_STAMP(si); ++si;
-    }
-    // ---- last layer: one row block (rows 0 .. out_f-1 live), its 16 K-steps in ONE chunk
-    f32x16 accL = zero16();
-    w2_chunk<63>();  // first chunk behind fwd_epilogue(D - 2)'s 64 stores
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const bf16x8 A = *reinterpret_cast<const bf16x8*>(ring + (qs & (W2_SLOTS - 1)) * W2_CHUNK_BYTES + (t * 64 + lane) * 16);
-      accL = mfma_bf16(A, hB[t], accL);
-    }
-    ++qs;
-    w2_phase_end(gbase, qs, NQ, ring, w, lane);
-    INR_STAMP(si); ++si;
-    float y[4], dy[4], g[4];
-#pragma unroll
-    for (int o = 0; o < 4; ++o) {
-      float z = accL[o];  // half 0: rows 0..3
-      if (o < nd.out_f) z += bias_lds[(D - 1) * 256 + o];
-      act_fwd_rt(nd.last_act, z, w0, y[o], dy[o]);
-      g[o] = 0.f;
-      if (half == 0 && valid && o < nd.out_f && a.out != nullptr) a.out[crow * nd.out_f + o] = y[o];
-    }
-    if (sampled) loss_acc += loss_row(ld, nd.out_f, y, gtv, g);
-    float dzl[4];
-#pragma unroll
-    for (int o = 0; o < 4; ++o) dzl[o] = (half == 0 && o < nd.out_f) ? g[o] * dy[o] : 0.f;
-    // dZ_last rows (0,1), (2,3) of this coordinate: two dwords behind the hidden tensors (read by the GEMM kernel)
-    if (half == 0 && tile_ok) {
-      unsigned* dzL = sv + (size_t)2 * (D - 1) * (HSZ2 / 2);
-      dzL[wcol] = pack_bf16(dzl[0], dzl[1]);
-      dzL[TL + wcol] = pack_bf16(dzl[2], dzl[3]);
-    }
-
-    // ================================ backward ================================
-    INR_STAMP(si); ++si;
-    // dH_{D-2} = W_last^T dZ_last: one K-step (k = output row: element j of half 0 is row j for j < 4)
-    {
-      float v[8] = {dzl[0], dzl[1], dzl[2], dzl[3], 0.f, 0.f, 0.f, 0.f};
-      const bf16x8 b0 = pack8(v);
-#pragma unroll
-      for (int m = 0; m < NB; ++m) acc[m] = zero16();
-      w2_chunk<63>();  // second chunk behind fwd_epilogue(D - 2)'s 64 stores
-#pragma unroll
-      for (int m = 0; m < NB; ++m) acc[m] = mfma_bf16(w2_frag(ring, qs, 0, m, lane), b0, acc[m]);  // K-steps 1..3: zero weights
-      ++qs;
-      w2_phase_end(gbase, qs, NQ, ring, w, lane);
-    }
-    INR_STAMP(si); ++si;
-    for (int l = D - 2; l >= 0; --l) {
-      // dZ_l = dH_l * w0 cos(w0 z_l): z_l back from the stash (row pairs), dZ_l to the stash and into hB
-      const __amdgpu_buffer_rsrc_t rg = uniform_rsrc(sv + (size_t)(D - 1 + l) * (HSZ2 / 2), ts_bytes);
-      // the layer's 64 row pairs of this coordinate, all in flight before the first use (the B operands of the GEMM
-      // that just ended are dead, the next ones not yet formed: the registers are there)
-      // The loads are INLINE ASSEMBLY with hand-placed waits (w2_wait_rows): gfx9 has one counter for vector loads and
-      // stores, hipcc's wait insertion treats loads and stores pending together as able to return out of order and
-      // answers every such wait with vmcnt(0) -- here that drained all 64 loads AND the weight DMAs in flight in front
-      // of the first row block (the backward epilogues took 14-18 k cycles against 5 k forward; without the dZ stores,
-      // i.e. with only loads pending, the same code ran at forward speed).  The counter retires in order: behind the
-      // last load of row block m lie the 8 (7 - m) later loads and the 8 m stores of the blocks already done = 56.
-      unsigned zall[NB][8];
-      const u32x4 rz4 = w2_rsrc_words(sv + (size_t)l * (HSZ2 / 2), ts_bytes);
-#pragma unroll
-      for (int m = 0; m < NB; ++m)
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-          const int so = (16 * m + 4 * gq) * TL * 4;
-          zall[m][2 * gq] = (m == 0 && gq == 0) ? w2_load_asm_first(rz4, voff, so) : w2_load_asm(rz4, voff, so);
-          zall[m][2 * gq + 1] = w2_load_asm(rz4, voff, so + TL * 4);
-        }
-#pragma unroll
-      for (int m = 0; m < NB; ++m) {
-        w2_wait_rows<56>(zall[m]);
-        const unsigned (&zz)[8] = zall[m];
-        float dz[16];
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-#pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            const f16x2 zp = __builtin_bit_cast(f16x2, zz[2 * gq + e]);
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-              const float c = __builtin_amdgcn_cosf((float)zp[k] * krev);
-              dz[4 * gq + 2 * e + k] = acc[m][4 * gq + 2 * e + k] * (w0 * c);
-            }
-          }
-          const int so = (16 * m + 4 * gq) * TL * 4;
-          __builtin_amdgcn_raw_buffer_store_b32(pack_bf16(dz[4 * gq], dz[4 * gq + 1]), rg, voff, so, 0);
-          __builtin_amdgcn_raw_buffer_store_b32(pack_bf16(dz[4 * gq + 2], dz[4 * gq + 3]), rg, voff, so + TL * 4, 0);
-        }
-        float lo[8], hi[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          lo[j] = dz[j];
-          hi[j] = dz[8 + j];
-        }
-        hB[2 * m] = pack8(lo);  // (hB is free: the forward pass is over)
-        hB[2 * m + 1] = pack8(hi);
-        __builtin_amdgcn_sched_barrier(0);  // row block by row block, so that each waits for its own eight loads only
-      }
-      INR_STAMP(si); ++si;
-      if (l == 0) break;
-      // dH_{l-1} = W_l^T dZ_l
-#pragma unroll
-      for (int m = 0; m < NB; ++m) acc[m] = zero16();
-#pragma unroll
-      for (int ch = 0; ch < 4; ++ch) {
-        // the four chunks behind the backward epilogue's 64 stores
-        w2_chunk<63>();
-        const bf16x8 b[4] = {hB[4 * ch], hB[4 * ch + 1], hB[4 * ch + 2], hB[4 * ch + 3]};
-        if (ch == 0)
-          w2_chunk_mma<false>(acc, ring, qs, b, lane, gbase, NQ, w);
-        else
-          w2_chunk_mma<true>(acc, ring, qs, b, lane, gbase, NQ, w);
-        ++qs;
-      }
-      w2_phase_end(gbase, qs, NQ, ring, w, lane);
-      INR_STAMP(si); ++si;
-    }
+  float loss_acc = 0.f, amax = 0.f;
+  if (w < 4) {
+    SirenTile<MODE, false, true> t(nd, ld, a, r, bias_lds, encB_lds, phz, lane, w, mult);
+    for (int wtile = blockIdx.x; wtile < n_wtiles; wtile += gridDim.x) t.run(tpw * wtile);
+    loss_acc = t.loss_acc, amax = t.amax;
+  } else if (tpw == 2) {
+    SirenTile<MODE, true, true> t(nd, ld, a, r, bias_lds, encB_lds, phz, lane, w, mult);
+    for (int wtile = blockIdx.x; wtile < n_wtiles; wtile += gridDim.x) t.run(tpw * wtile + 1);
+    loss_acc = t.loss_acc, amax = t.amax;
+  } else {
+    SirenTile<MODE, true, false> t(nd, ld, a, r, bias_lds, encB_lds, phz, lane, w, mult);
+    for (int wtile = blockIdx.x; wtile < n_wtiles; wtile += gridDim.x) t.run(0);
   }
   // every DMA this wave issued has landed before the workgroup (and its LDS) goes away
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  // block loss partial -> slab loss word (fixed order: wave shuffle tree, then waves in order)
-  float v = loss_acc;
+  if (MODE != MODE_FWD) {
+    // the step's largest scaled |dZ|: non-negative floats order like their bit patterns
+    float m = amax;
 #pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-  __syncthreads();
-  if (lane == 0) red_lds[w] = v;
-  __syncthreads();
-  if (tid == 0) {
-    float t = 0.f;
-    for (int i = 0; i < NW; ++i) t += red_lds[i];
-    a.slabs[(size_t)blockIdx.x * nd.slab_floats + nd.slab_loss_off] = t;
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if (lane == 0 && st != nullptr && m > 0.f) atomicMax(reinterpret_cast<unsigned*>(st) + 1, __builtin_bit_cast(unsigned, m));
+    if (blockIdx.x == 0 && tid == 0 && st != nullptr) {
+      st[2] = mult;
+      st[3] = st[0];
+    }
+  }
+  if (MODE == MODE_FUSED) {
+    // block loss partial -> slab loss word (fixed order: wave shuffle tree, then waves in order)
+    float v = loss_acc;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    __syncthreads();
+    if (lane == 0) red_lds[w] = v;
+    __syncthreads();
+    if (tid == 0) {
+      float t = 0.f;
+      for (int i = 0; i < NW; ++i) t += red_lds[i];
+      a.slabs[(size_t)blockIdx.x * nd.slab_floats + nd.slab_loss_off] = t;
+    }
   }
 }
 
-inline hipError_t launch_siren_bf16_fused(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int grid, hipStream_t st) {
-  const size_t lds_bytes = (size_t)W2_SLOTS * W2_CHUNK_BYTES + ((size_t)nd.D * 256 + 3 * (size_t)nd.E + W2_WAVES) * sizeof(float);
-  if (lds_bytes > 160 * 1024 || a.save == nullptr || a.slabs == nullptr || a.save_by_block) return hipErrorInvalidValue;
-  hipError_t e = allow_full_lds<inr_siren_bf16_kernel>();
+template <int MODE>
+inline hipError_t launch_siren_bf16_mode(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int grid, hipStream_t st) {
+  const size_t lds_bytes = (size_t)PN_SLOTS * W2_PANEL_BYTES + PN_PHASE_BYTES +
+                           ((size_t)nd.D * 256 + 3 * (size_t)nd.E + PN_WAVES) * sizeof(float);
+  if (lds_bytes > 160 * 1024 || a.save_by_block) return hipErrorInvalidValue;
+  if (MODE != MODE_FWD && (a.save == nullptr || a.dz_state == nullptr)) return hipErrorInvalidValue;
+  if (MODE == MODE_FUSED && a.slabs == nullptr) return hipErrorInvalidValue;
+  hipError_t e = allow_full_lds<inr_siren_bf16_kernel<MODE>>();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(inr_siren_bf16_kernel, dim3(grid), dim3(64 * W2_WAVES), lds_bytes, st, nd, ld, a);
+  hipLaunchKernelGGL(inr_siren_bf16_kernel<MODE>, dim3(grid), dim3(64 * PN_WAVES), lds_bytes, st, nd, ld, a);
   return hipGetLastError();
 }
 

@@ -36,7 +36,7 @@ class LossDesc(C.Structure):
                 ("cons_inv", C.c_float * 4)]
 
 
-ABI_VERSION = 4  # INR_ABI_VERSION of include/inr_abi.h
+ABI_VERSION = 5  # INR_ABI_VERSION of include/inr_abi.h
 
 
 class Workspace(C.Structure):
@@ -60,6 +60,7 @@ SYMBOLS = {
     "inr_plan_sizes": (C.c_int, [_P, C.POINTER(Sizes)]),
     "inr_plan_launch_dims": (C.c_int, [_P, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "inr_plan_workspace": (C.c_int, [_P, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "inr_plan_grad_scale_state": (C.c_int, [_P, C.POINTER(C.c_float), _P]),
     "inr_pack_params": (C.c_int, [_P, _P, _P, _P]),
     "inr_encode_gauss": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P]),
     "inr_encode_logf": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P]),

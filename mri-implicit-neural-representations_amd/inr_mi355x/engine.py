@@ -83,7 +83,7 @@ class MLPEngine:
         self.step_save_by_tile = bool(sz.step_save_by_tile)
         self.in_features, self.out_features = in_features, out_features
         self.input_mode = input_mode
-        self.always_save = kind == L.KIND_WIRE2D or precision == L.PRECISION_BF16  # its orth terms travel through the save buffer even when not training
+        self.always_save = kind == L.KIND_WIRE2D  # its orth terms travel through the save buffer even when not training
         self.params: Optional[torch.Tensor] = None
         self.grads = self.exp_avg = self.exp_avg_sq = self.packed = None
         self._save = self._slabs = self._loss = None
@@ -129,6 +129,13 @@ class MLPEngine:
         ss, ns = C.c_int64(), C.c_int64()
         L.check(self.lib.inr_plan_workspace(self.plan, B, C.byref(ss), C.byref(ns)))
         return int(ss.value), int(ns.value)
+
+    def grad_scale_state(self):
+        """bf16 plans: the eight gradient-scale words (include/inr_abi.h: inr_plan_grad_scale_state) as a list of floats,
+        after the stream's queued work (synchronises).  Tests and diagnostics."""
+        buf = (C.c_float * 8)()
+        L.check(self.lib.inr_plan_grad_scale_state(self.plan, buf, self._stream()))
+        return [float(v) for v in buf]
 
     def _take_stash(self, B: int) -> None:
         if getattr(self, "_stash_rows", None) != B:

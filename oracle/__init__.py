@@ -20,3 +20,4 @@ the container: that stage follows the published formulas and is "parity
 unpinned" (SURVEY.md section 8c).
 """
 from .inr_oracle import *  # noqa: F401,F403
+from . import inr_oracle_bf16 as bf16  # noqa: F401  (the bf16 path's rounding model, checker of tests/test_gpu_bf16.py)
