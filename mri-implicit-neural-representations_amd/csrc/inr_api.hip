@@ -336,9 +336,9 @@ int inr_plan_create(const inr_net_desc* d, inr_plan** out) {
     return fail(INR_ERR_INVALID, "inr_plan_create: precision %d", d->precision);
   if (d->precision == INR_PRECISION_BF16 &&
       (d->kind != INR_KIND_SIREN || d->input != INR_INPUT_GAUSS || NB != 8 || (d->enc_size % 32) != 0 || D < 3 || D > 8 ||
-       d->enc_size > 512))
+       d->enc_size > 1024))
     return fail(INR_ERR_UNSUPPORTED, "inr_plan_create: the bf16 path is built for SIREN with the fused gauss encoder, "
-                "hidden width 129..256, 3 to 8 layers and an encoder size that is a multiple of 32 up to 512 (got kind %d, input "
+                "hidden width 129..256, 3 to 8 layers and an encoder size that is a multiple of 32 up to 1024 (got kind %d, input "
                 "%d, width %d, depth %d, enc_size %d)", d->kind, d->input, d->width, d->depth, d->enc_size);
 
   inr_plan* p = new (std::nothrow) inr_plan();

@@ -58,6 +58,9 @@ hipError_t launch_mlp_nb1(const NetDesc& nd, const LossDesc& ld, const MlpArgs& 
 hipError_t launch_mlp_nb2(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int mode, int grid, hipStream_t st);
 hipError_t launch_mlp_nb4(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int mode, int grid, hipStream_t st);
 hipError_t launch_siren_bf16(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int mode, int grid, hipStream_t st);
+hipError_t launch_siren_bf16_fwd(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int grid, hipStream_t st);
+hipError_t launch_siren_bf16_bwd(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int grid, hipStream_t st);
+hipError_t launch_siren_bf16_fused(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int grid, hipStream_t st);
 hipError_t launch_mlp_nb16(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int mode, int grid, hipStream_t st);
 hipError_t launch_mlp_nb8(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int mode, int grid, hipStream_t st);
 hipError_t launch_wire_nb2(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int mode, int grid, hipStream_t st);

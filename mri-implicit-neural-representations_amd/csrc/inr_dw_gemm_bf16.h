@@ -38,16 +38,18 @@ hipError_t launch_dz_roll(float* st, hipStream_t stream);
 #if defined(__HIPCC__)
 // Next step's gradient scale from what this step saw: st[1] = bits of max |dZ * mult|, st[3] = the power of two S inside
 // mult.  amax / S is the step's largest |dZ| in units of the loss gradient's own normalisation (fused steps: of
-// d(loss)/d(out) * count); the next S puts it into [2^7, 2^8): 2^7.8 of headroom below bf8's largest finite value
-// (57 344; an overflow would become an infinity in the GEMM), 2^23 above its smallest subnormal.  A step whose gradient
-// is exactly zero keeps the scale.
+// d(loss)/d(out) * count); the next S puts it into [2^4, 2^5): 2^10.8 of headroom below bf8's largest finite value 57 344
+// -- sequential batches of a k-space differ by two orders of magnitude in their largest gradient (the centre of a coil
+// against its periphery); beyond the headroom the conversion saturates (the kernel runs with MODE.FP16_OVFL set: a
+// clipped step, not an infinity) --, 2^18 above bf8's smallest normal value, 2^20 above its smallest subnormal.  A step
+// whose gradient is exactly zero keeps the scale.
 __device__ __forceinline__ void dz_state_roll(float* st) {
   const float amax = __builtin_bit_cast(float, reinterpret_cast<unsigned*>(st)[1]);
   if (amax > 0.f && amax < 3.0e38f) {
     int ex;
     (void)frexpf(amax / st[3], &ex);  // amax / S = f * 2^ex, f in [0.5, 1)
     ex = ex < -100 ? -100 : (ex > 100 ? 100 : ex);
-    st[0] = ldexpf(1.0f, 8 - ex);
+    st[0] = ldexpf(1.0f, 5 - ex);
   }
   reinterpret_cast<unsigned*>(st)[1] = 0u;
 }

@@ -44,10 +44,13 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-constexpr int PN_SLOTS = 7;   // ring slots of W2_PANEL_BYTES: six panels in flight ahead of the one being multiplied
+constexpr int PN_SLOTS = 8;   // ring slots of W2_PANEL_BYTES: seven panels in flight ahead of the one being multiplied
+constexpr int PN_LOOK = PN_SLOTS - 1;
 constexpr int PN_WAVES = 8;   // waves per workgroup; each issues 16 / 8 = 2 of a panel's 1 KB LDS-DMA pieces
-constexpr int PN_PD = 3;      // backward epilogues whose phase loads are in flight ahead of the one being computed
-constexpr int PN_PHASE_BYTES = PN_WAVES * 4 * 1024;  // their landing zone in LDS: per wave four sets of 4 dwords per lane
+#ifndef PN_PD_N
+#define PN_PD_N 2
+#endif
+constexpr int PN_PD = PN_PD_N;      // backward epilogues whose phase loads are in flight ahead of the one being computed
 
 __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
@@ -63,6 +66,16 @@ __device__ __forceinline__ unsigned pack_f16(float a, float b) {
 __device__ __forceinline__ bf16x8 pack8(const float* v) {
   u32x4 u = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
   return __builtin_bit_cast(bf16x8, u);
+}
+
+// "This value exists HERE": an empty volatile statement that takes the operand's four registers.  LLVM sinks arithmetic
+// whose result is only consumed much later (the sines of an epilogue feed the NEXT layer's GEMM) down to that consumer --
+// the first build of this kernel computed the sines of seven row blocks in one burst behind the layer's last panel, with
+// the pre-activations of all seven alive until then.  Volatile statements keep their order with the barriers.
+__device__ __forceinline__ void pin(bf16x8& v) {
+  u32x4 u = __builtin_bit_cast(u32x4, v);
+  asm volatile("" : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]));
+  v = __builtin_bit_cast(bf16x8, u);
 }
 
 // Phase byte of t revolutions into byte N of `word`: t + 1.5 * 2^15 has its unit in the last place at 2^-8, so the low
@@ -82,26 +95,28 @@ __device__ __forceinline__ void phase_byte(unsigned& word, float t, float magic)
 }
 
 // ---- the panel ring ---------------------------------------------------------------------------------------------
-// Stream position p lives in slot p mod 7.  An INTERVAL consumes c panels (two per layer-0 chunk, one everywhere else):
+// Stream position p lives in slot p & 7.  An INTERVAL consumes c panels (two per layer-0 chunk, one everywhere else):
 //   pn_begin<N>():  s_waitcnt vmcnt(N) -- this wave's pieces of the interval's panels have landed --, s_barrier --
 //   everybody's have, and everybody is done with the panels of the previous interval --, then requests up to position
-//   p + 6 into the slots just freed.
+//   p + 7 into the slots just freed.
 // N: the vector-memory counter retires IN ORDER, so "at most N operations outstanding" covers a panel when at least N
 // operations were issued after its pieces.  Behind the pieces of the interval's last panel lie the requests of the
-// panels after it: two pieces each, 7 - c_prev - c panels (c_prev: what the previous interval consumed) -- N0 =
-// 2 (7 - c_prev - c).  On top, where the preceding intervals are known to have issued S stash operations each (the
-// steady state of the hidden layers: 4 stores forward, 4 phase fetches + 4 stores backward, instructions that are
-// issued unconditionally), N = N0 + S h for the h <= 6 such intervals directly in front.  A smaller N only waits longer.
+// panels after it: two pieces each, 8 - c_prev - c panels (c_prev: what the previous interval consumed) -- pn_n0().  On
+// top, where the intervals in front are known to have issued S stash operations each (the hidden layers: 4 stores
+// forward, 4 loads + 4 stores backward, instructions that are issued unconditionally), S for each of the h <= 7 such
+// intervals directly in front.  A smaller N only waits longer.
 struct PnRing {
   const char* gbase;  // panel 0 of the image
   char* ring;
   int first, len;     // the stream cycles through images [first, first + len)
-  int p, slot;        // next position to consume, its slot
-  int req, req_img, req_slot;  // next position to request, its image (relative to first), its slot
+  int p;              // next position to consume
+  int req, req_img;   // next position to request, its image (relative to first)
   int w, lane;
 };
+constexpr int pn_n0(int c_prev, int c) { return 2 * (PN_SLOTS - c_prev - c); }
+constexpr int pn_min(int a, int b) { return a < b ? a : b; }
+constexpr int pn_max(int a, int b) { return a > b ? a : b; }
 
-__device__ __forceinline__ int pn_next(int slot) { return slot + 1 == PN_SLOTS ? 0 : slot + 1; }
 __device__ __forceinline__ void pn_issue(const PnRing& r, int img, int slot) {
   const char* src = r.gbase + (size_t)img * W2_PANEL_BYTES + (size_t)(2 * r.w) * 1024 + r.lane * 16;
   char* dst = r.ring + slot * W2_PANEL_BYTES + (2 * r.w) * 1024;
@@ -112,9 +127,8 @@ __device__ __forceinline__ void pn_issue(const PnRing& r, int img, int slot) {
 }
 __device__ __forceinline__ void pn_request(PnRing& r) {
   while (r.req < r.p + PN_SLOTS) {
-    pn_issue(r, r.first + r.req_img, r.req_slot);
+    pn_issue(r, r.first + r.req_img, r.req & (PN_SLOTS - 1));
     ++r.req;
-    r.req_slot = pn_next(r.req_slot);
     if (++r.req_img == r.len) r.req_img = 0;
   }
 }
@@ -125,46 +139,87 @@ __device__ __forceinline__ void pn_begin(PnRing& r) {
   __builtin_amdgcn_s_barrier();
   pn_request(r);
 }
-// the interval is over: its c panels are consumed
-__device__ __forceinline__ void pn_advance(PnRing& r, int c) {
-  r.p += c;
-  for (int i = 0; i < c; ++i) r.slot = pn_next(r.slot);
+__device__ __forceinline__ bf16x8 pn_frag(const PnRing& r, int p, int f) {
+  return *reinterpret_cast<const bf16x8*>(r.ring + (p & (PN_SLOTS - 1)) * W2_PANEL_BYTES + (f * 64 + r.lane) * 16);
 }
-__device__ __forceinline__ bf16x8 pn_frag(const PnRing& r, int slot, int f) {
-  return *reinterpret_cast<const bf16x8*>(r.ring + slot * W2_PANEL_BYTES + (f * 64 + r.lane) * 16);
-}
-// one row block: 16 K-steps of the panel in `slot` against the 16 B operands
-__device__ __forceinline__ f32x16 pn_mma_block(const PnRing& r, int slot, const bf16x8 (&b)[16]) {
+// one row block: 16 K-steps of panel p against the 16 B operands
+__device__ __forceinline__ f32x16 pn_mma_block(const PnRing& r, int p, const bf16x8 (&b)[16]) {
+  // fragments eight at a time (32 registers): left alone the compiler fetches all sixteen up front, 64 registers on top
+  // of two sets of B operands
+#ifndef PN_FRAGS
+#define PN_FRAGS 8
+#endif
   f32x16 acc = zero16();
 #pragma unroll
-  for (int t = 0; t < 16; ++t) acc = mfma_bf16(pn_frag(r, slot, t), b[t], acc);
+  for (int h = 0; h < 16 / PN_FRAGS; ++h) {
+    bf16x8 A[PN_FRAGS];
+#pragma unroll
+    for (int t = 0; t < PN_FRAGS; ++t) A[t] = pn_frag(r, p, PN_FRAGS * h + t);
+#pragma unroll
+    for (int t = 0; t < PN_FRAGS; ++t) acc = mfma_bf16(A[t], b[PN_FRAGS * h + t], acc);
+    __builtin_amdgcn_sched_barrier(0);
+  }
   return acc;
 }
 
-// ---- phase fetches ------------------------------------------------------------------------------------------------
-// The phase bytes of a backward epilogue are fetched PN_PD epilogues ahead and waited for with a counted vmcnt: hipcc's own
-// wait insertion answers a load that is pending together with stores (and LDS-DMA) with vmcnt(0), which would drain the
-// six weight panels in flight at every row block.  They travel by LDS-DMA into a landing zone of the wave (four sets of
-// 4 x 64 dwords) and are read back with plain LDS loads behind the wait.  Not into registers: a load whose wait the
-// compiler does not know about stays in flight across whatever the register allocator puts in between -- round 2 found a
-// spill there, this round's first build a loop-carried copy (at the back edge of the layer loop the loads of the next
-// layer's first row blocks were "moved" to where the next iteration expected them before they had landed), and
-// amdgpu_num_vgpr does not keep the allocator out of a register range on this compiler.  An LDS destination has no
-// allocator.
+// ---- vector loads the compiler does not see ------------------------------------------------------------------------
+// The phase bytes of a backward epilogue are fetched PN_PD epilogues ahead by inline assembly and waited for with a
+// counted vmcnt: hipcc's own wait insertion answers a load that is pending together with stores (and LDS-DMA) with
+// vmcnt(0), which would drain the seven weight panels in flight at every row block (and an LDS-DMA landing zone instead
+// of registers costs an LDS-DMA issue, 100-185 cycles, per dword fetched: measured, +11 k cycles per layer).  The price:
+// between such a load and its wait the destination registers belong to the memory system, and the register allocator
+// does not know.  Three ways it has gone wrong, each closed structurally and checked on every build by
+// tools/check_inflight_regs.py (tests/test_host.py):
+//   * a load whose result nobody uses (the uniform tail of the sequence) gets a destination the allocator hands to the
+//     next instruction -- the tail issues stores that a zero-sized descriptor drops instead;
+//   * a load in flight across a loop's back edge is "moved" to where the next iteration expects it before it has landed
+//     -- the layer loops are unrolled at compile time (the kernel is instantiated per depth): the only back edge left is
+//     the tile loop's, and no load is in flight there;
+//   * an SGPR operand reloaded from a spill (v_readlane) right in front of the load, which gfx9 only tolerates five wait
+//     states later and the compiler only pads for its own memory instructions -- the four loads of a row block are ONE
+//     statement with the pad in front and immediates for the later offsets.
+__device__ __forceinline__ u32x4 w2_rsrc_words(const void* p, int bytes) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+  u32x4 r;
+  r[0] = __builtin_amdgcn_readfirstlane((unsigned)a);
+  r[1] = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  r[2] = (unsigned)bytes;
+  r[3] = 0x00020000u;
+  return r;
+}
+// the four phase dwords of a row block (quads 8 mm + 2 g + half, g = 0..3: 1 KB apart)
+__device__ __forceinline__ void w2_load4_asm(unsigned (&z)[4], const u32x4& rsrc, int voff, int soff) {
+  asm volatile(
+      "s_nop 4\n\t"
+      "buffer_load_dword %0, %4, %5, %6 offen\n\t"
+      "buffer_load_dword %1, %4, %5, %6 offen offset:1024\n\t"
+      "buffer_load_dword %2, %4, %5, %6 offen offset:2048\n\t"
+      "buffer_load_dword %3, %4, %5, %6 offen offset:3072"
+      : "=&v"(z[0]), "=&v"(z[1]), "=&v"(z[2]), "=&v"(z[3])
+      : "v"(voff), "s"(rsrc), "s"(soff)
+      : "memory");
+}
+// at most N vector-memory operations outstanding; the four registers are operands so that no use moves above the wait
+template <int N>
+__device__ __forceinline__ void w2_wait4(unsigned (&z)[4]) {
+  static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit field");
+  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(z[0]), "+v"(z[1]), "+v"(z[2]), "+v"(z[3]) : "n"(N) : "memory");
+}
 
 // ---- one tile group (four waves, 128 coordinates = one stash tile) ----------------------------------------------
-// RB: role B (waves 4-7).  ACTIVE = false: the group has no tile in this launch shape (small batches run one stash
-// tile per workgroup): it takes part in every barrier and issues its share of the DMA pieces, nothing else.
-template <int MODE, bool RB, bool ACTIVE>
+// NH: hidden layers behind the first (D = NH + 2 Linear layers).  RB: role B (waves 4-7).  ACTIVE = false: the group has
+// no tile in this launch shape (small batches run one stash tile per workgroup): it takes part in every barrier and
+// issues its share of the DMA pieces, nothing else.
+template <int MODE, int NH, bool RB, bool ACTIVE>
 struct SirenTile {
-  static constexpr int TL = W2_TL;
+  static constexpr int TL = W2_TL, D = NH + 2;
+  static constexpr int NE = 8 * (NH + 1);  // backward epilogues per tile: row block e & 7 of dZ_lz, lz = D-2 - (e >> 3)
   const NetDesc& nd;
   const LossDesc& ld;
   const MlpArgs& a;
   PnRing& r;
   const float* bias_lds;
   const float* encB_lds;
-  unsigned* phz;  // this wave's landing zone for phase fetches: [4 sets][4][64 lanes] dwords
   int lane, half, col, wcol, w;
   float mult;        // what the loss gradient is multiplied by (inr_w2.h: gradient-scale state)
   float amax = 0.f;  // max |dZ * mult| this wave has stashed
@@ -176,19 +231,22 @@ struct SirenTile {
   long long crow;
   bool valid, tile_ok;
   __amdgpu_buffer_rsrc_t rs_tile;
-  bf16x8 hIn[16], hOut[16];
+  u32x4 rz_tile;
+  bf16x8 hbuf[2][16];  // B operands: layer l reads hbuf[(l - 1) & 1] and writes hbuf[l & 1]; backward likewise per epilogue
+  unsigned pz[PN_PD + 1][4];  // phase dwords of backward epilogues e, e+1, .. (set e % (PD + 1))
 
   __device__ __forceinline__ SirenTile(const NetDesc& nd_, const LossDesc& ld_, const MlpArgs& a_, PnRing& r_,
-                                       const float* bias, const float* encB, unsigned* phz_, int lane_, int w_, float mult_)
-      : nd(nd_), ld(ld_), a(a_), r(r_), bias_lds(bias), encB_lds(encB), phz(phz_), lane(lane_), half(lane_ >> 5), col(lane_ & 31),
+                                       const float* bias, const float* encB, int lane_, int w_, float mult_)
+      : nd(nd_), ld(ld_), a(a_), r(r_), bias_lds(bias), encB_lds(encB), lane(lane_), half(lane_ >> 5), col(lane_ & 31),
         wcol((w_ & 3) * 32 + (lane_ & 31)), w(w_), mult(mult_) {}
 
   // -------- forward epilogue of row block mm of hidden layer l: t = acc + bias (revolutions) -> phase bytes to the
   // stash, h = sin(2 pi t) -> B operands 2 mm, 2 mm + 1 of the next layer
-  __device__ __forceinline__ void epi_fwd(int l, int mm, const f32x16& acc, bf16x8 (&out)[16], int slot) {
-    const float* bl = bias_lds + l * 256 + 32 * mm + 4 * half;
+  template <int L, int MM>
+  __device__ __forceinline__ void epi_fwd(const f32x16& acc) {
+    const float* bl = bias_lds + L * 256 + 32 * MM + 4 * half;
     const float magic = 49152.0f;
-    const int so0 = (w2_stash_P(l) + 8 * mm * TL) * 4;
+    constexpr int so0 = (L * W2_TENSOR_DWORDS + 8 * MM * TL) * 4;  // w2_stash_P(L)
     float hv[16];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -206,32 +264,45 @@ struct SirenTile {
       phase_byte<3>(pk, t3, magic);
       __builtin_amdgcn_raw_buffer_store_b32(pk, rs_tile, voff, so0 + 2 * g * TL * 4, 0);  // quad 8 mm + 2 g (+ half in voff)
     }
-    out[slot] = pack8(hv);
-    out[slot + 1] = pack8(hv + 8);
+    hbuf[L & 1][2 * MM] = pack8(hv);
+    hbuf[L & 1][2 * MM + 1] = pack8(hv + 8);
+    pin(hbuf[L & 1][2 * MM]);
+    pin(hbuf[L & 1][2 * MM + 1]);
   }
 
-  // -------- backward epilogues: sequence e = 0, 1, ...: row block e & 7 of dZ_lz, lz = D-2 - (e >> 3)
-  // fetch the four phase dwords of row block mm of layer lz (quads 8 mm + 2 g + half, g = 0..3) into set SET (= row block
-  // & 3) of the landing zone.  lz < 0: past the tile's last epilogue -- the fetches are issued all the same, from layer 0,
-  // so that the counted waits see a uniform sequence (tiles past the batch point at tile 0: the reads are always valid)
-  template <int SET>
-  __device__ __forceinline__ void bwd_loads(int lz, int mm) {
-    const unsigned* src = sv + w2_stash_P(lz < 0 ? 0 : lz) + (8 * mm + half) * TL + wcol;
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 2 * g * TL),
-                                       (__attribute__((address_space(3))) void*)(phz + (SET * 4 + g) * 64), 4, 0, 0);
+  // -------- backward epilogues, sequence e = 0 .. NE-1.  Each wave runs  [loads of e + PD][epilogue e]  in this order.
+  // the four phase loads of epilogue E; E >= NE: four stores that a zero-sized descriptor drops (the counted waits see a
+  // uniform sequence; a load nobody reads would have a destination the allocator reuses while it is in flight)
+  template <int E>
+  __device__ __forceinline__ void bwd_loads() {
+    static_assert(2 * TL * 4 == 1024, "w2_load4_asm's immediates");
+    if constexpr (E >= NE) {
+      // (assembly: four identical stores through the builtin are one store after dead-store elimination -- and three
+      // operations fewer than the waits count)
+      const u32x4 none = w2_rsrc_words(sv, 0);
+      asm volatile(
+          "s_nop 4\n\t"
+          "buffer_store_dword %0, %0, %1, 0 offen\n\tbuffer_store_dword %0, %0, %1, 0 offen\n\t"
+          "buffer_store_dword %0, %0, %1, 0 offen\n\tbuffer_store_dword %0, %0, %1, 0 offen"
+          :
+          : "v"(voff), "s"(none)
+          : "memory");
+    } else {
+      constexpr int lz = D - 2 - (E >> 3), mm = E & 7;
+      w2_load4_asm(pz[E % (PN_PD + 1)], rz_tile, voff, (lz * W2_TENSOR_DWORDS + 8 * mm * TL) * 4);
+    }
   }
   // dZ = acc * cos(2 pi phase) (the transposed image carries w0): bf8 to the stash, bf16 into the next B operands.
-  // WAIT: vector-memory operations issued since the set's fetches
-  template <int SET, int WAIT>
-  __device__ __forceinline__ void epi_bwd(int lz, int mm, const f32x16& acc, bf16x8 (&out)[16], int slot) {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT) : "memory");
-    const int so0 = (w2_stash_G(lz, nd.D) + 8 * mm * TL) * 4;
+  // Behind the epilogue's loads lie 4 (PD + e) operations for the first PD epilogues of a tile, 8 PD from then on.
+  template <int E>
+  __device__ __forceinline__ void epi_bwd(const f32x16& acc) {
+    constexpr int lz = D - 2 - (E >> 3), mm = E & 7, set = E % (PN_PD + 1);
+    w2_wait4<(E < PN_PD ? 4 * (PN_PD + E) : 8 * PN_PD)>(pz[set]);
+    constexpr int so0 = ((D - 1 + lz) * W2_TENSOR_DWORDS + 8 * mm * TL) * 4;  // w2_stash_G(lz, D)
     float dz[16];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const unsigned pw = phz[(SET * 4 + g) * 64 + lane];
+      const unsigned pw = pz[set][g];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float c = __builtin_amdgcn_cosf((float)((pw >> (8 * j)) & 255u) * 0.00390625f);
@@ -243,20 +314,23 @@ struct SirenTile {
       pk = __builtin_amdgcn_cvt_pk_bf8_f32(dz[4 * g + 2], dz[4 * g + 3], pk, true);
       __builtin_amdgcn_raw_buffer_store_b32((unsigned)pk, rs_tile, voff, so0 + 2 * g * TL * 4, 0);
     }
-    out[slot] = pack8(dz);
-    out[slot + 1] = pack8(dz + 8);
+    hbuf[(E >> 3) & 1][2 * mm] = pack8(dz);
+    hbuf[(E >> 3) & 1][2 * mm + 1] = pack8(dz + 8);
+    pin(hbuf[(E >> 3) & 1][2 * mm]);
+    pin(hbuf[(E >> 3) & 1][2 * mm + 1]);
+    asm volatile("" : "+v"(amax));  // (the running maximum too: sunk to the kernel's end it kept every dZ alive -- in scratch)
   }
-
-  __device__ __forceinline__ void copy_out_to_in() {
-#pragma unroll
-    for (int t = 0; t < 16; ++t) hIn[t] = hOut[t];
+  template <int E>
+  __device__ __forceinline__ void bwd_step(const f32x16& acc) {
+    bwd_loads<E + PN_PD>();
+    epi_bwd<E>(acc);
   }
 
   // -------- the tile ------------------------------------------------------------------------------------------------
   // stile: this group's stash tile (may be past the batch: then every stash access is a no-op and the lanes compute on
   // zeros).  Returns with every epilogue of the tile done.
   __device__ __forceinline__ void run(int stile) {
-    const int D = nd.D, E = nd.E;
+    const int E = nd.E;
     const int nq0 = E / 32;  // layer-0 chunks of 64 encoder features (two panels each)
     constexpr bool FWD = MODE != MODE_BWD, BWD = MODE != MODE_FWD;
     float x0 = 0.f, x1 = 0.f, x2 = 0.f, gtv[4] = {0.f, 0.f, 0.f, 0.f};
@@ -269,6 +343,7 @@ struct SirenTile {
       ts_bytes = (tile_ok && a.save != nullptr) ? w2_stash_dwords(D) * 4 : 0;  // 0: every stash access is a no-op
       voff = (half * TL + wcol) * 4;  // the lane's byte offset inside a quad pair: quad parity = lane half, own coordinate
       rs_tile = uniform_rsrc(sv, ts_bytes);
+      if (BWD) rz_tile = w2_rsrc_words(sv, ts_bytes);
       if (FWD) {  // coordinates, sampling mask and target row in one batch of loads (row 0 where the lane has none)
         const long long cr = valid ? crow : 0;
         x0 = a.x[3 * cr + 0];
@@ -293,108 +368,89 @@ struct SirenTile {
     INR_STAMP(si); ++si;
 
     float dzl[4] = {0.f, 0.f, 0.f, 0.f};
-    if (FWD) {
+    if constexpr (FWD) {
       // ================================ layer 0 ================================
       // 2E encoder features per coordinate, generated per K-step on the vector ALUs (half 0: sines, half 1: cosines of
       // features 8t .. 8t+7), contraction outermost: eight accumulator blocks.  Role A forms the features of chunk
       // ch + 1 behind the MFMAs of chunk ch, role B those of chunk ch in front of them.
-      f32x16 acc8[8];
-      bf16x8 bq[4];
-      auto gen = [&](int ch) {
+      {
+        f32x16 acc8[8];
+        bf16x8 bq[4];
+        auto gen = [&](int ch) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const int t = 4 * ch + s;
-          float f[8];
+          for (int s = 0; s < 4; ++s) {
+            const int t = 4 * ch + s;
+            float f[8];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float* bj = encB_lds + 3 * (8 * t + j);
-            f[j] = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(fmaf(x2, bj[2], fmaf(x1, bj[1], fmaf(x0, bj[0], quarter)))));
-          }
-          bq[s] = pack8(f);
-        }
-      };
-      auto mma_chunk = [&]() {  // panels r.p (K-steps 0, 1 of the chunk) and r.p + 1 (K-steps 2, 3)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          bf16x8 A[8];
-#pragma unroll
-          for (int m = 0; m < 8; ++m) A[m] = pn_frag(r, (s >> 1) ? pn_next(r.slot) : r.slot, (s & 1) * 8 + m);
-#pragma unroll
-          for (int m = 0; m < 8; ++m) acc8[m] = mfma_bf16(A[m], bq[s], acc8[m]);
-        }
-      };
-      if (ACTIVE) {
-#pragma unroll
-        for (int m = 0; m < 8; ++m) acc8[m] = zero16();
-        if (!RB) gen(0);
-      }
-      for (int ch = 0; ch < nq0; ++ch) {
-        if (ch == 0)
-          pn_begin<8>(r);  // c = 2 behind c_prev <= 1
-        else
-          pn_begin<6>(r);  // c = 2 behind c_prev = 2
-        if (ACTIVE) {
-          if (RB) gen(ch);
-          mma_chunk();
-          if (!RB && ch + 1 < nq0) gen(ch + 1);
-        }
-        pn_advance(r, 2);
-      }
-      INR_STAMP(si); ++si;
-      // epilogue of layer 0, all eight row blocks (both roles: the 128 accumulator registers are free before the hidden
-      // layers, whose loop keeps two sets of B operands)
-      if (ACTIVE) {
-#pragma unroll
-        for (int m = 0; m < 8; ++m) epi_fwd(0, m, acc8[m], hIn, 2 * m);
-      }
-      INR_STAMP(si); ++si;
-
-      // ================================ hidden layers 1 .. D-2 ================================
-      f32x16 acc = zero16();
-      for (int l = 1; l < D - 1; ++l) {
-        const bool first = l == 1;
-        static_for<0, 8>([&](auto mc) {
-          constexpr int m = decltype(mc)::value;
-          // requests: 10 operations behind the panel's pieces (8 behind a layer-0 chunk); + 4 stores per hidden interval (at
-          // most the six in front), counted from the layer's second interval in the first layer (role B's first has no epilogue)
-          constexpr int N0 = m == 0 ? 8 : 10, NF = N0 + 4 * (m > 0 ? (m - 1 > 6 ? 6 : m - 1) : 0), NS = 34;
-          if (!ACTIVE) {
-            if (first) pn_begin<N0>(r); else pn_begin<10>(r);
-          } else if (first) {
-            pn_begin<NF>(r);
-          } else {
-            pn_begin<NS>(r);
-          }
-          if (ACTIVE) {
-            if (RB) {
-              if (m == 0) {
-                if (!first) {
-                  epi_fwd(l - 1, 7, acc, hOut, 14);
-                  copy_out_to_in();
-                }
-              } else {
-                epi_fwd(l, m - 1, acc, hOut, 2 * (m > 0 ? m - 1 : 0));
-              }
-              acc = pn_mma_block(r, r.slot, hIn);
-            } else {
-              acc = pn_mma_block(r, r.slot, hIn);
-              epi_fwd(l, m, acc, hOut, 2 * m);
-              if (m == 7) copy_out_to_in();
+            for (int j = 0; j < 8; ++j) {
+              const float* bj = encB_lds + 3 * (8 * t + j);
+              f[j] = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(fmaf(x2, bj[2], fmaf(x1, bj[1], fmaf(x0, bj[0], quarter)))));
             }
+            bq[s] = pack8(f);
           }
-          pn_advance(r, 1);
-        });
+        };
+        auto mma_chunk = [&]() {  // panels r.p (K-steps 0, 1 of the chunk) and r.p + 1 (K-steps 2, 3)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            bf16x8 A[8];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) A[m] = pn_frag(r, r.p + (s >> 1), (s & 1) * 8 + m);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) acc8[m] = mfma_bf16(A[m], bq[s], acc8[m]);
+          }
+        };
+        if (ACTIVE) {
+#pragma unroll
+          for (int m = 0; m < 8; ++m) acc8[m] = zero16();
+          if (!RB) gen(0);
+        }
+        for (int ch = 0; ch < nq0; ++ch) {
+          if (ch == 0)
+            pn_begin<pn_n0(1, 2)>(r);
+          else
+            pn_begin<pn_n0(2, 2)>(r);
+          if (ACTIVE) {
+            if (RB) gen(ch);
+            mma_chunk();
+            if (!RB && ch + 1 < nq0) gen(ch + 1);
+          }
+          r.p += 2;
+        }
+        INR_STAMP(si); ++si;
+        // epilogue of layer 0, all eight row blocks (both roles: the 128 accumulator registers are free before the
+        // hidden layers, which keep two sets of B operands)
+        if (ACTIVE) static_for<0, 8>([&](auto mc) { epi_fwd<0, decltype(mc)::value>(acc8[decltype(mc)::value]); });
         INR_STAMP(si); ++si;
       }
 
-      // ================================ last layer: one row block (rows 0 .. out_f-1 live) ================================
-      if (ACTIVE) pn_begin<34>(r); else pn_begin<10>(r);
-      if (ACTIVE) {
-        if (RB) {
-          epi_fwd(D - 2, 7, acc, hOut, 14);
-          copy_out_to_in();
+      // ================================ hidden layers 1 .. D-2, row block by row block ================================
+      f32x16 acc = zero16();
+      static_for<0, 8 * NH>([&](auto ic) {
+        constexpr int i = decltype(ic)::value, l = 1 + (i >> 3), m = i & 7;
+        // the requests behind the panel's pieces; + 4 stores for each of the (up to seven) intervals in front, counted
+        // from the second one (role B's first has no epilogue)
+        constexpr int N0 = i == 0 ? pn_n0(2, 1) : pn_n0(1, 1);
+        pn_begin<(ACTIVE ? N0 + 4 * pn_min(PN_LOOK, pn_max(0, i - 1)) : N0)>(r);
+        if (ACTIVE) {
+          if (RB) {
+            if constexpr (i > 0) epi_fwd<1 + ((i - 1) >> 3), (i - 1) & 7>(acc);
+            acc = pn_mma_block(r, r.p, hbuf[(l - 1) & 1]);
+          } else {
+            acc = pn_mma_block(r, r.p, hbuf[(l - 1) & 1]);
+            epi_fwd<l, m>(acc);
+          }
         }
-        const f32x16 accL = pn_mma_block(r, r.slot, hIn);
+        r.p += 1;
+        if constexpr (m == 7) {
+          INR_STAMP(si); ++si;
+        }
+      });
+
+      // ================================ last layer: one row block (rows 0 .. out_f-1 live) ================================
+      pn_begin<(ACTIVE ? pn_n0(1, 1) + 4 * pn_min(PN_LOOK, 8 * NH - 1) : pn_n0(1, 1))>(r);
+      if (ACTIVE) {
+        if (RB) epi_fwd<NH, 7>(acc);
+        const f32x16 accL = pn_mma_block(r, r.p, hbuf[NH & 1]);
         float y[4], dy[4], g[4];
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
@@ -413,11 +469,11 @@ struct SirenTile {
           *reinterpret_cast<f32x4*>(sv + w2_stash_dy(D) + 4 * wcol) = d4;
         }
       }
-      pn_advance(r, 1);
+      r.p += 1;
       INR_STAMP(si); ++si;
     }
 
-    if (BWD) {
+    if constexpr (BWD) {
       if (MODE == MODE_BWD && ACTIVE) {  // d(loss)/d(out) from the caller, act'(z_last) from the forward half
         if (valid && half == 0) {
           const f32x4 d4 = *reinterpret_cast<const f32x4*>(sv + w2_stash_dy(D) + 4 * wcol);
@@ -427,7 +483,7 @@ struct SirenTile {
         }
       }
       // ================================ dH_{D-2} = W_last^T dZ_last: one K-step, eight row blocks ================================
-      pn_begin<10>(r);
+      pn_begin<pn_n0(1, 1)>(r);
       f32x16 acc = zero16();
       if (ACTIVE) {
         // dZ_last rows (0,1), (2,3) of this coordinate as fp16 pairs: two dwords behind the 8-bit tensors
@@ -438,64 +494,38 @@ struct SirenTile {
         }
         float v[8] = {dzl[0], dzl[1], dzl[2], dzl[3], 0.f, 0.f, 0.f, 0.f};
         const bf16x8 b0 = pack8(v);  // k = output row: element j of half 0 is row j for j < 4
-        static_for<0, PN_PD>([&](auto ec) { bwd_loads<decltype(ec)::value & 3>(D - 2, decltype(ec)::value); });
+        static_for<0, PN_PD>([&](auto ec) { bwd_loads<decltype(ec)::value>(); });
         static_for<0, 8>([&](auto mc) {
           constexpr int m = decltype(mc)::value;
-          bwd_loads<(m + PN_PD) & 3>(D - 2 - ((m + PN_PD) >> 3), (m + PN_PD) & 7);
-          const f32x16 a1 = mfma_bf16(pn_frag(r, r.slot, m), b0, zero16());
-          // behind these loads: 4 (PD + e) operations for the first PD epilogues, then 8 PD
-          epi_bwd<m & 3, (m < PN_PD ? 4 * (PN_PD + m) : 8 * PN_PD)>(D - 2, m, a1, hOut, 2 * m);
+          bwd_step<m>(mfma_bf16(pn_frag(r, r.p, m), b0, zero16()));
         });
-        copy_out_to_in();
       }
-      pn_advance(r, 1);
+      r.p += 1;
       INR_STAMP(si); ++si;
 
-      // ================================ dH_{l-1} = W_l^T dZ_l, l = D-2 .. 1 ================================
-      for (int l = D - 2; l >= 1; --l) {
-        const bool first = l == D - 2;
-        static_for<0, 8>([&](auto mc) {
-          constexpr int m = decltype(mc)::value;
-          // + 8 stash operations per interval (at most the six in front), counted from the second interval of the first layer
-          // (role B's first has none)
-          constexpr int NF = 10 + 8 * (m > 0 ? (m - 1 > 6 ? 6 : m - 1) : 0), NS = 58;
-          if (!ACTIVE) {
-            pn_begin<10>(r);
-          } else if (first) {
-            pn_begin<NF>(r);
+      // ================================ dH_{l-1} = W_l^T dZ_l, l = D-2 .. 1, row block by row block ================================
+      static_for<0, 8 * NH>([&](auto jc) {
+        constexpr int j = decltype(jc)::value, li = j >> 3, m = j & 7;
+        // + 8 stash operations for each of the (up to seven) intervals in front, counted from the second (role B's first has
+        // no epilogue)
+        constexpr int NA = pn_n0(1, 1) + 8 * pn_min(PN_LOOK, pn_max(0, j - 1));
+        pn_begin<(ACTIVE ? pn_min(63, NA) : pn_n0(1, 1))>(r);
+        if (ACTIVE) {
+          // epilogue 8 (li + 1) + m: row block m of dZ_{l-1}, l = D-2-li
+          if (RB) {
+            if constexpr (j > 0) bwd_step<8 + j - 1>(acc);
+            acc = pn_mma_block(r, r.p, hbuf[li & 1]);
           } else {
-            pn_begin<NS>(r);
+            acc = pn_mma_block(r, r.p, hbuf[li & 1]);
+            bwd_step<8 + j>(acc);
           }
-          if (ACTIVE) {
-            // epilogue e = 8 (D-1-l) + m produces row block m of dZ_{l-1}; its loads were issued PD epilogues ago
-            if (RB) {
-              if (m == 0) {
-                if (!first) {  // row block 7 of dZ_l, then the layer's B operands are complete
-                  bwd_loads<(7 + PN_PD) & 3>(l - ((7 + PN_PD) >> 3), (7 + PN_PD) & 7);
-                  epi_bwd<3, 8 * PN_PD>(l, 7, acc, hOut, 14);
-                  copy_out_to_in();
-                }
-              } else {
-                constexpr int mp = m > 0 ? m - 1 : 0;
-                bwd_loads<(mp + PN_PD) & 3>(l - 1 - ((mp + PN_PD) >> 3), (mp + PN_PD) & 7);
-                epi_bwd<mp & 3, 8 * PN_PD>(l - 1, mp, acc, hOut, 2 * mp);
-              }
-              acc = pn_mma_block(r, r.slot, hIn);
-            } else {
-              acc = pn_mma_block(r, r.slot, hIn);
-              bwd_loads<(m + PN_PD) & 3>(l - 1 - ((m + PN_PD) >> 3), (m + PN_PD) & 7);
-              epi_bwd<m & 3, 8 * PN_PD>(l - 1, m, acc, hOut, 2 * m);
-              if (m == 7 && l > 1) copy_out_to_in();
-            }
-          }
-          pn_advance(r, 1);
-        });
-        INR_STAMP(si); ++si;
-      }
-      if (ACTIVE && RB) {  // role B's last epilogue: row block 7 of dZ_0
-        bwd_loads<(7 + PN_PD) & 3>(-1, (7 + PN_PD) & 7);
-        epi_bwd<3, 8 * PN_PD>(0, 7, acc, hOut, 14);
-      }
+        }
+        r.p += 1;
+        if constexpr (m == 7) {
+          INR_STAMP(si); ++si;
+        }
+      });
+      if (ACTIVE && RB) bwd_step<NE - 1>(acc);  // role B's last epilogue: row block 7 of dZ_0
       INR_STAMP(si); ++si;
     }
   }
@@ -504,17 +534,19 @@ struct SirenTile {
 // ---- the kernel ---------------------------------------------------------------------------------------------------
 // Workgroup = eight waves = two tile groups; group g = waves 4g .. 4g+3 works on stash tile tpw * (workgroup tile) + g;
 // wave w owns coordinates [32 (w & 3), + 32) of it: lane (col, half).
-template <int MODE>
+template <int MODE, int NH>
 __global__ __launch_bounds__(512, 2) void inr_siren_bf16_kernel(const NetDesc nd, const LossDesc ld, const MlpArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
-  constexpr int NW = PN_WAVES;
+  constexpr int NW = PN_WAVES, D = NH + 2;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: LDS-DMA destinations go through M0
-  unsigned* phz = reinterpret_cast<unsigned*>(lds_raw + PN_SLOTS * W2_PANEL_BYTES) + w * 1024;  // [8 waves][4 sets][4][64]
-  float* bias_lds = reinterpret_cast<float*>(lds_raw + PN_SLOTS * W2_PANEL_BYTES + PN_PHASE_BYTES);  // [D][256]
-  float* encB_lds = bias_lds + nd.D * 256;                                          // [E][3]
+  // MODE.FP16_OVFL: conversions to fp16 and bf8 saturate at the largest finite value instead of overflowing to infinity
+  // (tools/probes/bf8_clamp_probe.hip) -- a dZ beyond the gradient scale's headroom is clipped, not turned into NaNs
+  if (MODE != MODE_FWD) asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1");
+  float* bias_lds = reinterpret_cast<float*>(lds_raw + PN_SLOTS * W2_PANEL_BYTES);  // [D][256]
+  float* encB_lds = bias_lds + D * 256;                                             // [E][3]
   float* red_lds = encB_lds + 3 * nd.E;                                             // [8]
-  const int D = nd.D, E = nd.E;
+  const int E = nd.E;
   for (int i = tid; i < D * 256; i += 64 * NW) bias_lds[i] = a.packed[nd.w2_bias_off + i];
   for (int i = tid; i < 3 * E; i += 64 * NW) encB_lds[i] = a.encB != nullptr ? a.encB[i] : 0.f;
   PnRing r;
@@ -522,9 +554,9 @@ __global__ __launch_bounds__(512, 2) void inr_siren_bf16_kernel(const NetDesc nd
   r.ring = lds_raw;
   r.first = MODE == MODE_BWD ? w2_n_fwd(D, E) : 0;
   r.len = MODE == MODE_FUSED ? w2_np(D, E) : (MODE == MODE_FWD ? w2_n_fwd(D, E) : w2_np(D, E) - w2_n_fwd(D, E));
-  r.p = 0, r.slot = 0, r.req = 0, r.req_img = 0, r.req_slot = 0;
+  r.p = 0, r.req = 0, r.req_img = 0;
   r.w = w, r.lane = lane;
-  pn_request(r);    // prime the ring: positions 0 .. 6
+  pn_request(r);    // prime the ring: positions 0 .. 7
   __syncthreads();  // tables in LDS (the DMAs are waited for by the first interval)
 
   // gradient-scale state (inr_w2.h): fused steps and split steps keep their own
@@ -540,15 +572,15 @@ __global__ __launch_bounds__(512, 2) void inr_siren_bf16_kernel(const NetDesc nd
   const int n_wtiles = (a.n_tiles + tpw - 1) / tpw;
   float loss_acc = 0.f, amax = 0.f;
   if (w < 4) {
-    SirenTile<MODE, false, true> t(nd, ld, a, r, bias_lds, encB_lds, phz, lane, w, mult);
+    SirenTile<MODE, NH, false, true> t(nd, ld, a, r, bias_lds, encB_lds, lane, w, mult);
     for (int wtile = blockIdx.x; wtile < n_wtiles; wtile += gridDim.x) t.run(tpw * wtile);
     loss_acc = t.loss_acc, amax = t.amax;
   } else if (tpw == 2) {
-    SirenTile<MODE, true, true> t(nd, ld, a, r, bias_lds, encB_lds, phz, lane, w, mult);
+    SirenTile<MODE, NH, true, true> t(nd, ld, a, r, bias_lds, encB_lds, lane, w, mult);
     for (int wtile = blockIdx.x; wtile < n_wtiles; wtile += gridDim.x) t.run(tpw * wtile + 1);
     loss_acc = t.loss_acc, amax = t.amax;
   } else {
-    SirenTile<MODE, true, false> t(nd, ld, a, r, bias_lds, encB_lds, phz, lane, w, mult);
+    SirenTile<MODE, NH, true, false> t(nd, ld, a, r, bias_lds, encB_lds, lane, w, mult);
     for (int wtile = blockIdx.x; wtile < n_wtiles; wtile += gridDim.x) t.run(0);
   }
   // every DMA this wave issued has landed before the workgroup (and its LDS) goes away
@@ -580,17 +612,34 @@ __global__ __launch_bounds__(512, 2) void inr_siren_bf16_kernel(const NetDesc nd
   }
 }
 
-template <int MODE>
-inline hipError_t launch_siren_bf16_mode(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int grid, hipStream_t st) {
-  const size_t lds_bytes = (size_t)PN_SLOTS * W2_PANEL_BYTES + PN_PHASE_BYTES +
-                           ((size_t)nd.D * 256 + 3 * (size_t)nd.E + PN_WAVES) * sizeof(float);
+template <int MODE, int NH>
+inline hipError_t launch_siren_bf16_nh(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int grid, hipStream_t st) {
+  const size_t lds_bytes = (size_t)PN_SLOTS * W2_PANEL_BYTES + ((size_t)nd.D * 256 + 3 * (size_t)nd.E + PN_WAVES) * sizeof(float);
   if (lds_bytes > 160 * 1024 || a.save_by_block) return hipErrorInvalidValue;
   if (MODE != MODE_FWD && (a.save == nullptr || a.dz_state == nullptr)) return hipErrorInvalidValue;
   if (MODE == MODE_FUSED && a.slabs == nullptr) return hipErrorInvalidValue;
-  hipError_t e = allow_full_lds<inr_siren_bf16_kernel<MODE>>();
+  hipError_t e = allow_full_lds<inr_siren_bf16_kernel<MODE, NH>>();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(inr_siren_bf16_kernel<MODE>, dim3(grid), dim3(64 * PN_WAVES), lds_bytes, st, nd, ld, a);
+  hipLaunchKernelGGL((inr_siren_bf16_kernel<MODE, NH>), dim3(grid), dim3(64 * PN_WAVES), lds_bytes, st, nd, ld, a);
   return hipGetLastError();
+}
+
+// one instantiation per depth (3 .. 8 Linear layers): the layer loops are unrolled at compile time (see "vector loads the
+// compiler does not see")
+template <int MODE>
+inline hipError_t launch_siren_bf16_mode(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int grid, hipStream_t st) {
+#ifdef INR_ONLY_NH
+  return launch_siren_bf16_nh<MODE, INR_ONLY_NH>(nd, ld, a, grid, st);
+#endif
+  switch (nd.D) {
+    case 3: return launch_siren_bf16_nh<MODE, 1>(nd, ld, a, grid, st);
+    case 4: return launch_siren_bf16_nh<MODE, 2>(nd, ld, a, grid, st);
+    case 5: return launch_siren_bf16_nh<MODE, 3>(nd, ld, a, grid, st);
+    case 6: return launch_siren_bf16_nh<MODE, 4>(nd, ld, a, grid, st);
+    case 7: return launch_siren_bf16_nh<MODE, 5>(nd, ld, a, grid, st);
+    case 8: return launch_siren_bf16_nh<MODE, 6>(nd, ld, a, grid, st);
+    default: return hipErrorInvalidValue;
+  }
 }
 
 }  // namespace inr

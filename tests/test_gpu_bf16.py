@@ -90,21 +90,37 @@ def _oracle_inputs(dev, B, seed, masked):
     return net, enc, model, sd, eng, coords, gt, mask
 
 
-def _check_against_rounding_oracle(model, eng, ref, tol, what):
-    bad = []
-    for (name, p_), (o, n, s_, c) in zip(model.named_parameters(), model._layout):
-        got, want = eng.grads[o:o + n].cpu(), ref[name].reshape(-1)
-        if float(want.norm()) > 0 and rel_l2(got, want) > tol:
-            bad.append((name, rel_l2(got, want), float(got.norm() / want.norm())))
+def _check_against_rounding_oracle(model, eng, ref, ref_wide, what, floors=1.0):
+    """Every parameter tensor: relative L2 distance device -> oracle at most 3 x the distance between two evaluations of
+    the oracle that differ only in the order of their fp32 sums (fp32 against float64 accumulation).  That distance is
+    the model's own indeterminacy -- 1e-4 (last layer) to 4e-3 (first layer's weights) at the benchmark batch sizes,
+    independent of the batch size: a bf8 value on the other side of a rounding boundary moves by 12-25 %, and the gradient
+    sums are random walks -- and the device sits at 1.0-1.3 x it (profiles/r03_bf16_oracle_distances.txt).  Small batches
+    can have no such boundary case at all in one pair of evaluations, hence the floors: 8e-3 for the first layer, 4e-3 for
+    the hidden layers, 1e-3 for the last (measured device distances: 4.8e-3 / 2.1e-3 / 2e-4).  A wrong fragment order,
+    row pairing or scale is O(1); one wrong row of 256 is 6e-2."""
+    bad, rows = [], []
+    n_layers = len(list(model.named_parameters())) // 2
+    for idx, ((name, p_), (o, n, s_, c)) in enumerate(zip(model.named_parameters(), model._layout)):
+        got, want, alt = eng.grads[o:o + n].cpu(), ref[name].reshape(-1), ref_wide[name].reshape(-1)
+        if float(want.norm()) == 0:
+            continue
+        e_dev, e_self = rel_l2(got, want), rel_l2(alt, want)
+        rows.append((name, e_dev, e_self))
+        layer = idx // 2
+        floor = floors * (8e-3 if layer == 0 else (1e-3 if layer == n_layers - 1 else 4e-3))
+        if e_dev > max(3.0 * e_self, floor):
+            bad.append((name, e_dev, e_self, float(got.norm() / want.norm())))
     assert not bad, (what, bad)
+    return rows
 
 
 @pytest.mark.parametrize("masked", [False, True])
 @pytest.mark.parametrize("B", [1, 127, 4133, 32845])
 def test_bf16_step_matches_rounding_oracle(dev, B, masked):
-    """The fused bf16 step against the CPU model of its roundings (oracle/inr_oracle_bf16.py): every parameter tensor's
-    gradient within 2e-3 (relative L2), outputs within 2e-3 -- measured differences are what the order of the fp32 sums
-    and the last bit of the hardware sine leave: single values that round the other way."""
+    """The fused bf16 step against the CPU model of its roundings (oracle/inr_oracle_bf16.py): outputs within 2e-3, every
+    parameter tensor's gradient as close to the oracle as the oracle is to itself under another summation order
+    (_check_against_rounding_oracle)."""
     import oracle as O
     import inr_mi355x as M
     from inr_mi355x import _lib as L
@@ -117,14 +133,15 @@ def test_bf16_step_matches_rounding_oracle(dev, B, masked):
     st = eng.grad_scale_state()
     mult = st[2]
     assert mult > 0 and np.log2(st[3]) == np.round(np.log2(st[3]))  # the scale is a power of two
-    y, ref, amax = O.bf16.siren_bf16_step(sd, coords, enc.B.cpu(), net, lambda yy: (yy - gt) / (cnt * 2.0), mult,
-                                          mask=None if mask is None else mask.bool())
-    assert 2.0 ** 6 <= amax <= 2.0 ** 9, amax  # the calibrated scale put the largest |dZ| where it belongs
+    dldy, mk = (lambda yy: (yy - gt) / (cnt * 2.0)), (None if mask is None else mask.bool())
+    y, ref, amax = O.bf16.siren_bf16_step(sd, coords, enc.B.cpu(), net, dldy, mult, mask=mk)
+    _, ref_wide, _ = O.bf16.siren_bf16_step(sd, coords, enc.B.cpu(), net, dldy, mult, mask=mk, wide_sums=True)
+    assert 2.0 ** 3 <= amax <= 2.0 ** 6, amax  # the calibrated scale put the largest |dZ| where it belongs
     assert float((out - y).abs().max()) < 2e-3, float((out - y).abs().max())
     sel = slice(None) if mask is None else mask.bool()
     ref_loss = float(0.5 * ((y - gt)[sel] ** 2).mean())
     assert abs(loss - ref_loss) <= 2e-3 * abs(ref_loss), (loss, ref_loss)
-    _check_against_rounding_oracle(model, eng, ref, 2e-3, f"fused B={B}")
+    _check_against_rounding_oracle(model, eng, ref, ref_wide, f"fused B={B}")
 
 
 @pytest.mark.parametrize("B", [127, 4133])
@@ -143,8 +160,11 @@ def test_bf16_split_step_matches_rounding_oracle(dev, B):
     eng.backward(coords.to(dev), encB, dout)
     mult = eng.grad_scale_state()[6]
     y, ref, amax = O.bf16.siren_bf16_step(sd, coords, enc.B.cpu(), net, lambda yy: dout.cpu(), mult)
+    _, ref_wide, _ = O.bf16.siren_bf16_step(sd, coords, enc.B.cpu(), net, lambda yy: dout.cpu(), mult, wide_sums=True)
     assert float((out.cpu() - y).abs().max()) < 2e-3
-    _check_against_rounding_oracle(model, eng, ref, 2e-3, f"split B={B}")
+    # (the perturbation enters at the top of the chain here -- act'(z_last) of the device's own output against the oracle's --
+    # and small batches show twice the fused step's distances: floors x 2)
+    _check_against_rounding_oracle(model, eng, ref, ref_wide, f"split B={B}", floors=2.0)
 
 
 @pytest.mark.parametrize("B", [25000, 65536])
@@ -180,7 +200,7 @@ def test_bf16_training_tracks_fp32(dev):
     l32 = np.array([s[1] for s in t32.fit(300, log_every=1)])
     l16 = np.array([s[1] for s in t16.fit(300, log_every=1)])
     assert l32[-20:].mean() < 0.5 * l32[:3].mean()  # it trains
-    np.testing.assert_allclose(l16[:5], l32[:5], rtol=2e-2)
+    np.testing.assert_allclose(l16[:5], l32[:5], rtol=5e-2)
     assert abs(l16[-20:].mean() - l32[-20:].mean()) < 0.1 * l32[-20:].mean()
     p32, p16 = t32.evaluate(), t16.evaluate()
     assert abs(p32 - p16) < 0.3, (p32, p16)

@@ -45,22 +45,29 @@ def test_adam_schedule_table():
 
 
 def test_bf16_kernel_inline_asm_memory_hazards():
-    """The bf16 fused kernel's stash loads are inline assembly with hand-placed vmcnt waits; the compiler neither knows
-    that their registers are written asynchronously nor pads hardware hazards inside assembly text.  One build reloaded
-    a spilled SGPR (v_readlane) right in front of the first such load -- gfx9 needs 5 wait states between a VALU write
-    of an SGPR and a vector-memory read of it -- so the load read a stale offset and the gradients became
-    timing-dependent (the load now carries its own s_nop).  tools/check_inflight_regs.py walks the built kernel:
-    no instruction may touch a register of a load still in flight (in-order vmcnt model), and no vector-memory
-    instruction may read an SGPR a VALU instruction wrote fewer than 5 wait states earlier."""
+    """The bf16 kernels' phase loads are inline assembly with hand-placed vmcnt waits (csrc/inr_siren_bf16_impl.h, "vector
+    loads the compiler does not see"); the compiler neither knows that their registers are written asynchronously nor pads
+    hardware hazards inside assembly text.  Builds have gone wrong three ways: a spilled SGPR reloaded (v_readlane) right in
+    front of such a load -- gfx9 needs 5 wait states between a VALU write of an SGPR and a vector-memory read of it; a
+    load in flight "moved" by a loop-carried copy; a load nobody reads whose destination the allocator reused.
+    tools/check_inflight_regs.py walks every built kernel (three modes x six depths): no instruction may touch a
+    register of a load still in flight (in-order vmcnt model), and no vector-memory instruction may read an SGPR a VALU
+    instruction wrote fewer than 5 wait states earlier."""
     import subprocess
     import sys
-    obj = os.path.join(ROOT, "mri-implicit-neural-representations_amd", "build", "inr_siren_bf16.o")
-    if not os.path.exists(obj) or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
-        pytest.skip("needs the built object and llvm-objdump")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_inflight_regs.py"), obj,
-                        "inr_siren_bf16_kernel"], capture_output=True, text=True)
-    assert r.returncode == 0, r.stdout + r.stderr
-    assert " 0 touch a register in flight" in r.stdout and " 0 vector-memory instructions read an SGPR" in r.stdout
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("needs llvm-objdump")
+    seen = 0
+    for m in (0, 1, 2):
+        obj = os.path.join(ROOT, "mri-implicit-neural-representations_amd", "build", f"inr_siren_bf16_m{m}.o")
+        if not os.path.exists(obj):
+            pytest.skip("needs the built objects")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_inflight_regs.py"), obj,
+                            "inr_siren_bf16_kernel"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        seen += r.stdout.count(" 0 touch a register in flight")
+        assert r.stdout.count(" 0 touch a register in flight") == r.stdout.count(" 0 vector-memory instructions read an SGPR") == 6
+    assert seen == 18
 
 
 def test_no_valu_sgpr_to_vmem_hazard_in_any_kernel():

@@ -68,7 +68,7 @@ else:
     def step():
         eng.train_step(coords, enc.B.contiguous(), gt, M.LossSpec(L.LOSS_L2_HALF))
 nt, nb = eng.launch_dims(B)
-NWV = WAVES_PER_WORKGROUP
+NWV = 8 if PREC == "bf16" else WAVES_PER_WORKGROUP  # (the bf16 kernel: eight waves, two tile groups)
 dbg = torch.zeros(nb * NWV * 64, dtype=torch.int64, device=dev)
 lib.inr_debug_set_stamp_buffer(dbg.data_ptr(), dbg.numel())
 for _ in range(3):
@@ -109,13 +109,11 @@ else:
     order = [0, 1, 2, 3, 4, 10, 11, 12, 13, 26, 29, 22, 25, 18, 21, 41, 42]
     last = 42
     if PREC != "f32":  # inr_siren_bf16_kernel: stamps 0, 1, 2, ... in program order
-        labels = ["start", "L0 GEMM", "L0 epilogue"]
-        for l in (1, 2, 3):
-            labels += [f"L{l} GEMM", f"L{l} epilogue"]
-        labels += ["last GEMM", "loss", "dX last"]
-        for l in (3, 2, 1):
-            labels += [f"bwd epilogue {l}", f"dX L{l}"]
-        labels += ["bwd epilogue 0"]
+        labels = ["start", "L0 GEMM (+ features)", "L0 epilogue"]
+        labels += [f"L{l} (row blocks: GEMM | epilogue)" for l in (1, 2, 3)]
+        labels += ["last layer + loss", "dH last + dZ_3 epilogues"]
+        labels += [f"dX L{l} (row blocks: GEMM | epilogue)" for l in (3, 2, 1)]
+        labels += ["role B's last epilogue"]
         names = dict(enumerate(labels))
         order = list(range(len(labels)))
         last = len(labels) - 1
