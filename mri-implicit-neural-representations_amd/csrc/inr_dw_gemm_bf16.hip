@@ -236,11 +236,22 @@ __device__ __forceinline__ void dwgb_body(const DwGemmBf16Args& a, const DwGemmB
   };
   const _Float16* As = lds + (wm * 64 + li) * GB_PITCH + 8 * half;
   const _Float16* Bs = lds + GB_TILE + (wn * 128 + li) * GB_PITCH + 8 * half;
-  // stage s multiplies out of LDS stage s & 1 while register set `N` (stage s+1) is staged into the other one
+  // stage s multiplies out of LDS stage s & 1 while register set `N` (stage s+1) is staged into the other one and then
+  // refilled with stage s+3.  The two waves of a SIMD (w, w + 4) run the same program between the same barriers; left in
+  // lockstep both stage at the same time -- ~150 vector instructions, the matrix pipe idle -- and then both multiply.  So
+  // they take the two halves in opposite order: waves 0-3 multiply first and stage behind it, waves 4-7 stage first.  (The
+  // refill stays behind both for every wave: issued right behind the staging of the stage-first waves it measured 14 %
+  // slower -- their loads then compete with the other waves' at the head of every stage.)
+  const bool stage_first = w >= 4;
   auto compute = [&](int s, u32x4 (&NA)[LASTROWS ? 4 : 2], u32x4 (&NB)[2]) {
     const bool more = s + 1 < n_steps;
     const _Float16* Ab = As + (size_t)(s & 1) * GB_STAGE;
     const _Float16* Bb = Bs + (size_t)(s & 1) * GB_STAGE;
+    if (stage_first) {
+      stage_a(s + 1, more, NA);
+      stage_b(s + 1, NB);
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {  // four K = 16 sub-steps of the stage's 64 coordinates
       f16x8 A[2], B[4];
@@ -252,9 +263,13 @@ __device__ __forceinline__ void dwgb_body(const DwGemmBf16Args& a, const DwGemmB
       for (int i = 0; i < (LASTROWS ? 1 : 2); ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[i], B[j], acc[i][j], 0, 0, 0);
-      if (q == 0) stage_a(s + 1, more, NA);  // the next stage's staging behind the first two sub-steps
-      if (q == 1) stage_b(s + 1, NB);
     }
+    if (!stage_first) {
+      __builtin_amdgcn_sched_barrier(0);
+      stage_a(s + 1, more, NA);
+      stage_b(s + 1, NB);
+    }
+    fetch(s + 3, NA, NB);
   };
 
   float xs_next = 0.f;
@@ -273,13 +288,11 @@ __device__ __forceinline__ void dwgb_body(const DwGemmBf16Args& a, const DwGemmB
   __syncthreads();
 #pragma unroll 1
   for (int s = 0; s < n_steps; s += 2) {
-    compute(s, ra[1], rb[1]);       // stage s+1 -> LDS from set 1 ...
-    fetch(s + 3, ra[1], rb[1]);     // ... which then takes stage s+3
+    compute(s, ra[1], rb[1]);       // stage s+1 -> LDS from set 1, which then takes stage s+3
     xs_put(s + 2, xs_next);         // xs buffer s & 1: last read while stage s was staged, one barrier ago
     xs_next = xs_get(s + 3);
     __syncthreads();
     compute(s + 1, ra[0], rb[0]);
-    fetch(s + 4, ra[0], rb[0]);
     xs_put(s + 3, xs_next);
     xs_next = xs_get(s + 4);
     __syncthreads();

@@ -142,23 +142,25 @@ __device__ __forceinline__ void pn_begin(PnRing& r) {
 __device__ __forceinline__ bf16x8 pn_frag(const PnRing& r, int p, int f) {
   return *reinterpret_cast<const bf16x8*>(r.ring + (p & (PN_SLOTS - 1)) * W2_PANEL_BYTES + (f * 64 + r.lane) * 16);
 }
-// one row block: 16 K-steps of panel p against the 16 B operands
+// one row block: 16 K-steps of panel p against the 16 B operands.  The sixteen MFMAs are one dependent chain (a single
+// accumulator), and left alone the scheduler puts each fragment's LDS read right in front of the MFMA that needs it -- the
+// matrix pipe then waits out an LDS latency per K-step (the first build: 17 lgkmcnt(0) waits per row block).  Pinned order:
+// eight reads up front, then every MFMA of the first half paired with a read of the second half, then the rest.
 __device__ __forceinline__ f32x16 pn_mma_block(const PnRing& r, int p, const bf16x8 (&b)[16]) {
-  // fragments eight at a time (32 registers): left alone the compiler fetches all sixteen up front, 64 registers on top
-  // of two sets of B operands
-#ifndef PN_FRAGS
-#define PN_FRAGS 8
-#endif
   f32x16 acc = zero16();
+  bf16x8 A[16];
 #pragma unroll
-  for (int h = 0; h < 16 / PN_FRAGS; ++h) {
-    bf16x8 A[PN_FRAGS];
+  for (int t = 0; t < 16; ++t) A[t] = pn_frag(r, p, t);
 #pragma unroll
-    for (int t = 0; t < PN_FRAGS; ++t) A[t] = pn_frag(r, p, PN_FRAGS * h + t);
+  for (int t = 0; t < 16; ++t) acc = mfma_bf16(A[t], b[t], acc);
+  __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);  // 8 LDS reads
 #pragma unroll
-    for (int t = 0; t < PN_FRAGS; ++t) acc = mfma_bf16(A[t], b[PN_FRAGS * h + t], acc);
-    __builtin_amdgcn_sched_barrier(0);
+  for (int t = 0; t < 8; ++t) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 LDS read
   }
+  __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);  // 8 MFMAs
+  __builtin_amdgcn_sched_barrier(0);
   return acc;
 }
 
@@ -384,7 +386,11 @@ struct SirenTile {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
               const float* bj = encB_lds + 3 * (8 * t + j);
+#ifdef EXP_NOFRACT
+              f[j] = __builtin_amdgcn_sinf(fmaf(x2, bj[2], fmaf(x1, bj[1], fmaf(x0, bj[0], quarter))));
+#else
               f[j] = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(fmaf(x2, bj[2], fmaf(x1, bj[1], fmaf(x0, bj[0], quarter)))));
+#endif
             }
             bq[s] = pack8(f);
           }
@@ -543,6 +549,9 @@ __global__ __launch_bounds__(512, 2) void inr_siren_bf16_kernel(const NetDesc nd
   // MODE.FP16_OVFL: conversions to fp16 and bf8 saturate at the largest finite value instead of overflowing to infinity
   // (tools/probes/bf8_clamp_probe.hip) -- a dZ beyond the gradient scale's headroom is clipped, not turned into NaNs
   if (MODE != MODE_FWD) asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1");
+#ifdef EXP_SETPRIO
+  if (w >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
   float* bias_lds = reinterpret_cast<float*>(lds_raw + PN_SLOTS * W2_PANEL_BYTES);  // [D][256]
   float* encB_lds = bias_lds + D * 256;                                             // [E][3]
   float* red_lds = encB_lds + 3 * nd.E;                                             // [8]
@@ -628,9 +637,9 @@ inline hipError_t launch_siren_bf16_nh(const NetDesc& nd, const LossDesc& ld, co
 // compiler does not see")
 template <int MODE>
 inline hipError_t launch_siren_bf16_mode(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int grid, hipStream_t st) {
-#ifdef INR_ONLY_NH
-  return launch_siren_bf16_nh<MODE, INR_ONLY_NH>(nd, ld, a, grid, st);
-#endif
+#ifdef INR_ONLY_NH  // experiment builds (tools/build_exp.sh): one depth
+  return nd.D == INR_ONLY_NH + 2 ? launch_siren_bf16_nh<MODE, INR_ONLY_NH>(nd, ld, a, grid, st) : hipErrorInvalidValue;
+#else
   switch (nd.D) {
     case 3: return launch_siren_bf16_nh<MODE, 1>(nd, ld, a, grid, st);
     case 4: return launch_siren_bf16_nh<MODE, 2>(nd, ld, a, grid, st);
@@ -640,6 +649,7 @@ inline hipError_t launch_siren_bf16_mode(const NetDesc& nd, const LossDesc& ld, 
     case 8: return launch_siren_bf16_nh<MODE, 6>(nd, ld, a, grid, st);
     default: return hipErrorInvalidValue;
   }
+#endif
 }
 
 }  // namespace inr
