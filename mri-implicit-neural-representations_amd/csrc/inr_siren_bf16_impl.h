@@ -45,10 +45,10 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 constexpr int PN_SLOTS = 8;   // ring slots of W2_PANEL_BYTES: seven panels in flight ahead of the one being multiplied
-constexpr int PN_LOOK = PN_SLOTS - 1;
+constexpr int PN_LOOK = PN_SLOTS - 2;  // intervals in front whose stash operations lie behind a panel's request
 constexpr int PN_WAVES = 8;   // waves per workgroup; each issues 16 / 8 = 2 of a panel's 1 KB LDS-DMA pieces
 #ifndef PN_PD_N
-#define PN_PD_N 2
+#define PN_PD_N 3
 #endif
 constexpr int PN_PD = PN_PD_N;      // backward epilogues whose phase loads are in flight ahead of the one being computed
 
@@ -97,14 +97,17 @@ __device__ __forceinline__ void phase_byte(unsigned& word, float t, float magic)
 // ---- the panel ring ---------------------------------------------------------------------------------------------
 // Stream position p lives in slot p & 7.  An INTERVAL consumes c panels (two per layer-0 chunk, one everywhere else):
 //   pn_begin<N>():  s_waitcnt vmcnt(N) -- this wave's pieces of the interval's panels have landed --, s_barrier --
-//   everybody's have, and everybody is done with the panels of the previous interval --, then requests up to position
-//   p + 7 into the slots just freed.
+//   everybody's have, and everybody is done with the panels of the previous interval;
+//   pn_request():  up to position p + 7 into the slots that barrier freed -- issued BEHIND the interval's MFMAs, whose
+//   execution hides the 100-odd cycles an LDS-DMA instruction takes to issue (in front of them they were on the critical
+//   path of every interval).
 // N: the vector-memory counter retires IN ORDER, so "at most N operations outstanding" covers a panel when at least N
 // operations were issued after its pieces.  Behind the pieces of the interval's last panel lie the requests of the
 // panels after it: two pieces each, 8 - c_prev - c panels (c_prev: what the previous interval consumed) -- pn_n0().  On
 // top, where the intervals in front are known to have issued S stash operations each (the hidden layers: 4 stores
-// forward, 4 loads + 4 stores backward, instructions that are issued unconditionally), S for each of the h <= 7 such
-// intervals directly in front.  A smaller N only waits longer.
+// forward, 4 loads + 4 stores backward, instructions that are issued unconditionally), S for each of the h <= 6 such
+// intervals directly in front (a panel is requested at the END of the interval seven before its own: role B has nothing
+// behind that request in the same interval).  A smaller N only waits longer.
 struct PnRing {
   const char* gbase;  // panel 0 of the image
   char* ring;
@@ -137,7 +140,6 @@ __device__ __forceinline__ void pn_begin(PnRing& r) {
   static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit field");
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
   __builtin_amdgcn_s_barrier();
-  pn_request(r);
 }
 __device__ __forceinline__ bf16x8 pn_frag(const PnRing& r, int p, int f) {
   return *reinterpret_cast<const bf16x8*>(r.ring + (p & (PN_SLOTS - 1)) * W2_PANEL_BYTES + (f * 64 + r.lane) * 16);
@@ -344,7 +346,14 @@ struct SirenTile {
       sv = reinterpret_cast<unsigned*>(a.save) + (size_t)(tile_ok ? stile : 0) * nd.save_floats_per_tile;
       ts_bytes = (tile_ok && a.save != nullptr) ? w2_stash_dwords(D) * 4 : 0;  // 0: every stash access is a no-op
       voff = (half * TL + wcol) * 4;  // the lane's byte offset inside a quad pair: quad parity = lane half, own coordinate
+#ifdef EXP_NOSTASH  // timing experiment: no stash traffic at all (results meaningless)
+      ts_bytes = 0;
+#endif
+#ifdef EXP_NOSTORE  // timing experiment: the stash stores are dropped, the loads stay
+      rs_tile = uniform_rsrc(sv, 0);
+#else
       rs_tile = uniform_rsrc(sv, ts_bytes);
+#endif
       if (BWD) rz_tile = w2_rsrc_words(sv, ts_bytes);
       if (FWD) {  // coordinates, sampling mask and target row in one batch of loads (row 0 where the lane has none)
         const long long cr = valid ? crow : 0;
@@ -411,14 +420,14 @@ struct SirenTile {
           if (!RB) gen(0);
         }
         for (int ch = 0; ch < nq0; ++ch) {
-          if (ch == 0)
-            pn_begin<pn_n0(1, 2)>(r);
-          else
-            pn_begin<pn_n0(2, 2)>(r);
+          pn_begin<pn_n0(2, 2)>(r);  // (behind a pair of row blocks, a layer-0 chunk, or -- MODE_FWD -- the last layer: 8 <= 10)
           if (ACTIVE) {
             if (RB) gen(ch);
             mma_chunk();
+            pn_request(r);
             if (!RB && ch + 1 < nq0) gen(ch + 1);
+          } else {
+            pn_request(r);
           }
           r.p += 2;
         }
@@ -430,33 +439,46 @@ struct SirenTile {
       }
 
       // ================================ hidden layers 1 .. D-2, row block by row block ================================
+      // Two row blocks (two panels) per barrier: role A runs  M E M E,  role B  E M E M  (its first epilogue belongs to
+      // the row block before) -- complementary without a barrier in the middle, and half as many rendezvous of eight
+      // waves (with one per row block half of all wave cycles were spent waiting: PMC, SQ_WAIT_ANY).
       f32x16 acc = zero16();
-      static_for<0, 8 * NH>([&](auto ic) {
-        constexpr int i = decltype(ic)::value, l = 1 + (i >> 3), m = i & 7;
-        // the requests behind the panel's pieces; + 4 stores for each of the (up to seven) intervals in front, counted
-        // from the second one (role B's first has no epilogue)
-        constexpr int N0 = i == 0 ? pn_n0(2, 1) : pn_n0(1, 1);
-        pn_begin<(ACTIVE ? N0 + 4 * pn_min(PN_LOOK, pn_max(0, i - 1)) : N0)>(r);
+      static_for<0, 4 * NH>([&](auto ic) {
+        constexpr int I = decltype(ic)::value, i0 = 2 * I, l = 1 + (i0 >> 3), m0 = i0 & 7;
+        // the requests behind the interval's panels (two consumed here, two by the interval in front, a layer-0 chunk or a
+        // pair of row blocks); + 8 stores for each of the (up to two) intervals in front, counted from the second one
+        // (role B's first has one epilogue only)
+        constexpr int N0 = pn_n0(2, 2);
+        pn_begin<(ACTIVE ? N0 + 8 * pn_min(2, pn_max(0, I - 1)) : N0)>(r);
         if (ACTIVE) {
           if (RB) {
-            if constexpr (i > 0) epi_fwd<1 + ((i - 1) >> 3), (i - 1) & 7>(acc);
+            if constexpr (i0 > 0) epi_fwd<1 + ((i0 - 1) >> 3), (i0 - 1) & 7>(acc);
             acc = pn_mma_block(r, r.p, hbuf[(l - 1) & 1]);
+            pn_request(r);
+            epi_fwd<l, m0>(acc);
+            acc = pn_mma_block(r, r.p + 1, hbuf[(l - 1) & 1]);
           } else {
             acc = pn_mma_block(r, r.p, hbuf[(l - 1) & 1]);
-            epi_fwd<l, m>(acc);
+            pn_request(r);
+            epi_fwd<l, m0>(acc);
+            acc = pn_mma_block(r, r.p + 1, hbuf[(l - 1) & 1]);
+            epi_fwd<l, m0 + 1>(acc);
           }
+        } else {
+          pn_request(r);
         }
-        r.p += 1;
-        if constexpr (m == 7) {
+        r.p += 2;
+        if constexpr (m0 == 6) {
           INR_STAMP(si); ++si;
         }
       });
 
       // ================================ last layer: one row block (rows 0 .. out_f-1 live) ================================
-      pn_begin<(ACTIVE ? pn_n0(1, 1) + 4 * pn_min(PN_LOOK, 8 * NH - 1) : pn_n0(1, 1))>(r);
+      pn_begin<(ACTIVE ? pn_n0(2, 1) + 8 * 2 : pn_n0(2, 1))>(r);
       if (ACTIVE) {
         if (RB) epi_fwd<NH, 7>(acc);
         const f32x16 accL = pn_mma_block(r, r.p, hbuf[NH & 1]);
+        pn_request(r);
         float y[4], dy[4], g[4];
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
@@ -474,6 +496,8 @@ struct SirenTile {
           f32x4 d4 = {dy[0], dy[1], dy[2], dy[3]};
           *reinterpret_cast<f32x4*>(sv + w2_stash_dy(D) + 4 * wcol) = d4;
         }
+      } else {
+        pn_request(r);
       }
       r.p += 1;
       INR_STAMP(si); ++si;
@@ -489,7 +513,8 @@ struct SirenTile {
         }
       }
       // ================================ dH_{D-2} = W_last^T dZ_last: one K-step, eight row blocks ================================
-      pn_begin<pn_n0(1, 1)>(r);
+      pn_begin<(MODE == MODE_BWD ? pn_n0(2, 1) : pn_n0(1, 1))>(r);  // behind the last layer, or the tile before's last pair
+      pn_request(r);
       f32x16 acc = zero16();
       if (ACTIVE) {
         // dZ_last rows (0,1), (2,3) of this coordinate as fp16 pairs: two dwords behind the 8-bit tensors
@@ -510,24 +535,32 @@ struct SirenTile {
       INR_STAMP(si); ++si;
 
       // ================================ dH_{l-1} = W_l^T dZ_l, l = D-2 .. 1, row block by row block ================================
-      static_for<0, 8 * NH>([&](auto jc) {
-        constexpr int j = decltype(jc)::value, li = j >> 3, m = j & 7;
-        // + 8 stash operations for each of the (up to seven) intervals in front, counted from the second (role B's first has
-        // no epilogue)
-        constexpr int NA = pn_n0(1, 1) + 8 * pn_min(PN_LOOK, pn_max(0, j - 1));
-        pn_begin<(ACTIVE ? pn_min(63, NA) : pn_n0(1, 1))>(r);
+      static_for<0, 4 * NH>([&](auto jc) {
+        constexpr int J = decltype(jc)::value, j0 = 2 * J, li = j0 >> 3, m0 = j0 & 7;
+        // + 16 stash operations for each of the (up to two) intervals in front, counted from the second (role B's first has
+        // one epilogue only)
+        constexpr int N0 = J == 0 ? pn_n0(1, 2) : pn_n0(2, 2);
+        pn_begin<(ACTIVE ? pn_min(63, N0 + 16 * pn_min(2, pn_max(0, J - 1))) : N0)>(r);
         if (ACTIVE) {
           // epilogue 8 (li + 1) + m: row block m of dZ_{l-1}, l = D-2-li
           if (RB) {
-            if constexpr (j > 0) bwd_step<8 + j - 1>(acc);
+            if constexpr (j0 > 0) bwd_step<8 + j0 - 1>(acc);
             acc = pn_mma_block(r, r.p, hbuf[li & 1]);
+            pn_request(r);
+            bwd_step<8 + j0>(acc);
+            acc = pn_mma_block(r, r.p + 1, hbuf[li & 1]);
           } else {
             acc = pn_mma_block(r, r.p, hbuf[li & 1]);
-            bwd_step<8 + j>(acc);
+            pn_request(r);
+            bwd_step<8 + j0>(acc);
+            acc = pn_mma_block(r, r.p + 1, hbuf[li & 1]);
+            bwd_step<8 + j0 + 1>(acc);
           }
+        } else {
+          pn_request(r);
         }
-        r.p += 1;
-        if constexpr (m == 7) {
+        r.p += 2;
+        if constexpr (m0 == 6) {
           INR_STAMP(si); ++si;
         }
       });

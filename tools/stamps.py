@@ -74,6 +74,20 @@ lib.inr_debug_set_stamp_buffer(dbg.data_ptr(), dbg.numel())
 for _ in range(3):
     step()
 torch.cuda.synchronize()
+if PREC == "bf16":  # wall time of the fused kernel alone (grads = NULL) in this build: cycles / time = the clock it ran at
+    ws = eng._ws(*eng.workspace(B)); ld = eng.loss_desc(M.LossSpec(L.LOSS_L2_HALF), B)
+    def fused_only():
+        L.check(lib.inr_train_step(eng.plan, C.byref(ld), eng.params.data_ptr(), eng.packed.data_ptr(), coords.data_ptr(),
+                                   enc.B.contiguous().data_ptr(), gt.data_ptr(), None, B, C.byref(ws), None,
+                                   eng._loss_word.data_ptr(), eng._stream()))
+    for _ in range(200):
+        fused_only()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(200):
+        fused_only()
+    e1.record(); torch.cuda.synchronize()
+    KERNEL_US = e0.elapsed_time(e1) / 200 * 1e3
 lib.inr_debug_set_stamp_buffer(None, 0)
 d = dbg.cpu().view(nb, NWV, 64).double()
 if PREC == "mfn":
@@ -119,6 +133,10 @@ else:
         last = len(labels) - 1
 tot = (d[:, :, last] - d[:, :, 0])
 print(f"B={B} blocks={nb} (last tile of each) total cycles/wave: mean {tot.mean():.0f} min {tot.min():.0f} max {tot.max():.0f}")
+if PREC == "bf16":
+    span = float((d[:, :, last].max(dim=1).values - d[:, :, 0].min(dim=1).values).mean())
+    print(f"fused kernel alone: {KERNEL_US:.1f} us per launch; first stamp -> last stamp of a workgroup {span:.0f} cycles: "
+          f">= {span / KERNEL_US / 1e3:.2f} GHz (the launch also loads its tables and drains)")
 prev = order[0]
 for i in order[1:]:
     seg = d[:, :, i] - d[:, :, prev]
