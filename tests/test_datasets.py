@@ -191,3 +191,53 @@ def test_recon_size_without_namespace():
     assert D.recon_size_from_ismrmrd(xml) == (320, 320, 1)
     with pytest.raises(RuntimeError):
         D.recon_size_from_ismrmrd("<h><encoding/></h>")
+
+
+# ---- pinned to the reference's own ingest arithmetic (tests/golden/ingest.npz, tools/make_golden.py: ingest_vectors) ----
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def _ingest_checks(device):
+    """datasets.py against what MRIDataset.__normalize_kspace (nerp_datasets.py:108-143), complex_center_crop /
+    normalize_image / gaussian_filter_2d / create_coords (data/utils.py:19-28,65-108) and retrieve_size
+    (nerp_datasets.py:151-170) of the reference returned for the same tensors, rtol 1e-5."""
+    import json
+    from inr_mi355x.synthetic import create_coords
+    z = np.load(os.path.join(GOLD, "ingest.npz"))
+    meta = json.load(open(os.path.join(GOLD, "ingest_meta.json")))
+    k = torch.from_numpy(z["kspace"]).to(device)
+    for n in meta["normalizations"]:
+        got = D.normalize_kspace(k.clone(), n).cpu().numpy()
+        np.testing.assert_allclose(got, z[f"norm/{n}"], rtol=1e-5, atol=1e-7, err_msg=n)
+    img = torch.from_numpy(z["image"]).to(device)
+    np.testing.assert_allclose(D.normalize_image(img).cpu().numpy(), z["normalize_image"], rtol=1e-5, atol=1e-7)
+    for tag, shp in meta["crops"].items():
+        got = D.complex_center_crop(img, shp).cpu().numpy()
+        assert got.shape == z[f"crop/{tag}"].shape and np.array_equal(got, z[f"crop/{tag}"]), tag
+    # the 3 x 3 blur of the 'gaussian_blur' scheme on its own: [N,1,H,W] in the reference, [C,H,W,2] here
+    x = torch.from_numpy(z["blur_in"]).to(device)  # [2,1,9,7]
+    got = D._gaussian_blur(x.permute(1, 2, 3, 0).contiguous(), 0.1).permute(3, 0, 1, 2).cpu().numpy()
+    np.testing.assert_allclose(got, z["blur_out"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(create_coords(3, 5, 4).numpy(), z["coords_3_5_4"], rtol=0, atol=1e-7)
+    assert list(D.recon_size_from_ismrmrd(meta["header"])) == meta["recon_size"]
+
+
+def test_ingest_matches_reference_fixtures_cpu():
+    _ingest_checks("cpu")
+
+
+@pytest.mark.gpu
+def test_ingest_matches_reference_fixtures_on_device():
+    """The same on the MI355X (the tensors stay in HBM, reductions and the blur run as device kernels), and the whole
+    slice pipeline -- hipFFT ifft2c, crop, fft2c, normalisation -- against the float64 restatement at 1e-5 of the
+    largest value (the centred FFT itself is fastmri's published definition: third-party, absent)."""
+    _ingest_checks("cuda:0")
+    ks = _scan(S=2, C=4, H=48, W=40, seed=5)
+    for normalization in ("max", "coil", "abs_max", "stand"):
+        got = D.preprocess_slice(ks[1], (32, 24, 1), False, True, normalization, False, "cuda:0").cpu().numpy()
+        want = _ref(ks[1], (32, 24, 1), False, normalization)
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max(), (normalization, np.abs(got - want).max())
+    got = D.preprocess_slice(ks[0], (32, 24, 1), True, True, None, False, "cuda:0").cpu().numpy()
+    want = _ref(ks[0], (32, 24, 1), True, None)
+    assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max()

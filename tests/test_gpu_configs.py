@@ -190,7 +190,8 @@ def test_config3_wire_hdr_batch_25000(dev):
         grad = eng.grads.clone()
         e_gpu, e_cpu = rel_l2(grad.cpu(), g64), rel_l2(g32, g64)
         le_gpu, le_cpu = abs(loss - float(l64)) / abs(float(l64)), abs(float(l32) - float(l64)) / abs(float(l64))
-        record_parity(f"config3:wire_{kind}_25000", e_gpu=e_gpu, e_cpu=e_cpu, loss_e_gpu=le_gpu, loss_e_cpu=le_cpu)
+        record_parity(f"config3:wire_{kind}_25000", e_gpu=e_gpu, e_cpu=e_cpu, loss_e_gpu=le_gpu, loss_e_cpu=le_cpu,
+                      e_gpu_vs_cpu32=rel_l2(grad.cpu(), g32))
         assert e_gpu <= max(5 * e_cpu, 1e-5), (kind, e_gpu, e_cpu)  # measured: 1.02 (L2), 1.70 (HDR)
         assert le_gpu <= max(5 * le_cpu, 1e-5), (kind, le_gpu, le_cpu)
     eng.train_step(cd, None, gd, spec, hdr_A=A)  # (spec, loss, grad: the HDR pass)
@@ -265,7 +266,8 @@ def test_config4_multiscale_lsl_consistency(dev):
     live = torch.cat([flat[o:o + n] for (o, n, s, c), lv in zip(model._layout, model._live) if lv])
     e_gpu, e_cpu = rel_l2(live, g64), rel_l2(g32, g64)
     le_gpu, le_cpu = abs(loss - float(l64)) / abs(float(l64)), abs(float(l32) - float(l64)) / abs(float(l64))
-    record_parity("config4:lsl_cons_2000", e_gpu=e_gpu, e_cpu=e_cpu, loss_e_gpu=le_gpu, loss_e_cpu=le_cpu)
+    record_parity("config4:lsl_cons_2000", e_gpu=e_gpu, e_cpu=e_cpu, loss_e_gpu=le_gpu, loss_e_cpu=le_cpu,
+                  e_gpu_vs_cpu32=rel_l2(live, g32))
     assert e_gpu <= max(4 * e_cpu, 1e-5), (e_gpu, e_cpu)
     assert le_gpu <= max(4 * le_cpu, 1e-5), (le_gpu, le_cpu)
 

@@ -201,7 +201,7 @@ def test_mfn_full_size_vs_oracle(dev, shape):
     from conftest import record_parity
     for name, got, r32, r64 in (("out", out, o32, o64), ("grad", live, g32, g64)):
         e_gpu, e_cpu = rel_l2(got, r64), rel_l2(r32, r64)
-        record_parity(f"mfn_full:{shape}", what=name, e_gpu=e_gpu, e_cpu=e_cpu)
+        record_parity(f"mfn_full:{shape}", what=name, e_gpu=e_gpu, e_cpu=e_cpu, e_gpu_vs_cpu32=rel_l2(got, r32))
         assert e_gpu <= max(4 * e_cpu, 1e-5), (name, e_gpu, e_cpu)
     assert abs(float(loss) - float(l64)) <= max(4 * abs(float(l32) - float(l64)), 1e-5 * abs(float(l64)))
 

@@ -55,7 +55,7 @@ def _check(got_out, got_loss, got_grad, r32, r64, tag="", plain=False):
     from conftest import record_parity
     for name, got, a32, a64 in (("out", got_out, r32[0], r64[0]), ("grad", got_grad, r32[2], r64[2])):
         e_gpu, e_cpu = rel_l2(got, a64), rel_l2(a32, a64)
-        record_parity("widths:" + tag, what=name, e_gpu=e_gpu, e_cpu=e_cpu)
+        record_parity("widths:" + tag, what=name, e_gpu=e_gpu, e_cpu=e_cpu, e_gpu_vs_cpu32=rel_l2(got, a32))
         assert e_gpu <= (1e-5 if plain else max(FACTOR * e_cpu, 1e-5)), (name, e_gpu, e_cpu)
     l32, l64 = float(r32[1]), float(r64[1])
     assert abs(float(got_loss) - l64) <= (1e-5 * abs(l64) if plain else max(FACTOR * abs(l32 - l64), 1e-5 * abs(l64)))

@@ -161,7 +161,7 @@ def test_wire_full_size_vs_oracle(dev, B, loss_kind):
     from conftest import record_parity
     for name, got, r32, r64 in (("out", got_out, out32, out64), ("grad", got_grad, grad32, grad64)):
         e_gpu, e_cpu = rel_l2(got, r64), rel_l2(r32, r64)
-        record_parity(f"wire_full:{loss_kind}:B{B}", what=name, e_gpu=e_gpu, e_cpu=e_cpu)
+        record_parity(f"wire_full:{loss_kind}:B{B}", what=name, e_gpu=e_gpu, e_cpu=e_cpu, e_gpu_vs_cpu32=rel_l2(got, r32))
         assert e_gpu <= max(5 * e_cpu, 1e-5), (name, e_gpu, e_cpu)  # measured maxima (profiles/r02_parity_errors.jsonl): 3.45 HDR, 1.23 L2
     e_gpu, e_cpu = abs(float(loss) - float(loss64)) / abs(float(loss64)), abs(float(loss32) - float(loss64)) / abs(float(loss64))
     record_parity(f"wire_full:{loss_kind}:B{B}", what="loss", e_gpu=e_gpu, e_cpu=e_cpu)

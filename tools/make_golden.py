@@ -589,9 +589,64 @@ def clustering_vectors():
         json.dump(meta, f, indent=1, sort_keys=True)
 
 
+def ingest_vectors():
+    """The reference's OWN ingest arithmetic (not third-party): MRIDataset.__normalize_kspace for its seven schemes
+    (nerp_datasets.py:108-143), retrieve_size on an ISMRMRD header (:151-170), and complex_center_crop /
+    normalize_image / gaussian_filter_2d / create_coords of data/utils.py:19-28,65-108.  nerp_datasets.py imports h5py and
+    fastmri.data.transforms at module scope (both absent here, neither touched by these functions): empty stand-ins are
+    registered for them, fastmri.complex_abs is the in-memory formula this script already uses.  What stays unpinned is
+    what fastmri itself computes (ifft2c / fft2c)."""
+    import matplotlib
+    matplotlib.use("Agg")
+    sys.modules.setdefault("h5py", types.ModuleType("h5py"))
+    fmd = types.ModuleType("fastmri.data")
+    fmd.transforms = types.ModuleType("fastmri.data.transforms")
+    sys.modules.setdefault("fastmri.data", fmd)
+    sys.modules.setdefault("fastmri.data.transforms", fmd.transforms)
+    from data.nerp_datasets import MRIDataset
+    from data import utils as ref_utils
+    norm = MRIDataset._MRIDataset__normalize_kspace
+    g = torch.Generator().manual_seed(77)
+    arrs, meta = {}, {"normalizations": ["abs_max", "max", "gaussian_blur", "max_std", "tonemap", "coil", "stand", "none"]}
+    k = torch.randn(3, 20, 14, 2, generator=g) * torch.tensor([1.0, 0.2, 3.0])[:, None, None, None]
+    k[1, 10, 7] = torch.tensor([9.0, -4.0])  # a k-space centre: the maxima differ between coils and components
+    arrs["kspace"] = npy(k)
+    for n in meta["normalizations"]:
+        arrs[f"norm/{n}"] = npy(quiet(norm, k.clone(), n))
+    img = torch.randn(2, 18, 11, 2, generator=g)
+    arrs["image"] = npy(img)
+    arrs["normalize_image"] = npy(ref_utils.normalize_image(img))
+    crops = {"inside": (10, 6), "wider_than_w": (12, 20), "full": (18, 11)}
+    for tag, shp in crops.items():
+        arrs[f"crop/{tag}"] = npy(ref_utils.complex_center_crop(img, shp))
+    meta["crops"] = {t: list(v) for t, v in crops.items()}
+    x = torch.randn(2, 1, 9, 7, generator=g)
+    arrs["blur_in"], arrs["blur_out"] = npy(x), npy(ref_utils.gaussian_filter_2d(x, 0.1))
+    arrs["blur_out_sigma1"] = npy(ref_utils.gaussian_filter_2d(x, 1.0))
+    arrs["coords_3_5_4"] = npy(ref_utils.create_coords(3, 5, 4))
+    header = ('<?xml version="1.0" encoding="utf-8"?><ismrmrdHeader xmlns="http://www.ismrm.org/ISMRMRD"><encoding>'
+              '<encodedSpace><matrixSize><x>640</x><y>372</y><z>1</z></matrixSize></encodedSpace>'
+              '<reconSpace><matrixSize><x>320</x><y>322</y><z>1</z></matrixSize></reconSpace>'
+              '<encodingLimits><kspace_encoding_step_1><minimum>0</minimum><maximum>367</maximum><center>184</center>'
+              '</kspace_encoding_step_1></encodingLimits></encoding></ismrmrdHeader>')
+
+    class _Field:  # what h5py hands back for file["ismrmrd_header"][()]
+        def __init__(self, b):
+            self.b = b
+
+        def __getitem__(self, _):
+            return self.b
+
+    meta["header"] = header
+    meta["recon_size"] = list(MRIDataset.retrieve_size({"ismrmrd_header": _Field(header.encode())}))
+    np.savez_compressed(os.path.join(OUT, "ingest.npz"), **arrs)
+    with open(os.path.join(OUT, "ingest_meta.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    parts = dict(clustering=clustering_vectors, undersampling=undersampling_vectors, init=init_hashes,
+    parts = dict(ingest=ingest_vectors, clustering=clustering_vectors, undersampling=undersampling_vectors, init=init_hashes,
                  models=model_vectors, losses=loss_vectors, center=center_vectors, trajectory=trajectory,
                  multiscale=multiscale_trajectory)
     for name in (sys.argv[1:] or list(parts)):  # python tools/make_golden.py [part ...]; default: everything
