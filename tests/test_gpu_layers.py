@@ -119,16 +119,19 @@ def test_one_bounded_linear_width_512(dev):
     dist = torch.sqrt(coords[:, 1] ** 2 + coords[:, 2] ** 2)
     assert int((dist < 0.2).sum()) > 5 and int((dist > 0.9).sum()) > 5
 
-    def ref(dtype):
-        keys = O.trainable_keys("BoundedFourier", sd)
-        params = {k: (v.to(dtype).clone().requires_grad_(True) if k in keys else v.to(dtype)) for k, v in sd.items()}
+    names = [n for n, _ in mdl.named_parameters()]
+    assert len(names) == len(mdl._live)
+
+    def ref(dtype):  # (O.trainable_keys knows the depth-8 multiscale shapes only: here the live set is the model's own)
+        params = {k: v.to(dtype).clone().requires_grad_(True) for k, v in sd.items()}
         x = O.encode(coords.to(dtype), enc.B.cpu().to(dtype), "gauss")
         outs = O.bounded_forward(params, x, net, dist.to(dtype), bounds)
         loss = sum(O.loss_l2_half(o.contiguous(), gt.to(dtype)) for o in outs)
-        live_keys = [k for k in keys]
-        gr = torch.autograd.grad(loss, [params[k] for k in live_keys], allow_unused=True)
-        return (torch.stack([o.detach() for o in outs]), loss.detach(),
-                torch.cat([x_.reshape(-1) for x_ in gr if x_ is not None]))
+        live_names = [n for n, lv in zip(names, mdl._live) if lv]
+        gr = torch.autograd.grad(loss, [params[n] for n in live_names])
+        dead = torch.autograd.grad(loss, [params[n] for n, lv in zip(names, mdl._live) if not lv], allow_unused=True)
+        assert all(g_ is None for g_ in dead)  # what the engine skips really has no gradient in the reference's graph
+        return torch.stack([o.detach() for o in outs]), loss.detach(), torch.cat([g_.reshape(-1) for g_ in gr])
 
     r32, r64 = ref(torch.float32), ref(torch.float64)
     eng = mdl._engine()
