@@ -96,6 +96,29 @@ def cpu_baseline(image, coords, shape, seconds=15.0, psnr_steps=1000):
     out = {"value": (k - 2) * bs / dt, "unit": "coord-samples/s", "cores": torch.get_num_threads(), "kind": "port",
            "sample": f"{k - 2} steps x {bs} rows of the same workload (oracle: PyTorch-CPU fp32, "
                      f"encode+fwd+0.5*MSE+autograd+Adam), {dt:.1f} s"}
+    # the same step fed the reference's way: batches collated item by item by a torch DataLoader
+    # over the per-coordinate dataset -- the host-bound figure the reference's loop would see on these cores.  Four batches.
+    loader = torch.utils.data.DataLoader(O.PerItemDataset(coords, image), batch_size=bs, shuffle=False, num_workers=0)
+    sd2 = {k_: v.clone().requires_grad_(True) for k_, v in sd.items()}
+    opt_state = O.adam_init(sd2)
+    t_data = t_all = 0.0
+    it = iter(loader)
+    for i in range(5):
+        ta = time.perf_counter()
+        xb, gb, _, _ = next(it)
+        tb = time.perf_counter()
+        loss = O.loss_l2_half(O.siren_forward(sd2, O.encode(xb, B, "gauss"), cfg["net"]), gb)
+        grads = dict(zip(sd2.keys(), torch.autograd.grad(loss, list(sd2.values()))))
+        with torch.no_grad():
+            O.adam_step(sd2, grads, opt_state, cfg["lr"], 0.9, 0.999, 1e-8, 0.0)
+        tc = time.perf_counter()
+        if i > 0:  # (the first batch pays the iterator's start-up)
+            t_data += tb - ta
+            t_all += tc - ta
+    out["dataloader_bound"] = {"value": 4 * bs / t_all, "unit": "coord-samples/s", "data_only": 4 * bs / t_data,
+                               "sample": f"4 batches x {bs} rows through a per-item DataLoader (default collate, no workers) "
+                                         f"+ the same CPU step: {t_all / 4 * 1e3:.0f} ms per batch, {t_data / 4 * 1e3:.0f} ms "
+                                         "of it collating"}
     if psnr_steps > 0:
         with torch.no_grad():
             pred = torch.cat([O.model_forward("SIREN", sd, O.encode(coords[lo:lo + (1 << 18)], B, "gauss"), cfg["net"])
@@ -172,6 +195,44 @@ def bf16_path(cfg, image, coords, shape, dev, args, fused_kernel_ms_of, main_lin
     return res
 
 
+def config5_percoil(dev, steps=15, warmup=4):
+    """BASELINE config 5 -- radial acc-4 undersampling, per-coil batches (one 640 x 368 coil = 235 520 coordinates per
+    step, the forward pass on all of them, the loss on the ~59 k sampled ones), TV on the coil's grid (train.py:158-192
+    with per_coil / use_tv; losses.py:326-343), SIREN 5x256 -- on both precisions.  The step is split at the loss (forward
+    with stash -> loss + TV gradient -> backward + weight-gradient GEMM -> Adam).  Algorithmic FLOP per coordinate as the
+    graded workload's (every row goes through forward, dX and dW: unsampled rows carry a zero pointwise gradient but
+    their TV gradient)."""
+    import yaml
+    from inr_mi355x.synthetic import make_kspace
+    from inr_mi355x.train import INRTrainer
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "config_siren_radial_tv_bf16.yaml")))
+    image, coords, shape = make_kspace(2, SHAPE[1], SHAPE[2], seed=1234, normalization="coil")
+    out = {"workload": "SIREN 5x256 gauss-512, radial-4 mask, per-coil batches of 640x368 = 235 520 coordinates, L2 + TV "
+                       "(split step: forward | loss + TV | backward + dW GEMM | Adam)", "rows_per_step": SHAPE[1] * SHAPE[2]}
+    for prec in ("f32", "bf16"):
+        c = dict(cfg)
+        c.pop("precision")
+        if prec == "bf16":
+            c["precision"] = "bf16"
+        tr = INRTrainer(c, image, coords, shape, dev, seed=0, mask_seed=7)
+        spe = tr.steps_per_epoch
+        for i in range(warmup):
+            tr.step(0, i % spe)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            tr.step(0, (warmup + i) % spe)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        peak = BF16_MFMA_PEAK_TFLOPS if prec == "bf16" else F32_MFMA_PEAK_TFLOPS
+        ach = FLOP_PER_SAMPLE * tr.bs / (ms * 1e-3) / 1e12
+        out[prec] = {"ms_per_step": ms, "coord_samples_per_s": tr.bs / (ms * 1e-3), "achieved_tflops": ach, "peak": peak,
+                     "frac": ach / peak, "sampled_fraction": float(tr.mask_cpu.float().mean())}
+        del tr
+    out["bf16_speedup"] = out["f32"]["ms_per_step"] / out["bf16"]["ms_per_step"]
+    return out
+
+
 MS_FLOP_PER_SAMPLE = 19_423_232  # SURVEY.md 8(d): MultiscaleKFourier 8x512/in512, 4 heads, live layers only
 MS_CONFIG = {
     "model": "MultiscaleKFourier", "loss": "LSL", "loss_opts": {"hdr_eps": 3e-3, "hdr_ff_sigma": 2, "hdr_ff_factor": 0.5},
@@ -180,6 +241,48 @@ MS_CONFIG = {
     "net": {"network_input_size": 512, "network_output_size": 2, "network_depth": 8, "network_width": 512},
     "encoder": {"embedding": "gauss", "scale": 4, "embedding_size": 256, "coordinates_size": 3},
 }
+
+
+def config4_shard_sweep(tr, dev, reps=6):
+    """ONE GPU, the step a rank of an N-GPU job would run: the gradient path on 100 000 / N rows of batch 0 (global count
+    and consistency counts kept: exactly what rank 0 computes) and the Adam update, timed apart with HIP events.  From
+    them the ceiling of the strong-scaling curve,  T(1) / (T_grad(N) + T_adam + all-reduce estimate),  with the all-reduce
+    of the flat gradient priced as a ring over xGMI links at 100 GB/s effective:  2 (N - 1) / N x bytes / (rings x 100 GB/s)
+    for ONE ring and for FOUR (RCCL builds several rings over the 7 links; the measured value comes from SCALE runs).
+    No curve is claimed from this: it says where the time of a shard-sized step goes before a multi-GPU box is there."""
+    eng = tr.engine
+    lo, hi = 0, min(tr.bs, tr.n)
+    cons = tr._cons_spec(0, lo, hi)
+    lr = tr.config["lr"]
+    out = {"rows_global": hi - lo, "allreduce_bytes": 4 * (eng.n_params + 1), "by_n": {}}
+
+    def timed(fn, n):
+        for _ in range(2):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+
+    t_adam = timed(lambda: eng.adam_step(lr, tr.config["beta1"], tr.config["beta2"], 1e-8, tr.config["weight_decay"]), reps)
+    t1 = None
+    for n in (1, 2, 4, 8):
+        shi = lo + (hi - lo) // n
+        x, g, d = tr._inputs(lo, shi), tr.image[lo:shi], tr.dist[lo:shi]
+        t_grad = timed(lambda: eng.train_step(x, tr.enc_B, g, tr.loss, count=hi - lo, dist=d, scale=tr.scale, cons=cons), reps)
+        nt, nb = eng.launch_dims(shi - lo)
+        if n == 1:
+            t1 = t_grad + t_adam
+        ar = [2.0 * (n - 1) / n * out["allreduce_bytes"] / (rings * 100e9) * 1e3 for rings in (1, 4)]
+        out["by_n"][str(n)] = {"rows": shi - lo, "tiles": nt, "workgroups": nb, "grad_path_ms": t_grad, "adam_ms": t_adam,
+                               "allreduce_est_ms": {"one_ring": ar[0], "four_rings": ar[1]},
+                               "ceiling": {"one_ring": t1 / (t_grad + t_adam + ar[0]),
+                                           "four_rings": t1 / (t_grad + t_adam + ar[1])}}
+    return out
 
 
 def multiscale_config4(dev, rank, world, pg, steps, warmup, barrier):
@@ -214,7 +317,9 @@ def multiscale_config4(dev, rank, world, pg, steps, warmup, barrier):
         it = (warmup + i) % spe
         rows += min((it + 1) * tr.bs, tr.n) - it * tr.bs
     ach = MS_FLOP_PER_SAMPLE * rows / dt / 1e12
-    return {"workload": "MultiscaleKFourier 8x512 gauss-512, LSL + 0.1 consistency, 4-ring k-means partition, "
+    sweep = config4_shard_sweep(tr, dev) if world == 1 else None
+    return {"shard_sweep": sweep,
+            "workload": "MultiscaleKFourier 8x512 gauss-512, LSL + 0.1 consistency, 4-ring k-means partition, "
                         "synthetic 640x368x15-coil", "value": rows / dt, "unit": "coord-samples/s", "n_gpus": world,
             "scaling": "strong", "global_batch": tr.bs, "steps": steps, "warmup": warmup,
             "ms_per_step": dt / steps * 1e3, "radii": [float(r) for r in tr.radii],
@@ -232,6 +337,7 @@ def main():
     ap.add_argument("--no-bf16", action="store_true", help="skip the bf16-MFMA throughput path's extra object")
     ap.add_argument("--psnr-steps", type=int, default=1000, help="total steps before the PSNR read-out (N=1)")
     ap.add_argument("--no-multiscale", action="store_true", help="skip the config-4 (multi-scale) object")
+    ap.add_argument("--no-config5", action="store_true", help="skip the config-5 (radial mask, per-coil TV) object")
     ap.add_argument("--ms-steps", type=int, default=10, help="timed steps of the config-4 object")
     ap.add_argument("--graph", type=int, default=0,
                     help="N=1: replay each batch's step as one captured HIP graph.  Off by default: measured slower "
@@ -379,6 +485,9 @@ def main():
         "roofline": {"bound": "mfma", "kernel": "inr_mlp_kernel<8,GAUSS,SIN,FUSED>", "achieved": achieved,
                      "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS,
                      "kernel_ms": k_ms, "flop_per_sample": FLOP_FUSED_F32, "traffic": traffic,
+                     "traffic_source": "profiles/traffic_latest.json: HBM bytes per launch from separate rocprofv3 --pmc "
+                                       "passes of this workload (FETCH_SIZE x 2 + WRITE_SIZE), committed with the round's "
+                                       "profiles -- not measured by this run",
                      "note": "exact-fp32 path (v_mfma_f32_32x32x2_f32); peak = dense f32 MFMA. This kernel: encoder, "
                              "forward, loss, dX and the last layer's dW; dW of the 256-row layers is dw_gemm_kernel",
                      "gradient_path": {"kernels": "inr_mlp_kernel + dw_gemm_kernel<128> + reduce_slabs_real_kernel",
@@ -428,6 +537,8 @@ def main():
         if ref is not None and "psnr_at_1k_steps" in out["bf16_path"]:
             out["bf16_path"]["psnr_at_1k_steps"]["delta_vs_reference_db"] = (
                 out["bf16_path"]["psnr_at_1k_steps"]["psnr_db"] - ref["psnr_db"])
+    if world == 1 and rank == 0 and not args.no_config5:
+        out["config5_percoil_tv"] = config5_percoil(dev)
     if not args.no_multiscale:  # every rank takes part (strong scaling over the world)
         ms = multiscale_config4(dev, rank, world, pg, args.ms_steps, 3, barrier)
         if rank == 0:

@@ -61,6 +61,7 @@ struct inr_plan {
   mutable std::mutex side_mu;
   mutable hipStream_t side = nullptr;
   mutable int side_dev = -1;
+  mutable hipEvent_t fork = nullptr, join = nullptr;  // the split step's two events, created with the side stream
   // bf16 plans: the gradient-scale state of the 8-bit stash (inr_w2.h), W2_STATE_FLOATS floats on the device, allocated
   // with the plan; what the host remembers about it: whether a kind of step (0 fused, 1 split) has been calibrated, and
   // for which batch size / loss.  One stream at a time may step a bf16 plan.
@@ -454,6 +455,8 @@ int inr_plan_create(const inr_net_desc* d, inr_plan** out) {
 
 int inr_plan_destroy(inr_plan* plan) {
   if (plan != nullptr && plan->side != nullptr) (void)hipStreamDestroy(plan->side);
+  if (plan != nullptr && plan->fork != nullptr) (void)hipEventDestroy(plan->fork);
+  if (plan != nullptr && plan->join != nullptr) (void)hipEventDestroy(plan->join);
   if (plan != nullptr && plan->dz_state != nullptr) (void)hipFree(plan->dz_state);
   delete plan;
   return INR_OK;
@@ -657,12 +660,22 @@ static hipStream_t side_stream(const inr_plan* plan) {
   if (hipGetDevice(&dev) != hipSuccess) return nullptr;
   if (plan->side != nullptr && plan->side_dev != dev) {
     (void)hipStreamDestroy(plan->side);
+    if (plan->fork != nullptr) (void)hipEventDestroy(plan->fork);
+    if (plan->join != nullptr) (void)hipEventDestroy(plan->join);
     plan->side = nullptr;
+    plan->fork = plan->join = nullptr;
   }
   if (plan->side == nullptr) {
     int least = 0, greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
     if (hipStreamCreateWithPriority(&plan->side, hipStreamNonBlocking, least) != hipSuccess) plan->side = nullptr;
+    if (plan->side != nullptr && (hipEventCreateWithFlags(&plan->fork, hipEventDisableTiming) != hipSuccess ||
+                                  hipEventCreateWithFlags(&plan->join, hipEventDisableTiming) != hipSuccess)) {
+      if (plan->fork != nullptr) (void)hipEventDestroy(plan->fork);
+      (void)hipStreamDestroy(plan->side);
+      plan->side = nullptr;
+      plan->fork = plan->join = nullptr;
+    }
     plan->side_dev = dev;
   }
   return plan->side;
@@ -955,12 +968,7 @@ static int run_fused_step(const inr_plan* plan, const LossDesc& ld, const inr::M
     if (grads == nullptr) return INR_OK;  // profiling: leave the per-block slabs unreduced
     return finish_gradients(plan, a, nt, nb, grads, loss_out, params, packed, st, who, af);
   }
-  hipEvent_t fork = nullptr, join = nullptr;
-  if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess) {
-    if (fork != nullptr) (void)hipEventDestroy(fork);
-    return fail(INR_ERR_HIP, "%s: event creation failed", who);
-  }
+  const hipEvent_t fork = plan->fork, join = plan->join;  // (created once, with the side stream)
   float* chunk_slabs = a.slabs + (size_t)nb * plan->nd.slab_floats;
   inr::MlpArgs a1 = a, a2 = a;
   a1.n_tiles = (int)sc.full;
@@ -979,8 +987,6 @@ static int run_fused_step(const inr_plan* plan, const LossDesc& ld, const inr::M
   if (rc == INR_OK && e == hipSuccess) e = inr::launch_dw_gemm(sc.gB, st);
   if (rc == INR_OK && e == hipSuccess)
     e = reduce_stage(plan, a.slabs, (int)nb, grads, loss_out, params, packed, st, sc.red, af);
-  (void)hipEventDestroy(fork);
-  (void)hipEventDestroy(join);
   if (rc != INR_OK) return rc;
   if (e != hipSuccess) return hip_fail(e, (std::string(who) + ": split step").c_str());
   return INR_OK;

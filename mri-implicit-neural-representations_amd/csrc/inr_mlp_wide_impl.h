@@ -347,6 +347,7 @@ __global__ __launch_bounds__(256) void inr_mlp_wide_kernel(const NetDesc nd, con
     float* sv_g = sv_last + 4 * TL;  // WIRE2D (never gauss): copy of a layer's output gradient [NB*32][TL]
     const bool stash = saving && hh == 0;  // one wave of the pair writes the (shared) lazy-activation stash
     int si = 0;  // diagnostic builds: phase stamps 0, 1, 2, ... in program order (tools/stamps.py wire)
+    (void)si;
     // what the loss section needs from memory, requested now (fetched where it is used, the last-layer biases, the
     // sampling mask and the target row were three serialized round trips between the last layer and the loss)
     float gt_pre[4] = {0.f, 0.f, 0.f, 0.f}, lb_pre[4] = {0.f, 0.f, 0.f, 0.f};

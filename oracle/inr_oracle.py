@@ -34,7 +34,7 @@ __all__ = [
     "loss_consistency", "loss_tv", "reg_l1", "reg_l2", "make_loss",
     "adam_init", "adam_step", "lr_factor",
     "complex_abs", "rss", "fft2c", "ifft2c", "psnr",
-    "train_single_scale", "train_multiscale", "create_pairs", "reconstruct",
+    "train_single_scale", "train_multiscale", "create_pairs", "reconstruct", "PerItemDataset",
 ]
 
 
@@ -705,6 +705,22 @@ def reconstruct(flat: Tensor, shape, in_image_space: bool) -> Tensor:
 # --------------------------------------------------------------------------------------
 # Training loops (train.py:155-198; train_kspace_multiscale.py:161-201)
 # --------------------------------------------------------------------------------------
+class PerItemDataset(torch.utils.data.Dataset):
+    """The reference's data path for one batch: MRIDataset.__getitem__ returns ONE coordinate's
+    (coords[idx], image[idx], [], []) (nerp_datasets.py:236-237) and the loops draw batches of `batch_size` of them from
+    a torch DataLoader with the default collate, shuffle=False, num_workers=0 (models/utils.py:84-90) -- 25 000 Python calls
+    and a 25 000-way stack per batch.  Used by bench.py to time the host-bound figure the reference would actually see."""
+
+    def __init__(self, coords: Tensor, image: Tensor):
+        self.coords, self.image = coords, image
+
+    def __getitem__(self, idx):
+        return self.coords[idx], self.image[idx], list(), list()
+
+    def __len__(self):
+        return len(self.image)
+
+
 def _batches(n: int, bs: int):
     """Sequential, unshuffled, drop_last=False (models/utils.py:84-90; SURVEY A.4 #1)."""
     for lo in range(0, n, bs):
