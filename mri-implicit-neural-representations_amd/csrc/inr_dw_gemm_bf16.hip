@@ -114,7 +114,11 @@ __device__ __forceinline__ u32x4 gauss_features(const float* xs, const float* en
 
 // ENC: B = encoder features (first layer); BIAS: this column block also produces db; LASTROWS: dZ has only its first
 // four rows (the out_features <= 4 rows of the last layer, fp16 row pairs): the rest of the A tile stays zero
-template <int TL, bool ENC, bool BIAS, bool LASTROWS>
+// NSETS: register sets of fetched operands -- a stage's operands are requested NSETS stages before they are staged.  The
+// hidden-layer units afford a third set (128 accumulator registers + 3 x 16); the first-layer units, which also hold
+// encoder arithmetic, keep two.  (Inlined: as real functions the variants would take their arguments through memory --
+// flat loads, whose waits are vmcnt(0) and drain the prefetch -- and buffer descriptors from memory cost waterfall loops.)
+template <int TL, bool ENC, bool BIAS, bool LASTROWS, int NSETS>
 __device__ __forceinline__ void dwgb_body(const DwGemmBf16Args& a, const DwGemmBf16Unit& it, int kc, char* lds_raw) {
   _Float16* lds = reinterpret_cast<_Float16*>(lds_raw);
   float* xs_lds = reinterpret_cast<float*>(lds_raw + (size_t)2 * GB_STAGE * 2);  // [2 stages][64 coords][3]
@@ -148,24 +152,28 @@ __device__ __forceinline__ void dwgb_body(const DwGemmBf16Args& a, const DwGemmB
   const int seg = t & 7, quad = t >> 3;
   const unsigned* sv = reinterpret_cast<const unsigned*>(a.save);
   const size_t tile_dwords = (size_t)a.save_floats_per_tile;
-  // two register sets: while stage s multiplies, set (s+1)&1 -- fetched a whole stage earlier -- is staged into LDS and
-  // then refilled with stage s+3 (global latency is several microseconds under load; a stage is ~1)
-  u32x4 ra[2][LASTROWS ? 4 : 2], rb[2][2];
+  // NSETS register sets: while stage s multiplies, the set of stage s+1 -- fetched NSETS stages earlier -- is staged into
+  // LDS and then refilled with stage s+1+NSETS (global latency is several microseconds under load, a stage 1.5-3: with two
+  // sets the launch ran at the pace of its loads -- a loads -> LDS -> barrier skeleton took three quarters of its time)
+  u32x4 ra[NSETS][LASTROWS ? 4 : 2], rb[NSETS][2];
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
 
   // (through a buffer descriptor on the tile's wave-uniform base: the thread's part of an address is the byte offset of its
   // (row quad, segment), formed once; tensor and K-step offsets are scalar -- no 64-bit vector adds in the loop)
-  const int voffA = (quad * TL + 8 * seg) * 4;
-  const int voffB = ((it.n0 / 4 + quad) * TL + 8 * seg) * 4;
-  const int voffL = 8 * seg * 4;  // LASTROWS: row pair p at p * TL dwords
+  static_assert(GB_KS == W2_HALF, "a stage is one half-tile block of the 8-bit tensors");
+  const int voffA = (quad * W2_HALF + 8 * seg) * 4;
+  const int voffB = ((it.n0 / 4 + quad) * W2_HALF + 8 * seg) * 4;
+  const int voffL = 8 * seg * 4;  // LASTROWS: row pair p at p * TL dwords (fp16 pairs, whole-tile rows)
   auto fetch = [&](int s, u32x4 (&A)[LASTROWS ? 4 : 2], u32x4 (&B)[2]) {
     if (s >= n_steps) s = n_steps - 1;  // past the end: the last stage again (loaded, never multiplied)
     const int tile = t0 + s / KS_PER_TILE, c0 = (s % KS_PER_TILE) * GB_KS;
-    const unsigned long long ba = reinterpret_cast<unsigned long long>(sv + (size_t)tile * tile_dwords + c0);
+    const unsigned long long ba = reinterpret_cast<unsigned long long>(sv + (size_t)tile * tile_dwords);
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)ba), hi = __builtin_amdgcn_readfirstlane((unsigned)(ba >> 32));
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, 0x7ffffff0, 0x00020000);
-    const int soA = it.dz_off * 4, soB = it.z_off * 4;
+    // the stage's half-tile block of the 8-bit tensors; dZ_last (fp16 row pairs): its 64 coordinates of the tile's rows
+    const int blk = (s % KS_PER_TILE) * (W2_TENSOR_DWORDS / 2);
+    const int soA = (it.dz_off + (LASTROWS ? c0 : blk)) * 4, soB = (it.z_off + blk) * 4;
     if (LASTROWS) {
       if (quad == 0) {
         A[0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voffL, soA, 0));
@@ -201,6 +209,11 @@ __device__ __forceinline__ void dwgb_body(const DwGemmBf16Args& a, const DwGemmB
   auto stage_a = [&](int s, bool count, const u32x4 (&A)[LASTROWS ? 4 : 2]) {
     _Float16* st = lds + (size_t)(s & 1) * GB_STAGE + (4 * quad) * GB_PITCH + 8 * seg;
     u32x4 row[4];
+#ifdef GB_EXP_NOSTAGEVALU
+    if (!LASTROWS) {
+      row[0] = A[0], row[1] = A[1], row[2] = A[0], row[3] = A[1];
+    } else
+#endif
     if (LASTROWS) {
       if (quad != 0) return;
       split_rows(A[0], A[1], row[0], row[1]);
@@ -221,6 +234,12 @@ __device__ __forceinline__ void dwgb_body(const DwGemmBf16Args& a, const DwGemmB
   auto stage_b = [&](int s, const u32x4 (&B)[2]) {
     _Float16* st = lds + (size_t)(s & 1) * GB_STAGE + GB_TILE + (4 * quad) * GB_PITCH + 8 * seg;
     u32x4 row[4];
+#ifdef GB_EXP_NOSTAGEVALU
+    if (true) {
+      row[0] = B[0], row[1] = B[1], row[2] = B[0], row[3] = B[1];
+      if (ENC) row[0] = row[1] = row[2] = row[3] = u32x4{1u, 2u, 3u, (unsigned)seg};
+    } else
+#endif
     if (ENC) {
       const float* xs = xs_lds + (s & 1) * GB_KS * 3 + 24 * seg;
 #pragma unroll
@@ -262,14 +281,19 @@ __device__ __forceinline__ void dwgb_body(const DwGemmBf16Args& a, const DwGemmB
 #pragma unroll
       for (int i = 0; i < (LASTROWS ? 1 : 2); ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[i], B[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j)
+#ifdef GB_EXP_NOMFMA
+          acc[i][j][q] += (float)A[i][0] + (float)B[j][0];
+#else
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[i], B[j], acc[i][j], 0, 0, 0);
+#endif
     }
     if (!stage_first) {
       __builtin_amdgcn_sched_barrier(0);
       stage_a(s + 1, more, NA);
       stage_b(s + 1, NB);
     }
-    fetch(s + 3, NA, NB);
+    fetch(s + 1 + NSETS, NA, NB);
   };
 
   float xs_next = 0.f;
@@ -277,25 +301,38 @@ __device__ __forceinline__ void dwgb_body(const DwGemmBf16Args& a, const DwGemmB
     fetch(0, ra[0], rb[0]);
     xs_put(0, xs_get(0));
     xs_next = xs_get(1);
-    fetch(1, ra[1], rb[1]);
+#pragma unroll
+    for (int k = 1; k < NSETS; ++k) fetch(k, ra[k], rb[k]);
     if (ENC || LASTROWS) __syncthreads();  // xs of stage 0, the encoder matrix, the zeroed A tiles
     stage_a(0, true, ra[0]);
     stage_b(0, rb[0]);
-    fetch(2, ra[0], rb[0]);
+    fetch(NSETS, ra[0], rb[0]);
     xs_put(1, xs_next);
     xs_next = xs_get(2);
   }
   __syncthreads();
+  // stage k multiplies while stage k+1 goes from set (k+1) % NSETS into LDS; compute() then refills that set
+  auto step = [&](int k, u32x4 (&NA)[LASTROWS ? 4 : 2], u32x4 (&NB)[2]) {
+    compute(k, NA, NB);
+    xs_put(k + 2, xs_next);  // xs buffer k & 1: last read while stage k was staged, one barrier ago
+    xs_next = xs_get(k + 3);
+    __syncthreads();
+  };
+  if (NSETS == 2) {
 #pragma unroll 1
-  for (int s = 0; s < n_steps; s += 2) {
-    compute(s, ra[1], rb[1]);       // stage s+1 -> LDS from set 1, which then takes stage s+3
-    xs_put(s + 2, xs_next);         // xs buffer s & 1: last read while stage s was staged, one barrier ago
-    xs_next = xs_get(s + 3);
-    __syncthreads();
-    compute(s + 1, ra[0], rb[0]);
-    xs_put(s + 3, xs_next);
-    xs_next = xs_get(s + 4);
-    __syncthreads();
+    for (int s = 0; s < n_steps; s += 2) {
+      step(s, ra[1], rb[1]);
+      step(s + 1, ra[0], rb[0]);
+    }
+  } else {
+#pragma unroll 1
+    for (int s = 0; s < n_steps; s += 3) {
+      step(s, ra[1 % NSETS], rb[1 % NSETS]);
+      if (s + 1 >= n_steps) break;
+      step(s + 1, ra[2 % NSETS], rb[2 % NSETS]);
+      if (s + 2 >= n_steps) break;
+      step(s + 2, ra[0], rb[0]);
+    }
   }
   // ---- chunk slab: dW rows follow the MFMA C layout (register r of lane (li, half): row (r&3)+8(r>>2)+4 half, col li);
   // the gradient scale comes off here
@@ -334,15 +371,18 @@ __global__ __launch_bounds__(GB_NT, 2) void dw_gemm_bf16_kernel(const DwGemmBf16
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
   const int kc = blockIdx.x / a.n_units;
   const DwGemmBf16Unit& it = a.unit[blockIdx.x - kc * a.n_units];
+#ifdef GB_EXP_NOENC  // timing experiment: the first-layer units leave at once
+  if (it.z_off < 0) return;
+#endif
   if (it.z_off < 0) {
     if (it.n0 == 0)
-      dwgb_body<TL, true, true, false>(a, it, kc, lds_raw);
+      dwgb_body<TL, true, true, false, 2>(a, it, kc, lds_raw);
     else
-      dwgb_body<TL, true, false, false>(a, it, kc, lds_raw);
+      dwgb_body<TL, true, false, false, 2>(a, it, kc, lds_raw);
   } else if (it.M <= 4) {
-    dwgb_body<TL, false, true, true>(a, it, kc, lds_raw);  // last layer: out_features <= 4 rows of dZ
+    dwgb_body<TL, false, true, true, 3>(a, it, kc, lds_raw);  // last layer: out_features <= 4 rows of dZ
   } else {
-    dwgb_body<TL, false, true, false>(a, it, kc, lds_raw);  // hidden layers: one column tile (K <= 256), always with db
+    dwgb_body<TL, false, true, false, 3>(a, it, kc, lds_raw);  // hidden layers: one column tile (K <= 256), always with db
   }
   // the next step's gradient scale (inr_w2.h): nothing in this launch reads words 0 and 1
   if (a.dz_state != nullptr && blockIdx.x == 0 && threadIdx.x == 0) dz_state_roll(a.dz_state);

@@ -191,14 +191,14 @@ __device__ __forceinline__ u32x4 w2_rsrc_words(const void* p, int bytes) {
   r[3] = 0x00020000u;
   return r;
 }
-// the four phase dwords of a row block (quads 8 mm + 2 g + half, g = 0..3: 1 KB apart)
+// the four phase dwords of a row block (quads 8 mm + 2 g + half, g = 0..3: 512 B apart)
 __device__ __forceinline__ void w2_load4_asm(unsigned (&z)[4], const u32x4& rsrc, int voff, int soff) {
   asm volatile(
       "s_nop 4\n\t"
       "buffer_load_dword %0, %4, %5, %6 offen\n\t"
-      "buffer_load_dword %1, %4, %5, %6 offen offset:1024\n\t"
-      "buffer_load_dword %2, %4, %5, %6 offen offset:2048\n\t"
-      "buffer_load_dword %3, %4, %5, %6 offen offset:3072"
+      "buffer_load_dword %1, %4, %5, %6 offen offset:512\n\t"
+      "buffer_load_dword %2, %4, %5, %6 offen offset:1024\n\t"
+      "buffer_load_dword %3, %4, %5, %6 offen offset:1536"
       : "=&v"(z[0]), "=&v"(z[1]), "=&v"(z[2]), "=&v"(z[3])
       : "v"(voff), "s"(rsrc), "s"(soff)
       : "memory");
@@ -250,7 +250,7 @@ struct SirenTile {
   __device__ __forceinline__ void epi_fwd(const f32x16& acc) {
     const float* bl = bias_lds + L * 256 + 32 * MM + 4 * half;
     const float magic = 49152.0f;
-    constexpr int so0 = (L * W2_TENSOR_DWORDS + 8 * MM * TL) * 4;  // w2_stash_P(L)
+    constexpr int so0 = (L * W2_TENSOR_DWORDS + 8 * MM * W2_HALF) * 4;  // w2_stash_P(L), quad 8 MM
     float hv[16];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -266,7 +266,7 @@ struct SirenTile {
       phase_byte<1>(pk, t1, magic);
       phase_byte<2>(pk, t2, magic);
       phase_byte<3>(pk, t3, magic);
-      __builtin_amdgcn_raw_buffer_store_b32(pk, rs_tile, voff, so0 + 2 * g * TL * 4, 0);  // quad 8 mm + 2 g (+ half in voff)
+      __builtin_amdgcn_raw_buffer_store_b32(pk, rs_tile, voff, so0 + 2 * g * W2_HALF * 4, 0);  // quad 8 mm + 2 g (+ half in voff)
     }
     hbuf[L & 1][2 * MM] = pack8(hv);
     hbuf[L & 1][2 * MM + 1] = pack8(hv + 8);
@@ -279,7 +279,7 @@ struct SirenTile {
   // uniform sequence; a load nobody reads would have a destination the allocator reuses while it is in flight)
   template <int E>
   __device__ __forceinline__ void bwd_loads() {
-    static_assert(2 * TL * 4 == 1024, "w2_load4_asm's immediates");
+    static_assert(2 * W2_HALF * 4 == 512, "w2_load4_asm's immediates");
     if constexpr (E >= NE) {
       // (assembly: four identical stores through the builtin are one store after dead-store elimination -- and three
       // operations fewer than the waits count)
@@ -293,7 +293,7 @@ struct SirenTile {
           : "memory");
     } else {
       constexpr int lz = D - 2 - (E >> 3), mm = E & 7;
-      w2_load4_asm(pz[E % (PN_PD + 1)], rz_tile, voff, (lz * W2_TENSOR_DWORDS + 8 * mm * TL) * 4);
+      w2_load4_asm(pz[E % (PN_PD + 1)], rz_tile, voff, (lz * W2_TENSOR_DWORDS + 8 * mm * W2_HALF) * 4);
     }
   }
   // dZ = acc * cos(2 pi phase) (the transposed image carries w0): bf8 to the stash, bf16 into the next B operands.
@@ -302,7 +302,7 @@ struct SirenTile {
   __device__ __forceinline__ void epi_bwd(const f32x16& acc) {
     constexpr int lz = D - 2 - (E >> 3), mm = E & 7, set = E % (PN_PD + 1);
     w2_wait4<(E < PN_PD ? 4 * (PN_PD + E) : 8 * PN_PD)>(pz[set]);
-    constexpr int so0 = ((D - 1 + lz) * W2_TENSOR_DWORDS + 8 * mm * TL) * 4;  // w2_stash_G(lz, D)
+    constexpr int so0 = ((D - 1 + lz) * W2_TENSOR_DWORDS + 8 * mm * W2_HALF) * 4;  // w2_stash_G(lz, D), quad 8 mm
     float dz[16];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -316,7 +316,7 @@ struct SirenTile {
       amax = fmaxf(amax, fmaxf(fabsf(dz[4 * g + 2]), fabsf(dz[4 * g + 3])));
       int pk = __builtin_amdgcn_cvt_pk_bf8_f32(dz[4 * g], dz[4 * g + 1], 0, false);
       pk = __builtin_amdgcn_cvt_pk_bf8_f32(dz[4 * g + 2], dz[4 * g + 3], pk, true);
-      __builtin_amdgcn_raw_buffer_store_b32((unsigned)pk, rs_tile, voff, so0 + 2 * g * TL * 4, 0);
+      __builtin_amdgcn_raw_buffer_store_b32((unsigned)pk, rs_tile, voff, so0 + 2 * g * W2_HALF * 4, 0);
     }
     hbuf[(E >> 3) & 1][2 * mm] = pack8(dz);
     hbuf[(E >> 3) & 1][2 * mm + 1] = pack8(dz + 8);
@@ -345,7 +345,8 @@ struct SirenTile {
       valid = tile_ok && crow < a.B;
       sv = reinterpret_cast<unsigned*>(a.save) + (size_t)(tile_ok ? stile : 0) * nd.save_floats_per_tile;
       ts_bytes = (tile_ok && a.save != nullptr) ? w2_stash_dwords(D) * 4 : 0;  // 0: every stash access is a no-op
-      voff = (half * TL + wcol) * 4;  // the lane's byte offset inside a quad pair: quad parity = lane half, own coordinate
+      // the lane's byte offset inside an 8-bit tensor (inr_w2.h): its half tile, quad parity = lane half, own coordinate
+      voff = ((wcol >> 6) * (W2_TENSOR_DWORDS / 2) + half * W2_HALF + (wcol & (W2_HALF - 1))) * 4;
 #ifdef EXP_NOSTASH  // timing experiment: no stash traffic at all (results meaningless)
       ts_bytes = 0;
 #endif

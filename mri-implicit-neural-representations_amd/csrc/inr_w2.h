@@ -45,15 +45,17 @@ INR_HD inline void w2_kperm_inv(int k, int& t, int& h, int& j) {
 INR_HD inline long long w2_index(int p, int f, int lane, int j) { return (((long long)p * 16 + f) * 64 + lane) * 8 + j; }
 
 // ---- stash of one tile of TL = 128 coordinates (dword offsets) --------------------------------------------------
-// Per hidden layer l (0 .. D-2) two 8-bit tensors of [256 rows][128 coordinates] in ROW-QUAD layout: rows 4q .. 4q+3 of
-// coordinate c share the dword at q * 128 + c (a lane of the fused kernel holds rows 8g + 4 half + (0..3) of its
-// coordinate in four consecutive accumulator registers: one dword store per quad, 128 contiguous bytes per half-wave;
-// the GEMM kernel reads 8 consecutive coordinates of a quad and transposes bytes while staging):
+// Per hidden layer l (0 .. D-2) two 8-bit tensors of [256 rows][128 coordinates] in ROW-QUAD layout, one 16 KB block per
+// half tile: rows 4q .. 4q+3 of coordinate c share the dword at (c >> 6) * 4096 + q * 64 + (c & 63) (a lane of the fused
+// kernel holds rows 8g + 4 half + (0..3) of its coordinate in four consecutive accumulator registers: one dword store per
+// quad, 128 contiguous bytes per half-wave; the GEMM kernel's stage of 64 coordinates is one contiguous block -- it reads
+// 8 consecutive coordinates of a quad per thread and transposes bytes while staging):
 //   P_l  phase bytes  round(256 * frac(w0 z_l / 2 pi)):  sin / cos of the layer's pre-activation to 2 pi / 256
 //   G_l  dZ_l as bf8 (e5m2: the high byte of the fp16 of the same value), times the step's power-of-two gradient scale
 // then dZ_last as fp16 row pairs (2 dwords per coordinate) and act'(z_last) as fp32 (4 dwords per coordinate; written by
 // the forward half of a split step for its backward half).
 #define W2_TL 128
+#define W2_HALF 64            // coordinates per half tile = per GEMM stage
 #define W2_TENSOR_DWORDS 8192
 INR_HD inline int w2_stash_P(int l) { return l * W2_TENSOR_DWORDS; }
 INR_HD inline int w2_stash_G(int l, int D) { return (D - 1 + l) * W2_TENSOR_DWORDS; }
