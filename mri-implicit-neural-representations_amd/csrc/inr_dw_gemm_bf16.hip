@@ -41,6 +41,18 @@ constexpr int GB_TILE = 256 * GB_PITCH;   // one operand tile (elements)
 constexpr int GB_STAGE = 2 * GB_TILE;     // A tile + B tile
 constexpr int GB_NT = 512;                // threads: eight waves, two per SIMD (staging of one hides under MFMAs of the other)
 
+#ifdef GB_STAMPS  // timing experiment: per-wave cycle sums of the parts of a stage (tools/gemm_stamps.py)
+__device__ long long gb_stamps[512 * 8 * 8];
+#define GB_T(k)                                                \
+  do {                                                         \
+    const long long now_ = (long long)__builtin_readcyclecounter(); \
+    tsum[k] += now_ - tlast;                                   \
+    tlast = now_;                                              \
+  } while (0)
+#else
+#define GB_T(k) do {} while (0)
+#endif
+
 __device__ __forceinline__ unsigned pk_f16(float a, float b) {
   f32x2 v = {a, b};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
@@ -74,10 +86,9 @@ __device__ __forceinline__ u32x4 bf8_row(const u32x4& a, const u32x4& b) {
 // sum of 8 fp16 (4 dwords) into acc: v_dot2c_f32_f16 against a pair of ones (fp32 accumulate, one instruction per
 // dword).  Inline assembly: through the builtin hipcc 7.2 selected the FIRST dword for all four dot products of an
 // unrolled loop (round 2, bf16 form) -- the row sums came out as 4 x the first coordinate pair.
-__device__ __forceinline__ float sum8(const u32x4& v, float acc) {
-  const unsigned ones = 0x3c003c00u;
+__device__ __forceinline__ float sum8(const u32x4& v, float acc, unsigned ones = 0x3c003c00u) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) asm volatile("v_dot2c_f32_f16 %0, %1, %2" : "+v"(acc) : "v"(v[i]), "v"(ones));
+  for (int i = 0; i < 4; ++i) asm("v_dot2c_f32_f16 %0, %1, %2" : "+v"(acc) : "v"(v[i]), "v"(ones));
   return acc;
 }
 
@@ -88,7 +99,11 @@ __device__ __forceinline__ u32x4 sin_row(const u32x4& a, const u32x4& b) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const unsigned d = i < 4 ? a[i] : b[i - 4];
+#ifdef GB_EXP_NOSIN
+    s[i] = (float)((d >> (8 * R)) & 255u) * 0.00390625f;
+#else
     s[i] = __builtin_amdgcn_sinf((float)((d >> (8 * R)) & 255u) * 0.00390625f);
+#endif
   }
   u32x4 o;
 #pragma unroll
@@ -149,7 +164,13 @@ __device__ __forceinline__ void dwgb_body(const DwGemmBf16Args& a, const DwGemmB
     }
   }
   // loader: the thread's item = row quad t >> 3 (rows 4q .. 4q+3), coordinates 8 (t & 7) .. + 7 of the stage
+#ifdef GB_EXP_QUADSWAP
+  // (16 consecutive lanes hold row quads Q and Q+2: their rows lie 8 x 144 B = 32 banks apart -- with Q and Q+1, 16 banks
+  // apart, the two 128-byte row pieces of a 16-lane group of a ds_write_b128 share 16 banks)
+  const int seg = t & 7, quad = ((t >> 3) & ~3) | (((t >> 3) & 1) << 1) | ((t >> 4) & 1);
+#else
   const int seg = t & 7, quad = t >> 3;
+#endif
   const unsigned* sv = reinterpret_cast<const unsigned*>(a.save);
   const size_t tile_dwords = (size_t)a.save_floats_per_tile;
   // NSETS register sets: while stage s multiplies, the set of stage s+1 -- fetched NSETS stages earlier -- is staged into
@@ -165,6 +186,12 @@ __device__ __forceinline__ void dwgb_body(const DwGemmBf16Args& a, const DwGemmB
   const int voffB = ((it.n0 / 4 + quad) * W2_HALF + 8 * seg) * 4;
   const int voffL = 8 * seg * 4;  // LASTROWS: row pair p at p * TL dwords (fp16 pairs, whole-tile rows)
   auto fetch = [&](int s, u32x4 (&A)[LASTROWS ? 4 : 2], u32x4 (&B)[2]) {
+#ifdef GB_EXP_NOLOAD  // timing experiment: no global loads (the sets keep whatever they hold)
+    if (s > 2) {
+      asm volatile("" : "+v"(A[0][0]), "+v"(A[1][0]), "+v"(B[0][0]), "+v"(B[1][0]));
+      return;
+    }
+#endif
     if (s >= n_steps) s = n_steps - 1;  // past the end: the last stage again (loaded, never multiplied)
     const int tile = t0 + s / KS_PER_TILE, c0 = (s % KS_PER_TILE) * GB_KS;
     const unsigned long long ba = reinterpret_cast<unsigned long long>(sv + (size_t)tile * tile_dwords);
@@ -209,6 +236,10 @@ __device__ __forceinline__ void dwgb_body(const DwGemmBf16Args& a, const DwGemmB
   auto stage_a = [&](int s, bool count, const u32x4 (&A)[LASTROWS ? 4 : 2]) {
     _Float16* st = lds + (size_t)(s & 1) * GB_STAGE + (4 * quad) * GB_PITCH + 8 * seg;
     u32x4 row[4];
+#ifdef GB_EXP_INTERLEAVE
+    unsigned ones = count ? 0x3c003c00u : 0u;  // (branch-free row sums: one scheduling region per stage)
+    asm volatile("" : "+v"(ones));
+#endif
 #ifdef GB_EXP_NOSTAGEVALU
     if (!LASTROWS) {
       row[0] = A[0], row[1] = A[1], row[2] = A[0], row[3] = A[1];
@@ -226,8 +257,16 @@ __device__ __forceinline__ void dwgb_body(const DwGemmBf16Args& a, const DwGemmB
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
+#ifdef GB_EXP_NOLDSWRITE
+      asm volatile("" ::"v"(row[r][0]), "v"(row[r][1]), "v"(row[r][2]), "v"(row[r][3]));
+#else
       *reinterpret_cast<u32x4*>(st + r * GB_PITCH) = row[r];
+#endif
+#ifdef GB_EXP_INTERLEAVE
+      if (BIAS) bsum[r] = sum8(row[r], bsum[r], ones);
+#else
       if (BIAS && count) bsum[r] = sum8(row[r], bsum[r]);
+#endif
     }
   };
   // ... and of the B item: rows through the sine (or the encoder)
@@ -251,7 +290,13 @@ __device__ __forceinline__ void dwgb_body(const DwGemmBf16Args& a, const DwGemmB
       row[3] = sin_row<3>(B[0], B[1]);
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) *reinterpret_cast<u32x4*>(st + r * GB_PITCH) = row[r];
+    for (int r = 0; r < 4; ++r) {
+#ifdef GB_EXP_NOLDSWRITE
+      asm volatile("" ::"v"(row[r][0]), "v"(row[r][1]), "v"(row[r][2]), "v"(row[r][3]));
+#else
+      *reinterpret_cast<u32x4*>(st + r * GB_PITCH) = row[r];
+#endif
+    }
   };
   const _Float16* As = lds + (wm * 64 + li) * GB_PITCH + 8 * half;
   const _Float16* Bs = lds + GB_TILE + (wn * 128 + li) * GB_PITCH + 8 * half;
@@ -261,15 +306,57 @@ __device__ __forceinline__ void dwgb_body(const DwGemmBf16Args& a, const DwGemmB
   // they take the two halves in opposite order: waves 0-3 multiply first and stage behind it, waves 4-7 stage first.  (The
   // refill stays behind both for every wave: issued right behind the staging of the stage-first waves it measured 14 %
   // slower -- their loads then compete with the other waves' at the head of every stage.)
+#ifdef GB_EXP_NOSTAGGER
+  const bool stage_first = false;
+#else
   const bool stage_first = w >= 4;
+#endif
+#if defined(GB_EXP_PRIO) && GB_EXP_PRIO == 1
+  if (w >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
+#ifdef GB_STAMPS
+  long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = (long long)__builtin_readcyclecounter();
+#endif
   auto compute = [&](int s, u32x4 (&NA)[LASTROWS ? 4 : 2], u32x4 (&NB)[2]) {
     const bool more = s + 1 < n_steps;
     const _Float16* Ab = As + (size_t)(s & 1) * GB_STAGE;
     const _Float16* Bb = Bs + (size_t)(s & 1) * GB_STAGE;
+#ifdef GB_EXP_INTERLEAVE
+    // one scheduling region: the stage's 32 MFMAs with the next stage's staging spread between them
+    stage_a(s + 1, more, NA);
+    stage_b(s + 1, NB);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f16x8 A[2], B[4];
+#pragma unroll
+      for (int i = 0; i < (LASTROWS ? 1 : 2); ++i) A[i] = *reinterpret_cast<const f16x8*>(Ab + i * 32 * GB_PITCH + 16 * q);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) B[j] = *reinterpret_cast<const f16x8*>(Bb + j * 32 * GB_PITCH + 16 * q);
+#pragma unroll
+      for (int i = 0; i < (LASTROWS ? 1 : 2); ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[i], B[j], acc[i][j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);  // 6 VALU
+      if (i < 24) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 LDS read
+      if ((i & 3) == 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // 1 LDS write
+    }
+#else
+    GB_T(0);
     if (stage_first) {
+#if defined(GB_EXP_PRIO) && GB_EXP_PRIO == 2
+      __builtin_amdgcn_s_setprio(1);
+#endif
       stage_a(s + 1, more, NA);
       stage_b(s + 1, NB);
+#if defined(GB_EXP_PRIO) && GB_EXP_PRIO == 2
+      __builtin_amdgcn_s_setprio(0);
+#endif
       __builtin_amdgcn_sched_barrier(0);
+      GB_T(1);
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {  // four K = 16 sub-steps of the stage's 64 coordinates
@@ -288,12 +375,22 @@ __device__ __forceinline__ void dwgb_body(const DwGemmBf16Args& a, const DwGemmB
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[i], B[j], acc[i][j], 0, 0, 0);
 #endif
     }
+    GB_T(2);
     if (!stage_first) {
       __builtin_amdgcn_sched_barrier(0);
+#if defined(GB_EXP_PRIO) && GB_EXP_PRIO == 2
+      __builtin_amdgcn_s_setprio(1);
+#endif
       stage_a(s + 1, more, NA);
       stage_b(s + 1, NB);
+#if defined(GB_EXP_PRIO) && GB_EXP_PRIO == 2
+      __builtin_amdgcn_s_setprio(0);
+#endif
+      GB_T(1);
     }
+#endif
     fetch(s + 1 + NSETS, NA, NB);
+    GB_T(3);
   };
 
   float xs_next = 0.f;
@@ -317,6 +414,7 @@ __device__ __forceinline__ void dwgb_body(const DwGemmBf16Args& a, const DwGemmB
     xs_put(k + 2, xs_next);  // xs buffer k & 1: last read while stage k was staged, one barrier ago
     xs_next = xs_get(k + 3);
     __syncthreads();
+    GB_T(4);
   };
   if (NSETS == 2) {
 #pragma unroll 1
@@ -334,6 +432,9 @@ __device__ __forceinline__ void dwgb_body(const DwGemmBf16Args& a, const DwGemmB
       step(s + 2, ra[0], rb[0]);
     }
   }
+#ifdef GB_STAMPS
+  GB_T(0);
+#endif
   // ---- chunk slab: dW rows follow the MFMA C layout (register r of lane (li, half): row (r&3)+8(r>>2)+4 half, col li);
   // the gradient scale comes off here
   const float unscale = a.dz_state != nullptr ? 1.0f / a.dz_state[2] : 1.0f;
@@ -364,6 +465,16 @@ __device__ __forceinline__ void dwgb_body(const DwGemmBf16Args& a, const DwGemmB
       if (seg == 0 && row < it.M) slab[it.gb_off + row] = v * unscale;
     }
   }
+#ifdef GB_STAMPS
+  __builtin_amdgcn_s_waitcnt(0);
+  GB_T(5);
+  if (lane == 0 && blockIdx.x < 512) {
+    unsigned id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(id));
+    tsum[6] = id, tsum[7] = n_steps;
+    for (int k = 0; k < 8; ++k) gb_stamps[(blockIdx.x * 8 + w) * 8 + k] = tsum[k];
+  }
+#endif
 }
 
 template <int TL>
@@ -394,6 +505,12 @@ hipError_t launch_dz_roll(float* st, hipStream_t stream) {
   hipLaunchKernelGGL(dz_roll_kernel, dim3(1), dim3(1), 0, stream, st);
   return hipGetLastError();
 }
+
+#ifdef GB_STAMPS
+extern "C" int inr_debug_gemm_stamps(long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(gb_stamps), sizeof(long long) * 512 * 8 * 8);
+}
+#endif
 
 hipError_t launch_dw_gemm_bf16(const DwGemmBf16Args& a, hipStream_t st) {
   if (a.n_units <= 0 || a.n_units > INR_DWGB_MAX_UNITS || a.n_chunks <= 0 || a.tiles_per_chunk <= 0 || a.TL != 128 ||
