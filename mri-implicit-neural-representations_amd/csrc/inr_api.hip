@@ -555,7 +555,7 @@ static void dw_gemm_bf16_setup(const inr_plan* plan, int64_t nt, inr::DwGemmBf16
   memset(g, 0, sizeof(*g));
   const int D = nd.D;
   int k = 0;
-  for (int n0 = 0; n0 < nd.L[0].K; n0 += 256) {  // first layer: B = encoder features, 2E columns
+  for (int n0 = 0; n0 < nd.E; n0 += 128) {  // first layer: B = encoder features, 128 frequencies (sine + cosine) a unit
     inr::DwGemmBf16Unit& u = g->unit[k++];
     u.dz_off = w2_stash_G(0, D), u.z_off = -1;
     u.gw_off = nd.L[0].gw_off, u.gb_off = nd.L[0].gb_off, u.M = 256, u.K = nd.L[0].K, u.n0 = n0;

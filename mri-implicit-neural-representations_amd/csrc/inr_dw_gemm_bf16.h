@@ -14,7 +14,8 @@ struct DwGemmBf16Unit {
   int gw_off, gb_off;  // slab offsets (floats) of dW [M x K] and db [M]
   int M;               // rows of dW stored (256 for the hidden layers' padded slabs, out_features for the last layer)
   int K;               // columns of dW
-  int n0;              // first column of this block
+  int n0;              // first column of this block; first-layer units: first of its 128 encoder frequencies (the block
+                       // holds their sine AND cosine columns, n0 + j and E + n0 + j)
 };
 
 struct DwGemmBf16Args {

@@ -70,19 +70,6 @@ __device__ __forceinline__ void split_rows(const u32x4& a, const u32x4& b, u32x4
   odd[3] = __builtin_amdgcn_perm(b[3], b[2], 0x07060302u);
 }
 
-// 8 dwords (coordinates c .. c+7, byte R of each = row 4q + R as bf8) -> row R as 8 fp16: byte R of coordinates (2i, 2i+1)
-// into the HIGH bytes of the two halves of dword i, zeros below (selector 0x0c)
-template <int R>
-__device__ __forceinline__ u32x4 bf8_row(const u32x4& a, const u32x4& b) {
-  constexpr unsigned sel = ((4u + R) << 24) | (0x0cu << 16) | ((unsigned)R << 8) | 0x0cu;
-  u32x4 o;
-  o[0] = __builtin_amdgcn_perm(a[1], a[0], sel);
-  o[1] = __builtin_amdgcn_perm(a[3], a[2], sel);
-  o[2] = __builtin_amdgcn_perm(b[1], b[0], sel);
-  o[3] = __builtin_amdgcn_perm(b[3], b[2], sel);
-  return o;
-}
-
 // sum of 8 fp16 (4 dwords) into acc: v_dot2c_f32_f16 against a pair of ones (fp32 accumulate, one instruction per
 // dword).  Inline assembly: through the builtin hipcc 7.2 selected the FIRST dword for all four dot products of an
 // unrolled loop (round 2, bf16 form) -- the row sums came out as 4 x the first coordinate pair.
@@ -92,48 +79,56 @@ __device__ __forceinline__ float sum8(const u32x4& v, float acc, unsigned ones =
   return acc;
 }
 
-// 8 dwords (byte R of each = phase of row 4q + R at coordinates c .. c+7) -> sin(2 pi phase / 256) of that row as 8 fp16
-template <int R>
-__device__ __forceinline__ u32x4 sin_row(const u32x4& a, const u32x4& b) {
-  float s[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const unsigned d = i < 4 ? a[i] : b[i - 4];
-#ifdef GB_EXP_NOSIN
-    s[i] = (float)((d >> (8 * R)) & 255u) * 0.00390625f;
-#else
-    s[i] = __builtin_amdgcn_sinf((float)((d >> (8 * R)) & 255u) * 0.00390625f);
-#endif
-  }
-  u32x4 o;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) o[i] = pk_f16(s[2 * i], s[2 * i + 1]);
-  return o;
+__device__ __forceinline__ float dot2c(float acc, unsigned v, unsigned ones) {
+  asm volatile("v_dot2c_f32_f16 %0, %1, %2" : "+v"(acc) : "v"(v), "v"(ones));
+  return acc;
 }
 
-// feature `row` (< E: sine, >= E: cosine of the same phase) of 8 consecutive coordinates whose (x0,x1,x2) sit in xs
-__device__ __forceinline__ u32x4 gauss_features(const float* xs, const float* encB, int E, int row) {
-  int s = row < E ? row : row - E;
-  s = s < E ? s : E - 1;  // rows past 2E (column blocks wider than the layer) are computed and never stored
-  const float quarter = row < E ? 0.f : 0.25f;
-  const float b0 = encB[3 * s + 0], b1 = encB[3 * s + 1], b2 = encB[3 * s + 2];
-  float f[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j)
-    f[j] = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(fmaf(xs[3 * j + 2], b2, fmaf(xs[3 * j + 1], b1, fmaf(xs[3 * j], b0, quarter)))));
-  u32x4 o;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) o[i] = pk_f16(f[2 * i], f[2 * i + 1]);
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>)
+template <int I>
+struct gb_ic {
+  static constexpr int value = I;
+};
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void gb_for(F&& f) {
+  if constexpr (I < N) {
+    f(gb_ic<I>{});
+    gb_for<N, I + 1>(f);
+  }
+}
+
+// phase bytes R of two dwords (coordinates 2p, 2p+1 of row 4q + R) -> the fp16 pair of their sines.  In [4, 8) an fp16 ulp
+// is 1/256: the bits 0x4400 | p ARE the value 4 + p / 256, and v_sin_f16 (argument in revolutions) of that is
+// sin(2 pi p / 256), correctly rounded for all 256 phases (tools/probes/sinf16_probe.hip) -- no conversion, no multiply.
+template <int R>
+__device__ __forceinline__ unsigned sin_pair(unsigned lo, unsigned hi) {
+  constexpr unsigned sel = (0x0cu << 24) | ((4u + R) << 16) | (0x0cu << 8) | (unsigned)R;
+  const unsigned x = __builtin_amdgcn_perm(hi, lo, sel) | 0x44004400u;
+  unsigned o;
+  asm volatile("v_sin_f16_sdwa %0, %1 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(o) : "v"(x));
+  asm volatile("v_sin_f16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1" : "+v"(o) : "v"(x));
   return o;
+}
+// encoder phase x . B_j (revolutions, reduced to [0, 1)) of one coordinate: the forward pass's fma chain
+__device__ __forceinline__ float gauss_phase(const float* x, float b0, float b1, float b2) {
+  return __builtin_amdgcn_fractf(fmaf(x[2], b2, fmaf(x[1], b1, fmaf(x[0], b0, 0.f))));
 }
 
 // ENC: B = encoder features (first layer); BIAS: this column block also produces db; LASTROWS: dZ has only its first
-// four rows (the out_features <= 4 rows of the last layer, fp16 row pairs): the rest of the A tile stays zero
-// NSETS: register sets of fetched operands -- a stage's operands are requested NSETS stages before they are staged.  The
-// hidden-layer units afford a third set (128 accumulator registers + 3 x 16); the first-layer units, which also hold
-// encoder arithmetic, keep two.  (Inlined: as real functions the variants would take their arguments through memory --
-// flat loads, whose waits are vmcnt(0) and drain the prefetch -- and buffer descriptors from memory cost waterfall loops.)
-template <int TL, bool ENC, bool BIAS, bool LASTROWS, int NSETS>
+// four rows (the out_features <= 4 rows of the last layer, fp16 row pairs): the rest of the A tile stays zero.
+//
+// The stage loop is ONE instruction stream per wave, the same for all eight: stage s multiplies out of LDS stage s & 1
+// while the operands of stage s+1 -- fetched two stages earlier into one of two register sets -- are converted and stored
+// into the other LDS stage; one barrier per stage.  The stream is cut into 32 slots of one MFMA + its share of everything
+// else (a fragment read for the next K = 16 group, a slice of the staging arithmetic: ~14 cycles of vector issue against
+// the MFMA's 32 on the pipe), fenced so that the compiler keeps the interleaving.  Why not "one wave of a SIMD stages
+// while the other multiplies" (rounds 2-3a): measured, the staging wave made no progress beside the multiplying one --
+// the launch took the SUM of its matrix, vector and LDS-store times (profiles/r03_dw_gemm_knockouts.txt).
+// Rotation: the last K = 16 group of a stage is multiplied after the barrier, from fragments read before it, under the
+// first fragment reads of the next stage -- no exposed LDS latency at the head of a stage.
+// (Inlined: as real functions the variants would take their arguments through memory -- flat loads, whose waits are
+// vmcnt(0) and drain the prefetch -- and buffer descriptors from memory cost waterfall loops.)
+template <int TL, bool ENC, bool BIAS, bool LASTROWS>
 __device__ __forceinline__ void dwgb_body(const DwGemmBf16Args& a, const DwGemmBf16Unit& it, int kc, char* lds_raw) {
   _Float16* lds = reinterpret_cast<_Float16*>(lds_raw);
   float* xs_lds = reinterpret_cast<float*>(lds_raw + (size_t)2 * GB_STAGE * 2);  // [2 stages][64 coords][3]
@@ -142,10 +137,12 @@ __device__ __forceinline__ void dwgb_body(const DwGemmBf16Args& a, const DwGemmB
   const int half = lane >> 5, li = lane & 31;
   const int wm = w >> 1, wn = w & 1;  // wave tile: rows [64 wm, +64) x columns [128 wn, +128) = 2 x 4 MFMA blocks
   constexpr int KS_PER_TILE = TL / GB_KS;
+  constexpr int NI = LASTROWS ? 1 : 2;   // row blocks of the wave tile that hold anything
+  constexpr int NA = LASTROWS ? 4 : 2;   // 16-byte loads of an A item
   const int t0 = kc * a.tiles_per_chunk;
   int n_mine = a.n_tiles - t0;
   if (n_mine > a.tiles_per_chunk) n_mine = a.tiles_per_chunk;
-  const int n_steps = (n_mine > 0 ? n_mine : 0) * KS_PER_TILE;
+  const int n_steps = (n_mine > 0 ? n_mine : 0) * KS_PER_TILE;  // even: two stages per tile
 
   f32x16 acc[2][4];
 #pragma unroll
@@ -164,19 +161,10 @@ __device__ __forceinline__ void dwgb_body(const DwGemmBf16Args& a, const DwGemmB
     }
   }
   // loader: the thread's item = row quad t >> 3 (rows 4q .. 4q+3), coordinates 8 (t & 7) .. + 7 of the stage
-#ifdef GB_EXP_QUADSWAP
-  // (16 consecutive lanes hold row quads Q and Q+2: their rows lie 8 x 144 B = 32 banks apart -- with Q and Q+1, 16 banks
-  // apart, the two 128-byte row pieces of a 16-lane group of a ds_write_b128 share 16 banks)
-  const int seg = t & 7, quad = ((t >> 3) & ~3) | (((t >> 3) & 1) << 1) | ((t >> 4) & 1);
-#else
   const int seg = t & 7, quad = t >> 3;
-#endif
   const unsigned* sv = reinterpret_cast<const unsigned*>(a.save);
   const size_t tile_dwords = (size_t)a.save_floats_per_tile;
-  // NSETS register sets: while stage s multiplies, the set of stage s+1 -- fetched NSETS stages earlier -- is staged into
-  // LDS and then refilled with stage s+1+NSETS (global latency is several microseconds under load, a stage 1.5-3: with two
-  // sets the launch ran at the pace of its loads -- a loads -> LDS -> barrier skeleton took three quarters of its time)
-  u32x4 ra[NSETS][LASTROWS ? 4 : 2], rb[NSETS][2];
+  u32x4 ra[2][NA], rb[2][2];  // two register sets of fetched operands
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
 
   // (through a buffer descriptor on the tile's wave-uniform base: the thread's part of an address is the byte offset of its
@@ -185,13 +173,7 @@ __device__ __forceinline__ void dwgb_body(const DwGemmBf16Args& a, const DwGemmB
   const int voffA = (quad * W2_HALF + 8 * seg) * 4;
   const int voffB = ((it.n0 / 4 + quad) * W2_HALF + 8 * seg) * 4;
   const int voffL = 8 * seg * 4;  // LASTROWS: row pair p at p * TL dwords (fp16 pairs, whole-tile rows)
-  auto fetch = [&](int s, u32x4 (&A)[LASTROWS ? 4 : 2], u32x4 (&B)[2]) {
-#ifdef GB_EXP_NOLOAD  // timing experiment: no global loads (the sets keep whatever they hold)
-    if (s > 2) {
-      asm volatile("" : "+v"(A[0][0]), "+v"(A[1][0]), "+v"(B[0][0]), "+v"(B[1][0]));
-      return;
-    }
-#endif
+  auto fetch = [&](int s, u32x4 (&A)[NA], u32x4 (&B)[2]) {
     if (s >= n_steps) s = n_steps - 1;  // past the end: the last stage again (loaded, never multiplied)
     const int tile = t0 + s / KS_PER_TILE, c0 = (s % KS_PER_TILE) * GB_KS;
     const unsigned long long ba = reinterpret_cast<unsigned long long>(sv + (size_t)tile * tile_dwords);
@@ -201,7 +183,7 @@ __device__ __forceinline__ void dwgb_body(const DwGemmBf16Args& a, const DwGemmB
     // the stage's half-tile block of the 8-bit tensors; dZ_last (fp16 row pairs): its 64 coordinates of the tile's rows
     const int blk = (s % KS_PER_TILE) * (W2_TENSOR_DWORDS / 2);
     const int soA = (it.dz_off + (LASTROWS ? c0 : blk)) * 4, soB = (it.z_off + blk) * 4;
-    if (LASTROWS) {
+    if constexpr (LASTROWS) {
       if (quad == 0) {
         A[0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voffL, soA, 0));
         A[1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voffL, soA + 16, 0));
@@ -232,219 +214,158 @@ __device__ __forceinline__ void dwgb_body(const DwGemmBf16Args& a, const DwGemmB
   auto xs_put = [&](int s, float v) {
     if (ENC && t < GB_KS * 3) xs_lds[(s & 1) * GB_KS * 3 + t] = v;
   };
-  // staging of the A item of stage s: rows as fp16 (and into the row sums, once: `count`)
-  auto stage_a = [&](int s, bool count, const u32x4 (&A)[LASTROWS ? 4 : 2]) {
-    _Float16* st = lds + (size_t)(s & 1) * GB_STAGE + (4 * quad) * GB_PITCH + 8 * seg;
-    u32x4 row[4];
-#ifdef GB_EXP_INTERLEAVE
-    unsigned ones = count ? 0x3c003c00u : 0u;  // (branch-free row sums: one scheduling region per stage)
-    asm volatile("" : "+v"(ones));
-#endif
-#ifdef GB_EXP_NOSTAGEVALU
-    if (!LASTROWS) {
-      row[0] = A[0], row[1] = A[1], row[2] = A[0], row[3] = A[1];
-    } else
-#endif
-    if (LASTROWS) {
-      if (quad != 0) return;
-      split_rows(A[0], A[1], row[0], row[1]);
-      split_rows(A[2], A[3], row[2], row[3]);
-    } else {
-      row[0] = bf8_row<0>(A[0], A[1]);
-      row[1] = bf8_row<1>(A[0], A[1]);
-      row[2] = bf8_row<2>(A[0], A[1]);
-      row[3] = bf8_row<3>(A[0], A[1]);
-    }
+
+  // ---- the staging of one stage, in 32 slices (slice k runs in slot k of the stage before) ---------------------------
+  // even k: pair (k/2) % 4 of B row k / 8 (coordinates 2p, 2p+1), the row stored after its fourth pair;
+  // odd k : piece (k/2) % 4 of A row k / 8: two byte permutes, two more + the store, then the row sum in two halves.
+  // Sums of a stage past the end (loaded, never multiplied) are kept out with a zero "ones" vector: no branch in a stage.
+  u32x4 rowA = {0u, 0u, 0u, 0u}, rowB = {0u, 0u, 0u, 0u}, rowC = {0u, 0u, 0u, 0u};
+  float eb0 = 0.f, eb1 = 0.f, eb2 = 0.f, eph0 = 0.f, eph1 = 0.f;
+  auto slice = [&](auto K, int s, unsigned ones, const u32x4 (&A)[NA], const u32x4 (&B)[2]) {
+    constexpr int k = decltype(K)::value, R = k / 8, pc = (k / 2) % 4;
+    _Float16* sa = lds + (size_t)(s & 1) * GB_STAGE + (4 * quad) * GB_PITCH + 8 * seg;
+    _Float16* sb = sa + GB_TILE;
+    if constexpr (k % 2 == 0) {
+      if constexpr (ENC) {
+        // first-layer units: the thread's four rows are the sine (rows 0, 1) and cosine (rows 2, 3) features of encoder
+        // frequencies n0 + 2 quad + (0, 1) -- one phase chain serves a sine and a cosine (v_cos_f32 of the sine's phase;
+        // the forward pass starts the cosine's chain at 1/4 turn instead: the same value to an ulp of the phase).
+        // Even slot e = k / 2: frequency f = e / 8, coordinate pair (e / 2) % 4; first the two phases, next slot the four
+        // features; a frequency's two rows are stored after its fourth pair.
+        constexpr int e = k / 2, f = e / 8, cp = (e / 2) % 4;
+        if constexpr (e % 2 == 0) {
+          const float* xs = xs_lds + (s & 1) * GB_KS * 3 + 24 * seg + 6 * cp;
+          if constexpr (cp == 0) {
+            int j = it.n0 + 2 * quad + f;
+            j = j < a.E ? j : a.E - 1;  // frequencies past E (enc_size not a multiple of 128) are computed and never stored
+            eb0 = encB_lds[3 * j + 0], eb1 = encB_lds[3 * j + 1], eb2 = encB_lds[3 * j + 2];
+          }
+          eph0 = gauss_phase(xs, eb0, eb1, eb2), eph1 = gauss_phase(xs + 3, eb0, eb1, eb2);
+        } else {
+          rowB[cp] = pk_f16(__builtin_amdgcn_sinf(eph0), __builtin_amdgcn_sinf(eph1));
+          rowC[cp] = pk_f16(__builtin_amdgcn_cosf(eph0), __builtin_amdgcn_cosf(eph1));
+          if constexpr (cp == 3) {
+            *reinterpret_cast<u32x4*>(sb + f * GB_PITCH) = rowB;
+            *reinterpret_cast<u32x4*>(sb + (2 + f) * GB_PITCH) = rowC;
+          }
+        }
+      } else {
+        rowB[pc] = sin_pair<R>(B[pc >> 1][2 * (pc & 1)], B[pc >> 1][2 * (pc & 1) + 1]);
+        if constexpr (pc == 3) *reinterpret_cast<u32x4*>(sb + R * GB_PITCH) = rowB;
+      }
+    } else if constexpr (LASTROWS) {
+      if constexpr (k == 1) {  // the four rows of dZ_last: row quad 0's threads only
+        if (quad == 0) {
+          u32x4 row[4];
+          split_rows(A[0], A[1], row[0], row[1]);
+          split_rows(A[2], A[3], row[2], row[3]);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-#ifdef GB_EXP_NOLDSWRITE
-      asm volatile("" ::"v"(row[r][0]), "v"(row[r][1]), "v"(row[r][2]), "v"(row[r][3]));
-#else
-      *reinterpret_cast<u32x4*>(st + r * GB_PITCH) = row[r];
-#endif
-#ifdef GB_EXP_INTERLEAVE
-      if (BIAS) bsum[r] = sum8(row[r], bsum[r], ones);
-#else
-      if (BIAS && count) bsum[r] = sum8(row[r], bsum[r]);
-#endif
+          for (int r = 0; r < 4; ++r) {
+            *reinterpret_cast<u32x4*>(sa + r * GB_PITCH) = row[r];
+            bsum[r] = sum8(row[r], bsum[r], ones);
+          }
+        }
+      }
+    } else {
+      constexpr unsigned sel = ((4u + R) << 24) | (0x0cu << 16) | ((unsigned)R << 8) | 0x0cu;  // bf8 byte -> fp16 high byte
+      if constexpr (pc == 0) {
+        rowA[0] = __builtin_amdgcn_perm(A[0][1], A[0][0], sel);
+        rowA[1] = __builtin_amdgcn_perm(A[0][3], A[0][2], sel);
+      } else if constexpr (pc == 1) {
+        rowA[2] = __builtin_amdgcn_perm(A[1][1], A[1][0], sel);
+        rowA[3] = __builtin_amdgcn_perm(A[1][3], A[1][2], sel);
+        *reinterpret_cast<u32x4*>(sa + R * GB_PITCH) = rowA;
+      } else if constexpr (BIAS) {
+        constexpr int h = 2 * (pc - 2);
+        bsum[R] = dot2c(dot2c(bsum[R], rowA[h], ones), rowA[h + 1], ones);
+      }
     }
   };
-  // ... and of the B item: rows through the sine (or the encoder)
-  auto stage_b = [&](int s, const u32x4 (&B)[2]) {
-    _Float16* st = lds + (size_t)(s & 1) * GB_STAGE + GB_TILE + (4 * quad) * GB_PITCH + 8 * seg;
-    u32x4 row[4];
-#ifdef GB_EXP_NOSTAGEVALU
-    if (true) {
-      row[0] = B[0], row[1] = B[1], row[2] = B[0], row[3] = B[1];
-      if (ENC) row[0] = row[1] = row[2] = row[3] = u32x4{1u, 2u, 3u, (unsigned)seg};
-    } else
-#endif
-    if (ENC) {
-      const float* xs = xs_lds + (s & 1) * GB_KS * 3 + 24 * seg;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) row[r] = gauss_features(xs, encB_lds, a.E, it.n0 + 4 * quad + r);
-    } else {
-      row[0] = sin_row<0>(B[0], B[1]);
-      row[1] = sin_row<1>(B[0], B[1]);
-      row[2] = sin_row<2>(B[0], B[1]);
-      row[3] = sin_row<3>(B[0], B[1]);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-#ifdef GB_EXP_NOLDSWRITE
-      asm volatile("" ::"v"(row[r][0]), "v"(row[r][1]), "v"(row[r][2]), "v"(row[r][3]));
-#else
-      *reinterpret_cast<u32x4*>(st + r * GB_PITCH) = row[r];
-#endif
-    }
-  };
+
   const _Float16* As = lds + (wm * 64 + li) * GB_PITCH + 8 * half;
   const _Float16* Bs = lds + GB_TILE + (wn * 128 + li) * GB_PITCH + 8 * half;
-  // stage s multiplies out of LDS stage s & 1 while register set `N` (stage s+1) is staged into the other one and then
-  // refilled with stage s+3.  The two waves of a SIMD (w, w + 4) run the same program between the same barriers; left in
-  // lockstep both stage at the same time -- ~150 vector instructions, the matrix pipe idle -- and then both multiply.  So
-  // they take the two halves in opposite order: waves 0-3 multiply first and stage behind it, waves 4-7 stage first.  (The
-  // refill stays behind both for every wave: issued right behind the staging of the stage-first waves it measured 14 %
-  // slower -- their loads then compete with the other waves' at the head of every stage.)
-#ifdef GB_EXP_NOSTAGGER
-  const bool stage_first = false;
-#else
-  const bool stage_first = w >= 4;
-#endif
-#if defined(GB_EXP_PRIO) && GB_EXP_PRIO == 1
-  if (w >= 4) __builtin_amdgcn_s_setprio(1);
-#endif
-#ifdef GB_STAMPS
-  long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = (long long)__builtin_readcyclecounter();
-#endif
-  auto compute = [&](int s, u32x4 (&NA)[LASTROWS ? 4 : 2], u32x4 (&NB)[2]) {
-    const bool more = s + 1 < n_steps;
+  f16x8 fa[2][NI], fb[2][4];  // MFMA fragments of two K = 16 groups
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) fa[b][i][e] = (_Float16)0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) fb[b][j][e] = (_Float16)0.f;
+  }
+  // one MFMA of K = 16 group g (fragment buffer (g + 1) & 1); m = its place among the group's 8 slots
+  auto mma = [&](auto G, auto Mi) {
+    constexpr int g = decltype(G)::value, m = decltype(Mi)::value, cb = (g + 1) & 1;
+    if constexpr (NI == 2) {
+      constexpr int i = m / 4, j = m % 4;
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cb][i], fb[cb][j], acc[i][j], 0, 0, 0);
+    } else if constexpr (m % 2 == 0) {
+      acc[0][m / 2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cb][0], fb[cb][m / 2], acc[0][m / 2], 0, 0, 0);
+    }
+  };
+  // Stage s: slot k = 8 g + m.  Group 0 multiplies the last K = 16 group of stage s-1 (fragment buffer 1: zeros before
+  // stage 0), groups 1 .. 3 the groups 0 .. 2 of stage s; group g's first slots read the fragments of (s, group g) into
+  // buffer g & 1.  Slice k of the staging of stage s+1 (register set NA / NB) rides along; then the set is refilled.
+  auto stage = [&](int s, u32x4 (&SA)[NA], u32x4 (&SB)[2]) {
     const _Float16* Ab = As + (size_t)(s & 1) * GB_STAGE;
     const _Float16* Bb = Bs + (size_t)(s & 1) * GB_STAGE;
-#ifdef GB_EXP_INTERLEAVE
-    // one scheduling region: the stage's 32 MFMAs with the next stage's staging spread between them
-    stage_a(s + 1, more, NA);
-    stage_b(s + 1, NB);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      f16x8 A[2], B[4];
-#pragma unroll
-      for (int i = 0; i < (LASTROWS ? 1 : 2); ++i) A[i] = *reinterpret_cast<const f16x8*>(Ab + i * 32 * GB_PITCH + 16 * q);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) B[j] = *reinterpret_cast<const f16x8*>(Bb + j * 32 * GB_PITCH + 16 * q);
-#pragma unroll
-      for (int i = 0; i < (LASTROWS ? 1 : 2); ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[i], B[j], acc[i][j], 0, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < 32; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
-      __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);  // 6 VALU
-      if (i < 24) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 LDS read
-      if ((i & 3) == 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // 1 LDS write
-    }
-#else
-    GB_T(0);
-    if (stage_first) {
-#if defined(GB_EXP_PRIO) && GB_EXP_PRIO == 2
-      __builtin_amdgcn_s_setprio(1);
-#endif
-      stage_a(s + 1, more, NA);
-      stage_b(s + 1, NB);
-#if defined(GB_EXP_PRIO) && GB_EXP_PRIO == 2
-      __builtin_amdgcn_s_setprio(0);
-#endif
+    unsigned ones = s + 1 < n_steps ? 0x3c003c00u : 0u;
+    asm volatile("" : "+v"(ones));  // (opaque: a select folded into the sums' asm operands becomes a branch)
+    gb_for<32>([&](auto K) {
+      constexpr int k = decltype(K)::value, g = k / 8, m = k % 8, rbuf = g & 1;
+      if constexpr (m < NI)
+        fa[rbuf][m] = *reinterpret_cast<const f16x8*>(Ab + m * 32 * GB_PITCH + 16 * g);
+      else if constexpr (m < NI + 4)
+        fb[rbuf][m - NI] = *reinterpret_cast<const f16x8*>(Bb + (m - NI) * 32 * GB_PITCH + 16 * g);
+      mma(gb_ic<g>{}, gb_ic<m>{});
+      slice(K, s + 1, ones, SA, SB);
       __builtin_amdgcn_sched_barrier(0);
-      GB_T(1);
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {  // four K = 16 sub-steps of the stage's 64 coordinates
-      f16x8 A[2], B[4];
-#pragma unroll
-      for (int i = 0; i < (LASTROWS ? 1 : 2); ++i) A[i] = *reinterpret_cast<const f16x8*>(Ab + i * 32 * GB_PITCH + 16 * q);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) B[j] = *reinterpret_cast<const f16x8*>(Bb + j * 32 * GB_PITCH + 16 * q);
-#pragma unroll
-      for (int i = 0; i < (LASTROWS ? 1 : 2); ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#ifdef GB_EXP_NOMFMA
-          acc[i][j][q] += (float)A[i][0] + (float)B[j][0];
-#else
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[i], B[j], acc[i][j], 0, 0, 0);
-#endif
-    }
-    GB_T(2);
-    if (!stage_first) {
-      __builtin_amdgcn_sched_barrier(0);
-#if defined(GB_EXP_PRIO) && GB_EXP_PRIO == 2
-      __builtin_amdgcn_s_setprio(1);
-#endif
-      stage_a(s + 1, more, NA);
-      stage_b(s + 1, NB);
-#if defined(GB_EXP_PRIO) && GB_EXP_PRIO == 2
-      __builtin_amdgcn_s_setprio(0);
-#endif
-      GB_T(1);
-    }
-#endif
-    fetch(s + 1 + NSETS, NA, NB);
-    GB_T(3);
+    });
+    fetch(s + 3, SA, SB);
   };
 
   float xs_next = 0.f;
-  if (n_steps > 0) {  // n_steps is even (two stages per tile)
+  if (n_steps > 0) {
     fetch(0, ra[0], rb[0]);
     xs_put(0, xs_get(0));
     xs_next = xs_get(1);
-#pragma unroll
-    for (int k = 1; k < NSETS; ++k) fetch(k, ra[k], rb[k]);
+    fetch(1, ra[1], rb[1]);
     if (ENC || LASTROWS) __syncthreads();  // xs of stage 0, the encoder matrix, the zeroed A tiles
-    stage_a(0, true, ra[0]);
-    stage_b(0, rb[0]);
-    fetch(NSETS, ra[0], rb[0]);
+    gb_for<32>([&](auto K) { slice(K, 0, 0x3c003c00u, ra[0], rb[0]); });
+    fetch(2, ra[0], rb[0]);
     xs_put(1, xs_next);
     xs_next = xs_get(2);
   }
   __syncthreads();
-  // stage k multiplies while stage k+1 goes from set (k+1) % NSETS into LDS; compute() then refills that set
-  auto step = [&](int k, u32x4 (&NA)[LASTROWS ? 4 : 2], u32x4 (&NB)[2]) {
-    compute(k, NA, NB);
-    xs_put(k + 2, xs_next);  // xs buffer k & 1: last read while stage k was staged, one barrier ago
-    xs_next = xs_get(k + 3);
+#pragma unroll 1
+  for (int s = 0; s < n_steps; s += 2) {
+    stage(s, ra[1], rb[1]);
+    xs_put(s + 2, xs_next);  // xs buffer s & 1: last read while stage s was staged, one barrier ago
+    xs_next = xs_get(s + 3);
     __syncthreads();
-    GB_T(4);
-  };
-  if (NSETS == 2) {
-#pragma unroll 1
-    for (int s = 0; s < n_steps; s += 2) {
-      step(s, ra[1], rb[1]);
-      step(s + 1, ra[0], rb[0]);
-    }
-  } else {
-#pragma unroll 1
-    for (int s = 0; s < n_steps; s += 3) {
-      step(s, ra[1 % NSETS], rb[1 % NSETS]);
-      if (s + 1 >= n_steps) break;
-      step(s + 1, ra[2 % NSETS], rb[2 % NSETS]);
-      if (s + 2 >= n_steps) break;
-      step(s + 2, ra[0], rb[0]);
-    }
+    stage(s + 1, ra[0], rb[0]);
+    xs_put(s + 3, xs_next);
+    xs_next = xs_get(s + 4);
+    __syncthreads();
   }
-#ifdef GB_STAMPS
-  GB_T(0);
-#endif
+  gb_for<8>([&](auto Mi) { mma(gb_ic<0>{}, Mi); });  // the last stage's last K = 16 group
   // ---- chunk slab: dW rows follow the MFMA C layout (register r of lane (li, half): row (r&3)+8(r>>2)+4 half, col li);
   // the gradient scale comes off here
   const float unscale = a.dz_state != nullptr ? 1.0f / a.dz_state[2] : 1.0f;
   float* slab = a.slabs + (size_t)kc * a.slab_floats;
 #pragma unroll
-  for (int i = 0; i < (LASTROWS ? 1 : 2); ++i) {
+  for (int i = 0; i < NI; ++i) {
     const int rb0 = 32 * (2 * wm + i);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int col = it.n0 + 32 * (4 * wn + j) + li;
+      // column of dW behind B-tile row rr; first-layer units: rows (4 qd + 0, 1) = sine, (4 qd + 2, 3) = cosine features
+      // of frequencies n0 + 2 qd + (0, 1)
+      const int rr = 32 * (4 * wn + j) + li;
+      const int freq = it.n0 + 2 * (rr >> 2) + (rr & 1);
+      const int col = ENC ? (freq < a.E ? ((rr & 2) ? a.E : 0) + freq : it.K) : it.n0 + rr;
       if (col < it.K) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -465,16 +386,6 @@ __device__ __forceinline__ void dwgb_body(const DwGemmBf16Args& a, const DwGemmB
       if (seg == 0 && row < it.M) slab[it.gb_off + row] = v * unscale;
     }
   }
-#ifdef GB_STAMPS
-  __builtin_amdgcn_s_waitcnt(0);
-  GB_T(5);
-  if (lane == 0 && blockIdx.x < 512) {
-    unsigned id;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(id));
-    tsum[6] = id, tsum[7] = n_steps;
-    for (int k = 0; k < 8; ++k) gb_stamps[(blockIdx.x * 8 + w) * 8 + k] = tsum[k];
-  }
-#endif
 }
 
 template <int TL>
@@ -485,15 +396,21 @@ __global__ __launch_bounds__(GB_NT, 2) void dw_gemm_bf16_kernel(const DwGemmBf16
 #ifdef GB_EXP_NOENC  // timing experiment: the first-layer units leave at once
   if (it.z_off < 0) return;
 #endif
+#ifdef GB_EXP_ONLYENC  // ... or all the others
+  if (it.z_off >= 0) return;
+#endif
+#ifdef GB_EXP_ONLYLAST
+  if (!(it.z_off >= 0 && it.M <= 4)) return;
+#endif
   if (it.z_off < 0) {
     if (it.n0 == 0)
-      dwgb_body<TL, true, true, false, 2>(a, it, kc, lds_raw);
+      dwgb_body<TL, true, true, false>(a, it, kc, lds_raw);
     else
-      dwgb_body<TL, true, false, false, 2>(a, it, kc, lds_raw);
+      dwgb_body<TL, true, false, false>(a, it, kc, lds_raw);
   } else if (it.M <= 4) {
-    dwgb_body<TL, false, true, true, 3>(a, it, kc, lds_raw);  // last layer: out_features <= 4 rows of dZ
+    dwgb_body<TL, false, true, true>(a, it, kc, lds_raw);  // last layer: out_features <= 4 rows of dZ
   } else {
-    dwgb_body<TL, false, true, false, 3>(a, it, kc, lds_raw);  // hidden layers: one column tile (K <= 256), always with db
+    dwgb_body<TL, false, true, false>(a, it, kc, lds_raw);  // hidden layers: one column tile (K <= 256), always with db
   }
   // the next step's gradient scale (inr_w2.h): nothing in this launch reads words 0 and 1
   if (a.dz_state != nullptr && blockIdx.x == 0 && threadIdx.x == 0) dz_state_roll(a.dz_state);

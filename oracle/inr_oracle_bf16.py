@@ -11,7 +11,8 @@ MI355X kernels round (csrc/inr_siren_bf16_impl.h, csrc/inr_dw_gemm_bf16.hip, csr
   backward  dZ_last * mult in bf16 against bf16(W^T * w0); dZ_l = dH_l * cos(2 pi P_l / 256) (fp32); the next GEMM's
             operand is bf16(dZ_l)
   dW, db    sum over coordinates of fp16(G_l) x fp16(sin(2 pi P_{l-1} / 256))  (layer 0: fp16 of the fp32 encoder
-            features; last layer: fp16(dZ_last * mult)), fp32 accumulate, divided by mult
+            features, regenerated with one phase chain per frequency; last layer: fp16(dZ_last * mult)), fp32
+            accumulate, divided by mult
 
 What stays different from the device: the order of the fp32 sums and the last bit of sin / cos (hardware v_sin_f32 against
 libm).  A value that lands within that noise of a rounding boundary rounds the other way (a 1-ulp difference of one bf16 /
@@ -74,6 +75,19 @@ def gauss_features_rev(coords: Tensor, enc_B: Tensor) -> Tensor:
     return torch.cat([_rev_sin(chain(0.0)), _rev_sin(chain(0.25))], dim=1)
 
 
+def gauss_features_gemm(coords: Tensor, enc_B: Tensor) -> Tensor:
+    """The same features as the weight-gradient GEMM regenerates them (csrc/inr_dw_gemm_bf16.hip, first-layer units): one
+    phase chain per frequency, its sine and its COSINE (the forward pass starts a second chain at 1/4 turn for the cosine
+    half: equal to an ulp of the phase)."""
+    x, Bm = coords.double(), enc_B.double()
+    t = torch.zeros((coords.shape[0], Bm.shape[0]), dtype=torch.float64)
+    for k in range(3):
+        t = (x[:, k:k + 1] * Bm[None, :, k] + t).float().double()
+    t = t.float()
+    t = t - torch.floor(t)
+    return torch.cat([_rev_sin(t), _rev_cos(t)], dim=1)
+
+
 def _mm(a: Tensor, b: Tensor, wide: bool) -> Tensor:
     """fp32 GEMM with fp32 accumulation (the device's) or, ``wide``, with float64 accumulation: the same roundings at
     every stated place, another order of the sums in between."""
@@ -114,7 +128,7 @@ def siren_bf16_step(sd: Dict[str, Tensor], coords: Tensor, enc_B: Tensor, net: d
     grads = {}
     amax = 0.0
     hs = [_f16(_rev_sin(p / 256.0)) for p in P]  # the GEMM's B operands: fp16 sine of the stashed phase
-    f16_feat = _f16(feat32)
+    f16_feat = _f16(gauss_features_gemm(coords, enc_B))
     a_last = _f16(dzl)
     grads[f"model.{D - 1}.linear.weight"] = (a_last.double().t() @ hs[D - 2].double() / mult).float()
     grads[f"model.{D - 1}.linear.bias"] = (a_last.double().sum(0) / mult).float()
