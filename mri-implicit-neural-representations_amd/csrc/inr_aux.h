@@ -25,9 +25,12 @@ struct AdamArgs {
 // entries of the layers in `mask` (bit l = L[l]) and the flat gradient entries [lo, hi) are summed over the n2 slabs
 // that FOLLOW the n_blocks slabs of the fused kernel (partial sums of the batch-level weight-gradient GEMM);
 // n2 == 0: one slab set
+// ... and, of those, the flat entries [lo3, hi3) over n3 slabs of the same set instead of n2 (the bf16 GEMM gives its
+// first-layer units, whose operand is arithmetic rather than a load, shorter chunks -- more of them; n3 == 0: none)
 struct SlabSplit {
   int lo, hi, n2;
   unsigned mask;
+  int lo3 = 0, hi3 = 0, n3 = 0;
 };
 hipError_t launch_reduce_slabs(const NetDesc& nd, const float* slabs, int n_blocks, float* grads, float* loss_out,
                                const float* params, const float* packed, hipStream_t st,

@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void reduce_slabs_real_kernel(const float* __r
   // split.lo / split.hi are multiples of 4 (checked by the launcher): a lane's four entries share a slab set
   const bool second = split.n2 > 0 && i4 >= split.lo && i4 < split.hi;
   const float* __restrict__ slabs = second ? slabs_all + (size_t)n_blocks_all * slab_floats : slabs_all;
-  const int n_blocks = second ? split.n2 : n_blocks_all;
+  const int n_blocks = second ? (split.n3 > 0 && i4 >= split.lo3 && i4 < split.hi3 ? split.n3 : split.n2) : n_blocks_all;
   const int per = (n_blocks + 3) / 4;
   const int b0 = w * per, b1 = (b0 + per < n_blocks) ? b0 + per : n_blocks;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
@@ -218,6 +218,8 @@ hipError_t launch_reduce_slabs(const NetDesc& nd, const float* slabs, int n_bloc
                                const float* params, const float* packed, hipStream_t st, SlabSplit split) {
   bool all_real = true;  // ... and slab layout == flat layout (not the case for MFN: L[] order != flat order)
   for (int l = 0; l < nd.ND; ++l) all_real = all_real && nd.L[l].ltype == LT_REAL && nd.L[l].gw_off == nd.L[l].w_off;
+  if (split.n3 > 0 && !(all_real && ((split.lo | split.hi | split.lo3 | split.hi3) & 3) == 0 && split.mask == 0))
+    return hipErrorInvalidValue;  // a third slab count is the flat-layout reduction's only
   if (all_real && ((split.lo | split.hi) & 3) == 0 && split.mask == 0) {  // slab offsets == flat offsets; slab_floats % 64 == 0 keeps every slab 16-byte aligned
     const int grid = (nd.P + 255) / 256;
     hipLaunchKernelGGL(reduce_slabs_real_kernel, dim3(grid + 1), dim3(256), 0, st, slabs, n_blocks, nd.slab_floats, nd.P,
@@ -379,7 +381,7 @@ __global__ __launch_bounds__(256) void reduce_adam_real_kernel(const NetDesc nd,
   const int i4 = (blockIdx.x * 64 + lane) * 4;
   const bool second = split.n2 > 0 && i4 >= split.lo && i4 < split.hi;
   const float* __restrict__ slabs = second ? slabs_all + (size_t)n_blocks_all * slab_floats : slabs_all;
-  const int n_blocks = second ? split.n2 : n_blocks_all;
+  const int n_blocks = second ? (split.n3 > 0 && i4 >= split.lo3 && i4 < split.hi3 ? split.n3 : split.n2) : n_blocks_all;
   const int per = (n_blocks + 3) / 4;
   const int b0 = w * per, b1 = (b0 + per < n_blocks) ? b0 + per : n_blocks;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
@@ -433,7 +435,7 @@ hipError_t launch_adam_pack(const NetDesc& nd, float* params, const float* grads
 hipError_t launch_reduce_slabs_adam(const NetDesc& nd, const float* slabs, int n_blocks, float* grads, float* loss_out,
                                     float* params, float* m1, float* m2, float* packed, const AdamArgs& aa_in,
                                     hipStream_t st, SlabSplit split) {
-  bool flat = ((split.lo | split.hi) & 3) == 0 && split.mask == 0 && !nd.gabor;
+  bool flat = ((split.lo | split.hi | split.lo3 | split.hi3) & 3) == 0 && split.mask == 0 && !nd.gabor;
   for (int l = 0; l < nd.ND; ++l) flat = flat && nd.L[l].ltype == LT_REAL && nd.L[l].gw_off == nd.L[l].w_off;
   if (!flat) {
     hipError_t e = launch_reduce_slabs(nd, slabs, n_blocks, grads, loss_out, params, packed, st, split);

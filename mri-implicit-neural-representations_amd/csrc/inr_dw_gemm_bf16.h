@@ -27,7 +27,13 @@ struct DwGemmBf16Args {
   long long B;
   long long save_floats_per_tile;
   int slab_floats;
-  int n_tiles, n_chunks, tiles_per_chunk;
+  int n_tiles;
+  // split-K over chunks of tiles, two classes of units: the first n_enc_units (first layer: their B operand is encoder
+  // arithmetic, ~1.3 x the time of a hidden unit per tile) take n_chunks_enc chunks of tiles_per_chunk_enc tiles, the others
+  // n_chunks of tiles_per_chunk; workgroups = n_enc_units * n_chunks_enc + (n_units - n_enc_units) * n_chunks.  Chunk kc of a
+  // unit writes the unit's entries of slab kc.
+  int n_enc_units, n_chunks_enc, tiles_per_chunk_enc;
+  int n_chunks, tiles_per_chunk;
   int TL, E, n_units;
   DwGemmBf16Unit unit[INR_DWGB_MAX_UNITS];
 };

@@ -129,7 +129,8 @@ __device__ __forceinline__ float gauss_phase(const float* x, float b0, float b1,
 // (Inlined: as real functions the variants would take their arguments through memory -- flat loads, whose waits are
 // vmcnt(0) and drain the prefetch -- and buffer descriptors from memory cost waterfall loops.)
 template <int TL, bool ENC, bool BIAS, bool LASTROWS>
-__device__ __forceinline__ void dwgb_body(const DwGemmBf16Args& a, const DwGemmBf16Unit& it, int kc, char* lds_raw) {
+__device__ __forceinline__ void dwgb_body(const DwGemmBf16Args& a, const DwGemmBf16Unit& it, int kc, int tiles_per_chunk,
+                                          char* lds_raw) {
   _Float16* lds = reinterpret_cast<_Float16*>(lds_raw);
   float* xs_lds = reinterpret_cast<float*>(lds_raw + (size_t)2 * GB_STAGE * 2);  // [2 stages][64 coords][3]
   float* encB_lds = xs_lds + 2 * GB_KS * 3;                                      // [E][3]
@@ -139,9 +140,9 @@ __device__ __forceinline__ void dwgb_body(const DwGemmBf16Args& a, const DwGemmB
   constexpr int KS_PER_TILE = TL / GB_KS;
   constexpr int NI = LASTROWS ? 1 : 2;   // row blocks of the wave tile that hold anything
   constexpr int NA = LASTROWS ? 4 : 2;   // 16-byte loads of an A item
-  const int t0 = kc * a.tiles_per_chunk;
+  const int t0 = kc * tiles_per_chunk;
   int n_mine = a.n_tiles - t0;
-  if (n_mine > a.tiles_per_chunk) n_mine = a.tiles_per_chunk;
+  if (n_mine > tiles_per_chunk) n_mine = tiles_per_chunk;
   const int n_steps = (n_mine > 0 ? n_mine : 0) * KS_PER_TILE;  // even: two stages per tile
 
   f32x16 acc[2][4];
@@ -220,7 +221,7 @@ __device__ __forceinline__ void dwgb_body(const DwGemmBf16Args& a, const DwGemmB
   // odd k : piece (k/2) % 4 of A row k / 8: two byte permutes, two more + the store, then the row sum in two halves.
   // Sums of a stage past the end (loaded, never multiplied) are kept out with a zero "ones" vector: no branch in a stage.
   u32x4 rowA = {0u, 0u, 0u, 0u}, rowB = {0u, 0u, 0u, 0u}, rowC = {0u, 0u, 0u, 0u};
-  float eb0 = 0.f, eb1 = 0.f, eb2 = 0.f, eph0 = 0.f, eph1 = 0.f;
+  float eb0 = 0.f, eb1 = 0.f, eb2 = 0.f, eph0 = 0.f, eph1 = 0.f, xq[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   auto slice = [&](auto K, int s, unsigned ones, const u32x4 (&A)[NA], const u32x4 (&B)[2]) {
     constexpr int k = decltype(K)::value, R = k / 8, pc = (k / 2) % 4;
     _Float16* sa = lds + (size_t)(s & 1) * GB_STAGE + (4 * quad) * GB_PITCH + 8 * seg;
@@ -233,14 +234,22 @@ __device__ __forceinline__ void dwgb_body(const DwGemmBf16Args& a, const DwGemmB
         // Even slot e = k / 2: frequency f = e / 8, coordinate pair (e / 2) % 4; first the two phases, next slot the four
         // features; a frequency's two rows are stored after its fourth pair.
         constexpr int e = k / 2, f = e / 8, cp = (e / 2) % 4;
-        if constexpr (e % 2 == 0) {
-          const float* xs = xs_lds + (s & 1) * GB_KS * 3 + 24 * seg + 6 * cp;
-          if constexpr (cp == 0) {
-            int j = it.n0 + 2 * quad + f;
+        const float* xs = xs_lds + (s & 1) * GB_KS * 3 + 24 * seg;
+        // (the six coordinates and the frequency's row of the encoder matrix are read from LDS one slot before the chain
+        // that takes them -- at the head of a stage there is no such slot: they were written across the barrier)
+        auto get = [&](auto CP, auto F) {
+          constexpr int ncp = decltype(CP)::value, nf = decltype(F)::value;
+#pragma unroll
+          for (int i = 0; i < 6; ++i) xq[i] = xs[6 * ncp + i];
+          if constexpr (ncp == 0) {
+            int j = it.n0 + 2 * quad + nf;
             j = j < a.E ? j : a.E - 1;  // frequencies past E (enc_size not a multiple of 128) are computed and never stored
             eb0 = encB_lds[3 * j + 0], eb1 = encB_lds[3 * j + 1], eb2 = encB_lds[3 * j + 2];
           }
-          eph0 = gauss_phase(xs, eb0, eb1, eb2), eph1 = gauss_phase(xs + 3, eb0, eb1, eb2);
+        };
+        if constexpr (e % 2 == 0) {
+          if constexpr (e == 0) get(gb_ic<0>{}, gb_ic<0>{});
+          eph0 = gauss_phase(xq, eb0, eb1, eb2), eph1 = gauss_phase(xq + 3, eb0, eb1, eb2);
         } else {
           rowB[cp] = pk_f16(__builtin_amdgcn_sinf(eph0), __builtin_amdgcn_sinf(eph1));
           rowC[cp] = pk_f16(__builtin_amdgcn_cosf(eph0), __builtin_amdgcn_cosf(eph1));
@@ -248,6 +257,7 @@ __device__ __forceinline__ void dwgb_body(const DwGemmBf16Args& a, const DwGemmB
             *reinterpret_cast<u32x4*>(sb + f * GB_PITCH) = rowB;
             *reinterpret_cast<u32x4*>(sb + (2 + f) * GB_PITCH) = rowC;
           }
+          if constexpr (e < 15) get(gb_ic<((e + 1) / 2) % 4>{}, gb_ic<(e + 1) / 8>{});
         }
       } else {
         rowB[pc] = sin_pair<R>(B[pc >> 1][2 * (pc & 1)], B[pc >> 1][2 * (pc & 1) + 1]);
@@ -391,26 +401,31 @@ __device__ __forceinline__ void dwgb_body(const DwGemmBf16Args& a, const DwGemmB
 template <int TL>
 __global__ __launch_bounds__(GB_NT, 2) void dw_gemm_bf16_kernel(const DwGemmBf16Args a) {
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
-  const int kc = blockIdx.x / a.n_units;
-  const DwGemmBf16Unit& it = a.unit[blockIdx.x - kc * a.n_units];
+  int b = blockIdx.x, kc, u, tpc;
+  const int enc_wgs = a.n_enc_units * a.n_chunks_enc;
+  if (b < enc_wgs) {
+    kc = b / a.n_enc_units, u = b - kc * a.n_enc_units, tpc = a.tiles_per_chunk_enc;
+  } else {
+    b -= enc_wgs;
+    const int others = a.n_units - a.n_enc_units;
+    kc = b / others, u = a.n_enc_units + b - kc * others, tpc = a.tiles_per_chunk;
+  }
+  const DwGemmBf16Unit& it = a.unit[u];
 #ifdef GB_EXP_NOENC  // timing experiment: the first-layer units leave at once
   if (it.z_off < 0) return;
 #endif
 #ifdef GB_EXP_ONLYENC  // ... or all the others
   if (it.z_off >= 0) return;
 #endif
-#ifdef GB_EXP_ONLYLAST
-  if (!(it.z_off >= 0 && it.M <= 4)) return;
-#endif
   if (it.z_off < 0) {
     if (it.n0 == 0)
-      dwgb_body<TL, true, true, false>(a, it, kc, lds_raw);
+      dwgb_body<TL, true, true, false>(a, it, kc, tpc, lds_raw);
     else
-      dwgb_body<TL, true, false, false>(a, it, kc, lds_raw);
+      dwgb_body<TL, true, false, false>(a, it, kc, tpc, lds_raw);
   } else if (it.M <= 4) {
-    dwgb_body<TL, false, true, true>(a, it, kc, lds_raw);  // last layer: out_features <= 4 rows of dZ
+    dwgb_body<TL, false, true, true>(a, it, kc, tpc, lds_raw);  // last layer: out_features <= 4 rows of dZ
   } else {
-    dwgb_body<TL, false, true, false>(a, it, kc, lds_raw);  // hidden layers: one column tile (K <= 256), always with db
+    dwgb_body<TL, false, true, false>(a, it, kc, tpc, lds_raw);  // hidden layers: one column tile (K <= 256), always with db
   }
   // the next step's gradient scale (inr_w2.h): nothing in this launch reads words 0 and 1
   if (a.dz_state != nullptr && blockIdx.x == 0 && threadIdx.x == 0) dz_state_roll(a.dz_state);
@@ -431,13 +446,16 @@ extern "C" int inr_debug_gemm_stamps(long long* host_out) {
 
 hipError_t launch_dw_gemm_bf16(const DwGemmBf16Args& a, hipStream_t st) {
   if (a.n_units <= 0 || a.n_units > INR_DWGB_MAX_UNITS || a.n_chunks <= 0 || a.tiles_per_chunk <= 0 || a.TL != 128 ||
-      a.E > 1024)
+      a.E > 1024 || a.n_enc_units < 0 || a.n_enc_units >= a.n_units ||
+      (a.n_enc_units > 0 && (a.n_chunks_enc <= 0 || a.tiles_per_chunk_enc <= 0)))
     return hipErrorInvalidValue;
+  for (int u = 0; u < a.n_units; ++u)  // the first-layer units come first
+    if ((a.unit[u].z_off < 0) != (u < a.n_enc_units)) return hipErrorInvalidValue;
   const size_t lds_bytes = (size_t)2 * GB_STAGE * 2 + (size_t)(2 * GB_KS * 3 + 3 * a.E) * sizeof(float);
   if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
   hipError_t e = allow_full_lds<dw_gemm_bf16_kernel<128>>();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(dw_gemm_bf16_kernel<128>, dim3((unsigned)(a.n_chunks * a.n_units)), dim3(GB_NT), lds_bytes, st, a);
+  hipLaunchKernelGGL(dw_gemm_bf16_kernel<128>, dim3((unsigned)(a.n_enc_units * a.n_chunks_enc + (a.n_units - a.n_enc_units) * a.n_chunks)), dim3(GB_NT), lds_bytes, st, a);
   return hipGetLastError();
 }
 
