@@ -141,30 +141,17 @@ __device__ __forceinline__ void pn_begin(PnRing& r) {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
   __builtin_amdgcn_s_barrier();
 }
-__device__ __forceinline__ bf16x8 pn_frag(const PnRing& r, int p, int f) {
-  return *reinterpret_cast<const bf16x8*>(r.ring + (p & (PN_SLOTS - 1)) * W2_PANEL_BYTES + (f * 64 + r.lane) * 16);
+// fragment f of the panel at stream position p: ONE address register per panel (opaque to the compiler, which otherwise
+// forms the sixteen lane addresses up front, a register each, and adds the slot to every one of them) + f KB as an immediate
+__device__ __forceinline__ unsigned pn_base(const PnRing& r, int p) {
+  unsigned b = (unsigned)((p & (PN_SLOTS - 1)) * W2_PANEL_BYTES + r.lane * 16);
+  asm volatile("" : "+v"(b));
+  return b;
 }
-// one row block: 16 K-steps of panel p against the 16 B operands.  The sixteen MFMAs are one dependent chain (a single
-// accumulator), and left alone the scheduler puts each fragment's LDS read right in front of the MFMA that needs it -- the
-// matrix pipe then waits out an LDS latency per K-step (the first build: 17 lgkmcnt(0) waits per row block).  Pinned order:
-// eight reads up front, then every MFMA of the first half paired with a read of the second half, then the rest.
-__device__ __forceinline__ f32x16 pn_mma_block(const PnRing& r, int p, const bf16x8 (&b)[16]) {
-  f32x16 acc = zero16();
-  bf16x8 A[16];
-#pragma unroll
-  for (int t = 0; t < 16; ++t) A[t] = pn_frag(r, p, t);
-#pragma unroll
-  for (int t = 0; t < 16; ++t) acc = mfma_bf16(A[t], b[t], acc);
-  __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);  // 8 LDS reads
-#pragma unroll
-  for (int t = 0; t < 8; ++t) {
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
-    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 LDS read
-  }
-  __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);  // 8 MFMAs
-  __builtin_amdgcn_sched_barrier(0);
-  return acc;
+__device__ __forceinline__ bf16x8 pn_frag(const PnRing& r, unsigned base, int f) {
+  return *reinterpret_cast<const bf16x8*>(r.ring + base + f * 1024);
 }
+// (row blocks: SirenTile::block -- 16 K-steps of one panel, each MFMA followed by a slice of the row block before's epilogue)
 
 // ---- vector loads the compiler does not see ------------------------------------------------------------------------
 // The phase bytes of a backward epilogue are fetched PN_PD epilogues ahead by inline assembly and waited for with a
@@ -211,10 +198,19 @@ __device__ __forceinline__ void w2_wait4(unsigned (&z)[4]) {
 }
 
 // ---- one tile group (four waves, 128 coordinates = one stash tile) ----------------------------------------------
-// NH: hidden layers behind the first (D = NH + 2 Linear layers).  RB: role B (waves 4-7).  ACTIVE = false: the group has
-// no tile in this launch shape (small batches run one stash tile per workgroup): it takes part in every barrier and
-// issues its share of the DMA pieces, nothing else.
-template <int MODE, int NH, bool RB, bool ACTIVE>
+// NH: hidden layers behind the first (D = NH + 2 Linear layers).  ACTIVE = false: the group has no tile in this launch
+// shape (small batches run one stash tile per workgroup): it takes part in every barrier and issues its share of the DMA
+// pieces, nothing else.
+//
+// ONE instruction stream, the same for all eight waves: a row block is 16 slots of  [MFMA t][slice t of the epilogue of
+// the row block BEFORE]  -- one value (bias, sine, phase byte; or cosine, product, bf8) per slot, ~20-26 cycles of vector
+// issue beside the MFMA's 32 on the pipe --, fenced so that the compiler keeps the interleaving; two accumulators
+// alternate.  The first row block of a layer reads ALL of the layer below, including the two B operands its last epilogue
+// produces: there the slices run at double rate (two values a slot, done behind MFMA 7) and the block's K-steps 14 and 15
+// are the ones that wait for them.  (Rounds 2-3a staggered the two waves of a SIMD instead -- one multiplies while the
+// other runs an epilogue.  Measured on the dW GEMM, which had the same plan: the partner made no progress beside the
+// multiplying wave, the kernel took the SUM of its matrix and vector times -- profiles/r03_dw_gemm_knockouts.txt.)
+template <int MODE, int NH, bool ACTIVE>
 struct SirenTile {
   static constexpr int TL = W2_TL, D = NH + 2;
   static constexpr int NE = 8 * (NH + 1);  // backward epilogues per tile: row block e & 7 of dZ_lz, lz = D-2 - (e >> 3)
@@ -225,6 +221,7 @@ struct SirenTile {
   const float* bias_lds;
   const float* encB_lds;
   int lane, half, col, wcol, w;
+  int bias_voff;     // byte offset of the lane's part of the bias table (+ 4 half rows) from the ring's base
   float mult;        // what the loss gradient is multiplied by (inr_w2.h: gradient-scale state)
   float amax = 0.f;  // max |dZ * mult| this wave has stashed
   float loss_acc = 0.f;
@@ -236,42 +233,69 @@ struct SirenTile {
   bool valid, tile_ok;
   __amdgpu_buffer_rsrc_t rs_tile;
   u32x4 rz_tile;
-  bf16x8 hbuf[2][16];  // B operands: layer l reads hbuf[(l - 1) & 1] and writes hbuf[l & 1]; backward likewise per epilogue
+  u32x4 hb[2][16];   // B operands (bf16 pairs): layer l reads hb[(l - 1) & 1] and writes hb[l & 1]; backward likewise
+  f32x16 acc2[2];    // row block i accumulates in acc2[i & 1] while the epilogue slices read the other
   unsigned pz[PN_PD + 1][4];  // phase dwords of backward epilogues e, e+1, .. (set e % (PD + 1))
+  // state of an epilogue between its slices
+  f32x4 eb4, eb4n;   // bias of the value group in work / the next one
+  float eprev = 0.f;
+  unsigned epk = 0;
 
   __device__ __forceinline__ SirenTile(const NetDesc& nd_, const LossDesc& ld_, const MlpArgs& a_, PnRing& r_,
                                        const float* bias, const float* encB, int lane_, int w_, float mult_)
       : nd(nd_), ld(ld_), a(a_), r(r_), bias_lds(bias), encB_lds(encB), lane(lane_), half(lane_ >> 5), col(lane_ & 31),
-        wcol((w_ & 3) * 32 + (lane_ & 31)), w(w_), mult(mult_) {}
+        wcol((w_ & 3) * 32 + (lane_ & 31)), w(w_), mult(mult_) {
+    bias_voff = PN_SLOTS * W2_PANEL_BYTES + 16 * half;
+    asm volatile("" : "+v"(bias_voff));
+  }
 
-  // -------- forward epilogue of row block mm of hidden layer l: t = acc + bias (revolutions) -> phase bytes to the
-  // stash, h = sin(2 pi t) -> B operands 2 mm, 2 mm + 1 of the next layer
-  template <int L, int MM>
-  __device__ __forceinline__ void epi_fwd(const f32x16& acc) {
-    const float* bl = bias_lds + L * 256 + 32 * MM + 4 * half;
-    const float magic = 49152.0f;
-    constexpr int so0 = (L * W2_TENSOR_DWORDS + 8 * MM * W2_HALF) * 4;  // w2_stash_P(L), quad 8 MM
-    float hv[16];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const f32x4 b4 = *reinterpret_cast<const f32x4*>(bl + 8 * g);
-      unsigned pk = 0;
-      const float t0 = acc[4 * g + 0] + b4[0], t1 = acc[4 * g + 1] + b4[1], t2 = acc[4 * g + 2] + b4[2],
-                  t3 = acc[4 * g + 3] + b4[3];
-      hv[4 * g + 0] = __builtin_amdgcn_sinf(t0);
-      hv[4 * g + 1] = __builtin_amdgcn_sinf(t1);
-      hv[4 * g + 2] = __builtin_amdgcn_sinf(t2);
-      hv[4 * g + 3] = __builtin_amdgcn_sinf(t3);
-      phase_byte<0>(pk, t0, magic);
-      phase_byte<1>(pk, t1, magic);
-      phase_byte<2>(pk, t2, magic);
-      phase_byte<3>(pk, t3, magic);
-      __builtin_amdgcn_raw_buffer_store_b32(pk, rs_tile, voff, so0 + 2 * g * W2_HALF * 4, 0);  // quad 8 mm + 2 g (+ half in voff)
+  // -------- forward epilogue of row block MM of hidden layer L, value V of 16 (accumulator register V: row
+  // 32 MM + 8 (V >> 2) + 4 half + (V & 3)): t = acc + bias (revolutions) -> phase byte (a dword store per four values),
+  // h = sin(2 pi t) -> bf16, dword (V >> 1) & 3 of B operand 2 MM + (V >> 3) of the next layer
+  template <int L, int MM, int V>
+  __device__ __forceinline__ void fwd_value(const f32x16& acc) {
+    constexpr int g = V >> 2, j = V & 3;
+    // (one opaque base register + immediates: left to itself the compiler forms the 4 x 8 x D table addresses up front,
+    // a register each -- 36 of them spilled)
+    const float* bl = reinterpret_cast<const float*>(r.ring + bias_voff) + L * 256 + 32 * MM;
+    if constexpr (V == 0) {
+      eb4 = *reinterpret_cast<const f32x4*>(bl);
+      eb4n = *reinterpret_cast<const f32x4*>(bl + 8);
+    } else if constexpr (j == 0) {
+      eb4 = eb4n;
+      if constexpr (g < 3) eb4n = *reinterpret_cast<const f32x4*>(bl + 8 * (g + 1));
     }
-    hbuf[L & 1][2 * MM] = pack8(hv);
-    hbuf[L & 1][2 * MM + 1] = pack8(hv + 8);
-    pin(hbuf[L & 1][2 * MM]);
-    pin(hbuf[L & 1][2 * MM + 1]);
+    if constexpr (j == 0) epk = 0;
+    const float t = acc[V] + eb4[j];
+    const float h = __builtin_amdgcn_sinf(t);
+    phase_byte<j>(epk, t, 49152.0f);
+    // ("this value exists HERE": the sine feeds the NEXT layer's GEMM, and left alone is computed down there)
+    if constexpr (j & 1) {
+      unsigned d = pack_bf16(eprev, h);
+      asm volatile("" : "+v"(d));
+      hb[L & 1][2 * MM + (V >> 3)][(V >> 1) & 3] = d;
+    } else {
+      eprev = h;
+      asm volatile("" : "+v"(eprev));
+    }
+    if constexpr (j == 3) {
+      constexpr int so0 = (L * W2_TENSOR_DWORDS + 8 * MM * W2_HALF) * 4;  // w2_stash_P(L), quad 8 MM
+      __builtin_amdgcn_raw_buffer_store_b32(epk, rs_tile, voff, so0 + 2 * g * W2_HALF * 4, 0);  // quad 8 mm + 2 g (+ half in voff)
+    }
+  }
+  // slice T of 16 (RATE 1) or of 8 (RATE 2: two values, nothing behind slot 7)
+  template <int L, int MM, int RATE, int T>
+  __device__ __forceinline__ void fwd_slice(const f32x16& acc) {
+    if constexpr (RATE == 1) {
+      fwd_value<L, MM, T>(acc);
+    } else if constexpr (T < 8) {
+      fwd_value<L, MM, 2 * T>(acc);
+      fwd_value<L, MM, 2 * T + 1>(acc);
+    }
+  }
+  template <int L, int MM>
+  __device__ __forceinline__ void epi_fwd(const f32x16& acc) {  // a whole epilogue at once (layer 0)
+    static_for<0, 16>([&](auto vc) { fwd_value<L, MM, decltype(vc)::value>(acc); });
   }
 
   // -------- backward epilogues, sequence e = 0 .. NE-1.  Each wave runs  [loads of e + PD][epilogue e]  in this order.
@@ -296,38 +320,64 @@ struct SirenTile {
       w2_load4_asm(pz[E % (PN_PD + 1)], rz_tile, voff, (lz * W2_TENSOR_DWORDS + 8 * mm * W2_HALF) * 4);
     }
   }
-  // dZ = acc * cos(2 pi phase) (the transposed image carries w0): bf8 to the stash, bf16 into the next B operands.
-  // Behind the epilogue's loads lie 4 (PD + e) operations for the first PD epilogues of a tile, 8 PD from then on.
-  template <int E>
-  __device__ __forceinline__ void epi_bwd(const f32x16& acc) {
-    constexpr int lz = D - 2 - (E >> 3), mm = E & 7, set = E % (PN_PD + 1);
-    w2_wait4<(E < PN_PD ? 4 * (PN_PD + E) : 8 * PN_PD)>(pz[set]);
-    constexpr int so0 = ((D - 1 + lz) * W2_TENSOR_DWORDS + 8 * mm * W2_HALF) * 4;  // w2_stash_G(lz, D), quad 8 mm
-    float dz[16];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const unsigned pw = pz[set][g];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float c = __builtin_amdgcn_cosf((float)((pw >> (8 * j)) & 255u) * 0.00390625f);
-        dz[4 * g + j] = acc[4 * g + j] * c;
-      }
-      amax = fmaxf(amax, fmaxf(fabsf(dz[4 * g]), fabsf(dz[4 * g + 1])));
-      amax = fmaxf(amax, fmaxf(fabsf(dz[4 * g + 2]), fabsf(dz[4 * g + 3])));
-      int pk = __builtin_amdgcn_cvt_pk_bf8_f32(dz[4 * g], dz[4 * g + 1], 0, false);
-      pk = __builtin_amdgcn_cvt_pk_bf8_f32(dz[4 * g + 2], dz[4 * g + 3], pk, true);
-      __builtin_amdgcn_raw_buffer_store_b32((unsigned)pk, rs_tile, voff, so0 + 2 * g * W2_HALF * 4, 0);
+  // value V of backward epilogue E: dZ = acc * cos(2 pi phase) (the transposed image carries w0): bf8 to the stash (a dword
+  // store per four values), bf16 into the next B operands.  Value 0 first issues the loads of epilogue E + PD and waits for
+  // its own: behind those lie 4 (PD + e) operations for the first PD epilogues of a tile, 8 PD from then on.
+  template <int E, int V>
+  __device__ __forceinline__ void bwd_value(const f32x16& acc) {
+    constexpr int lz = D - 2 - (E >> 3), mm = E & 7, set = E % (PN_PD + 1), g = V >> 2, j = V & 3;
+    if constexpr (V == 0) {
+      bwd_loads<E + PN_PD>();
+      w2_wait4<(E < PN_PD ? 4 * (PN_PD + E) : 8 * PN_PD)>(pz[set]);
     }
-    hbuf[(E >> 3) & 1][2 * mm] = pack8(dz);
-    hbuf[(E >> 3) & 1][2 * mm + 1] = pack8(dz + 8);
-    pin(hbuf[(E >> 3) & 1][2 * mm]);
-    pin(hbuf[(E >> 3) & 1][2 * mm + 1]);
-    asm volatile("" : "+v"(amax));  // (the running maximum too: sunk to the kernel's end it kept every dZ alive -- in scratch)
+    const unsigned pw = pz[set][g];
+    const float c = __builtin_amdgcn_cosf((float)((pw >> (8 * j)) & 255u) * 0.00390625f);
+    const float dz = acc[V] * c;
+    if constexpr (j & 1) {
+      amax = fmaxf(amax, fmaxf(fabsf(eprev), fabsf(dz)));
+      epk = (unsigned)__builtin_amdgcn_cvt_pk_bf8_f32(eprev, dz, j == 1 ? 0 : (int)epk, j == 3);
+      unsigned d = pack_bf16(eprev, dz);
+      asm volatile("" : "+v"(d), "+v"(epk));
+      hb[(E >> 3) & 1][2 * mm + (V >> 3)][(V >> 1) & 3] = d;
+    } else {
+      eprev = dz;
+      asm volatile("" : "+v"(eprev));
+    }
+    if constexpr (j == 3) {
+      constexpr int so0 = ((D - 1 + lz) * W2_TENSOR_DWORDS + 8 * mm * W2_HALF) * 4;  // w2_stash_G(lz, D), quad 8 mm
+      __builtin_amdgcn_raw_buffer_store_b32(epk, rs_tile, voff, so0 + 2 * g * W2_HALF * 4, 0);
+    }
+    if constexpr (V == 15) asm volatile("" : "+v"(amax));  // (sunk to the kernel's end the maximum kept every dZ alive)
+  }
+  template <int E, int RATE, int T>
+  __device__ __forceinline__ void bwd_slice(const f32x16& acc) {
+    if constexpr (RATE == 1) {
+      bwd_value<E, T>(acc);
+    } else if constexpr (T < 8) {
+      bwd_value<E, 2 * T>(acc);
+      bwd_value<E, 2 * T + 1>(acc);
+    }
   }
   template <int E>
-  __device__ __forceinline__ void bwd_step(const f32x16& acc) {
-    bwd_loads<E + PN_PD>();
-    epi_bwd<E>(acc);
+  __device__ __forceinline__ void epi_bwd(const f32x16& acc) {  // a whole epilogue at once
+    static_for<0, 16>([&](auto vc) { bwd_value<E, decltype(vc)::value>(acc); });
+  }
+
+  // -------- one row block: 16 K-steps of panel p against the 16 B operands b, MFMA t followed by slice(t).  The sixteen
+  // MFMAs are one dependent chain (a single accumulator).  Fragment reads: eight up front, then one per slot.
+  template <class Slice>
+  __device__ __forceinline__ void block(f32x16& acc, int p, const u32x4 (&b)[16], Slice&& slice) {
+    bf16x8 A[16];
+    const unsigned pb = pn_base(r, p);
+    static_for<0, 8>([&](auto tc) { A[decltype(tc)::value] = pn_frag(r, pb, decltype(tc)::value); });
+    acc = zero16();
+    static_for<0, 16>([&](auto tc) {
+      constexpr int t = decltype(tc)::value;
+      if constexpr (t < 8) A[t + 8] = pn_frag(r, pb, t + 8);
+      acc = mfma_bf16(A[t], __builtin_bit_cast(bf16x8, b[t]), acc);
+      slice(tc);
+      __builtin_amdgcn_sched_barrier(0);
+    });
   }
 
   // -------- the tile ------------------------------------------------------------------------------------------------
@@ -383,88 +433,92 @@ struct SirenTile {
     if constexpr (FWD) {
       // ================================ layer 0 ================================
       // 2E encoder features per coordinate, generated per K-step on the vector ALUs (half 0: sines, half 1: cosines of
-      // features 8t .. 8t+7), contraction outermost: eight accumulator blocks.  Role A forms the features of chunk
-      // ch + 1 behind the MFMAs of chunk ch, role B those of chunk ch in front of them.
+      // features 8t .. 8t+7), contraction outermost: eight accumulator blocks.  A chunk = 4 K-steps x 8 row blocks = 32
+      // slots of  [MFMA][one feature of the NEXT chunk]; the fragments of a K-step are read during the K-step before.
       {
         f32x16 acc8[8];
-        bf16x8 bq[4];
-        auto gen = [&](int ch) {
-#pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            const int t = 4 * ch + s;
-            float f[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              const float* bj = encB_lds + 3 * (8 * t + j);
-#ifdef EXP_NOFRACT
-              f[j] = __builtin_amdgcn_sinf(fmaf(x2, bj[2], fmaf(x1, bj[1], fmaf(x0, bj[0], quarter))));
-#else
-              f[j] = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(fmaf(x2, bj[2], fmaf(x1, bj[1], fmaf(x0, bj[0], quarter)))));
-#endif
-            }
-            bq[s] = pack8(f);
-          }
+        u32x4 bq[2][4];  // B operands of the chunk being multiplied / being generated
+        bf16x8 A[2][8];
+        float fprev = 0.f;
+        // feature j of K-step s of chunk ch into dst; the feature's row of the encoder matrix was read from LDS a slot
+        // earlier (nb), the next one's (of chunk chn: the same chunk, or the next behind its last feature) is read here
+        f32x4 nb[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};  // rows of features q, q+1 (set q & 1), read two slots ahead
+        auto enc_row = [&](int ch, int q, f32x4& dst) {  // q = 8 s + j < 32
+          dst = *reinterpret_cast<const f32x4*>(encB_lds + 4 * (32 * ch + q));
         };
-        auto mma_chunk = [&]() {  // panels r.p (K-steps 0, 1 of the chunk) and r.p + 1 (K-steps 2, 3)
-#pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            bf16x8 A[8];
-#pragma unroll
-            for (int m = 0; m < 8; ++m) A[m] = pn_frag(r, r.p + (s >> 1), (s & 1) * 8 + m);
-#pragma unroll
-            for (int m = 0; m < 8; ++m) acc8[m] = mfma_bf16(A[m], bq[s], acc8[m]);
+        auto gen_value = [&](int ch, int chn, auto SC, auto JC, u32x4 (&dst)[4]) {
+          constexpr int s = decltype(SC)::value, j = decltype(JC)::value, q = 8 * s + j;
+          const f32x4 b = nb[q & 1];
+          const float f = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(fmaf(x2, b[2], fmaf(x1, b[1], fmaf(x0, b[0], quarter)))));
+          if constexpr (q + 2 < 32)
+            enc_row(ch, q + 2, nb[q & 1]);
+          else
+            enc_row(chn, q + 2 - 32, nb[q & 1]);
+          if constexpr (j & 1) {
+            unsigned d = pack_bf16(fprev, f);
+            asm volatile("" : "+v"(d));
+            dst[s][j >> 1] = d;
+          } else {
+            fprev = f;
+            asm volatile("" : "+v"(fprev));
           }
         };
         if (ACTIVE) {
 #pragma unroll
           for (int m = 0; m < 8; ++m) acc8[m] = zero16();
-          if (!RB) gen(0);
+          enc_row(0, 0, nb[0]);
+          enc_row(0, 1, nb[1]);
+          static_for<0, 4>([&](auto sc) { static_for<0, 8>([&](auto jc) { gen_value(0, nq0 > 1 ? 1 : 0, sc, jc, bq[0]); }); });
         }
-        for (int ch = 0; ch < nq0; ++ch) {
-          pn_begin<pn_n0(2, 2)>(r);  // (behind a pair of row blocks, a layer-0 chunk, or -- MODE_FWD -- the last layer: 8 <= 10)
-          if (ACTIVE) {
-            if (RB) gen(ch);
-            mma_chunk();
-            pn_request(r);
-            if (!RB && ch + 1 < nq0) gen(ch + 1);
-          } else {
-            pn_request(r);
-          }
-          r.p += 2;
+        for (int ch = 0; ch < nq0; ch += 2) {  // two chunks a trip: the B operand sets alternate at compile time
+          static_for<0, 2>([&](auto hc) {
+            constexpr int hh = decltype(hc)::value;
+            const int chh = ch + hh;
+            if (chh < nq0) {
+              pn_begin<pn_n0(2, 2)>(r);  // (behind a pair of row blocks, a layer-0 chunk, or -- MODE_FWD -- the last layer: 8 <= 10)
+              if (ACTIVE) {
+                const int nxt = chh + 1 < nq0 ? chh + 1 : chh;  // (past the end: the last chunk again, never multiplied)
+                const int nxt2 = nxt + 1 < nq0 ? nxt + 1 : nxt;
+                const unsigned pb[2] = {pn_base(r, r.p), pn_base(r, r.p + 1)};  // K-steps 0, 1 / 2, 3 of the chunk
+                static_for<0, 8>([&](auto mc) { A[0][decltype(mc)::value] = pn_frag(r, pb[0], decltype(mc)::value); });
+                static_for<0, 4>([&](auto sc) {
+                  constexpr int s = decltype(sc)::value;
+                  static_for<0, 8>([&](auto mc) {
+                    constexpr int m = decltype(mc)::value;
+                    if constexpr (s < 3) A[(s + 1) & 1][m] = pn_frag(r, pb[(s + 1) >> 1], ((s + 1) & 1) * 8 + m);
+                    acc8[m] = mfma_bf16(A[s & 1][m], __builtin_bit_cast(bf16x8, bq[hh][s]), acc8[m]);
+                    gen_value(nxt, nxt2, sc, mc, bq[hh ^ 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                  });
+                });
+              }
+              pn_request(r);
+              r.p += 2;
+            }
+          });
         }
         INR_STAMP(si); ++si;
-        // epilogue of layer 0, all eight row blocks (both roles: the 128 accumulator registers are free before the
-        // hidden layers, which keep two sets of B operands)
+        // epilogue of layer 0, all eight row blocks
         if (ACTIVE) static_for<0, 8>([&](auto mc) { epi_fwd<0, decltype(mc)::value>(acc8[decltype(mc)::value]); });
         INR_STAMP(si); ++si;
       }
 
       // ================================ hidden layers 1 .. D-2, row block by row block ================================
-      // Two row blocks (two panels) per barrier: role A runs  M E M E,  role B  E M E M  (its first epilogue belongs to
-      // the row block before) -- complementary without a barrier in the middle, and half as many rendezvous of eight
-      // waves (with one per row block half of all wave cycles were spent waiting: PMC, SQ_WAIT_ANY).
-      f32x16 acc = zero16();
+      // Two row blocks (two panels) per barrier.  Row block i = 8 (l - 1) + m carries the epilogue of row block i - 1.
       static_for<0, 4 * NH>([&](auto ic) {
         constexpr int I = decltype(ic)::value, i0 = 2 * I, l = 1 + (i0 >> 3), m0 = i0 & 7;
         // the requests behind the interval's panels (two consumed here, two by the interval in front, a layer-0 chunk or a
         // pair of row blocks); + 8 stores for each of the (up to two) intervals in front, counted from the second one
-        // (role B's first has one epilogue only)
+        // (the first interval's first row block carries no epilogue)
         constexpr int N0 = pn_n0(2, 2);
         pn_begin<(ACTIVE ? N0 + 8 * pn_min(2, pn_max(0, I - 1)) : N0)>(r);
         if (ACTIVE) {
-          if (RB) {
-            if constexpr (i0 > 0) epi_fwd<1 + ((i0 - 1) >> 3), (i0 - 1) & 7>(acc);
-            acc = pn_mma_block(r, r.p, hbuf[(l - 1) & 1]);
-            pn_request(r);
-            epi_fwd<l, m0>(acc);
-            acc = pn_mma_block(r, r.p + 1, hbuf[(l - 1) & 1]);
-          } else {
-            acc = pn_mma_block(r, r.p, hbuf[(l - 1) & 1]);
-            pn_request(r);
-            epi_fwd<l, m0>(acc);
-            acc = pn_mma_block(r, r.p + 1, hbuf[(l - 1) & 1]);
-            epi_fwd<l, m0 + 1>(acc);
-          }
+          block(acc2[0], r.p, hb[(l - 1) & 1], [&](auto tc) {
+            // (m0 == 0: the epilogue of the layer below's last row block, whose B operands this block's last K-steps read)
+            if constexpr (i0 > 0) fwd_slice<1 + ((i0 - 1) >> 3), (i0 - 1) & 7, (m0 == 0 ? 2 : 1), decltype(tc)::value>(acc2[1]);
+          });
+          pn_request(r);
+          block(acc2[1], r.p + 1, hb[(l - 1) & 1], [&](auto tc) { fwd_slice<l, m0, 1, decltype(tc)::value>(acc2[0]); });
         } else {
           pn_request(r);
         }
@@ -477,8 +531,8 @@ struct SirenTile {
       // ================================ last layer: one row block (rows 0 .. out_f-1 live) ================================
       pn_begin<(ACTIVE ? pn_n0(2, 1) + 8 * 2 : pn_n0(2, 1))>(r);
       if (ACTIVE) {
-        if (RB) epi_fwd<NH, 7>(acc);
-        const f32x16 accL = pn_mma_block(r, r.p, hbuf[NH & 1]);
+        block(acc2[0], r.p, hb[NH & 1], [&](auto tc) { fwd_slice<NH, 7, 2, decltype(tc)::value>(acc2[1]); });
+        const f32x16& accL = acc2[0];
         pn_request(r);
         float y[4], dy[4], g[4];
 #pragma unroll
@@ -516,7 +570,6 @@ struct SirenTile {
       // ================================ dH_{D-2} = W_last^T dZ_last: one K-step, eight row blocks ================================
       pn_begin<(MODE == MODE_BWD ? pn_n0(2, 1) : pn_n0(1, 1))>(r);  // behind the last layer, or the tile before's last pair
       pn_request(r);
-      f32x16 acc = zero16();
       if (ACTIVE) {
         // dZ_last rows (0,1), (2,3) of this coordinate as fp16 pairs: two dwords behind the 8-bit tensors
         if (half == 0 && ts_bytes != 0) {
@@ -527,36 +580,34 @@ struct SirenTile {
         float v[8] = {dzl[0], dzl[1], dzl[2], dzl[3], 0.f, 0.f, 0.f, 0.f};
         const bf16x8 b0 = pack8(v);  // k = output row: element j of half 0 is row j for j < 4
         static_for<0, PN_PD>([&](auto ec) { bwd_loads<decltype(ec)::value>(); });
+        // the MFMA of row block m + 1 is on the pipe while the epilogue of row block m runs
+        const unsigned pb = pn_base(r, r.p);
+        acc2[0] = mfma_bf16(pn_frag(r, pb, 0), b0, zero16());
         static_for<0, 8>([&](auto mc) {
           constexpr int m = decltype(mc)::value;
-          bwd_step<m>(mfma_bf16(pn_frag(r, r.p, m), b0, zero16()));
+          if constexpr (m < 7) acc2[(m + 1) & 1] = mfma_bf16(pn_frag(r, pb, m + 1), b0, zero16());
+          epi_bwd<m>(acc2[m & 1]);
+          __builtin_amdgcn_sched_barrier(0);
         });
       }
       r.p += 1;
       INR_STAMP(si); ++si;
 
       // ================================ dH_{l-1} = W_l^T dZ_l, l = D-2 .. 1, row block by row block ================================
+      // Row block j = 8 li + m carries backward epilogue 8 + j - 1 (row block j - 1 of this sequence; the first one has
+      // none: the eight epilogues of dZ_{D-2} ran above).
       static_for<0, 4 * NH>([&](auto jc) {
         constexpr int J = decltype(jc)::value, j0 = 2 * J, li = j0 >> 3, m0 = j0 & 7;
-        // + 16 stash operations for each of the (up to two) intervals in front, counted from the second (role B's first has
-        // one epilogue only)
+        // + 16 stash operations for each of the (up to two) intervals in front, counted from the second (the first
+        // interval's first row block carries no epilogue)
         constexpr int N0 = J == 0 ? pn_n0(1, 2) : pn_n0(2, 2);
         pn_begin<(ACTIVE ? pn_min(63, N0 + 16 * pn_min(2, pn_max(0, J - 1))) : N0)>(r);
         if (ACTIVE) {
-          // epilogue 8 (li + 1) + m: row block m of dZ_{l-1}, l = D-2-li
-          if (RB) {
-            if constexpr (j0 > 0) bwd_step<8 + j0 - 1>(acc);
-            acc = pn_mma_block(r, r.p, hbuf[li & 1]);
-            pn_request(r);
-            bwd_step<8 + j0>(acc);
-            acc = pn_mma_block(r, r.p + 1, hbuf[li & 1]);
-          } else {
-            acc = pn_mma_block(r, r.p, hbuf[li & 1]);
-            pn_request(r);
-            bwd_step<8 + j0>(acc);
-            acc = pn_mma_block(r, r.p + 1, hbuf[li & 1]);
-            bwd_step<8 + j0 + 1>(acc);
-          }
+          block(acc2[0], r.p, hb[li & 1], [&](auto tc) {
+            if constexpr (j0 > 0) bwd_slice<8 + j0 - 1, (m0 == 0 ? 2 : 1), decltype(tc)::value>(acc2[1]);
+          });
+          pn_request(r);
+          block(acc2[1], r.p + 1, hb[li & 1], [&](auto tc) { bwd_slice<8 + j0, 1, decltype(tc)::value>(acc2[0]); });
         } else {
           pn_request(r);
         }
@@ -565,7 +616,7 @@ struct SirenTile {
           INR_STAMP(si); ++si;
         }
       });
-      if (ACTIVE && RB) bwd_step<NE - 1>(acc);  // role B's last epilogue: row block 7 of dZ_0
+      if (ACTIVE) epi_bwd<NE - 1>(acc2[1]);  // the last epilogue: row block 7 of dZ_0
       INR_STAMP(si); ++si;
     }
   }
@@ -587,11 +638,12 @@ __global__ __launch_bounds__(512, 2) void inr_siren_bf16_kernel(const NetDesc nd
   if (w >= 4) __builtin_amdgcn_s_setprio(1);
 #endif
   float* bias_lds = reinterpret_cast<float*>(lds_raw + PN_SLOTS * W2_PANEL_BYTES);  // [D][256]
-  float* encB_lds = bias_lds + D * 256;                                             // [E][3]
-  float* red_lds = encB_lds + 3 * nd.E;                                             // [8]
+  float* encB_lds = bias_lds + D * 256;                                             // [E][4]
+  float* red_lds = encB_lds + 4 * nd.E;                                             // [8]
   const int E = nd.E;
   for (int i = tid; i < D * 256; i += 64 * NW) bias_lds[i] = a.packed[nd.w2_bias_off + i];
-  for (int i = tid; i < 3 * E; i += 64 * NW) encB_lds[i] = a.encB != nullptr ? a.encB[i] : 0.f;
+  for (int i = tid; i < 4 * E; i += 64 * NW)  // rows padded to 16 bytes: one broadcast read per feature
+    encB_lds[i] = (a.encB != nullptr && (i & 3) != 3) ? a.encB[3 * (i >> 2) + (i & 3)] : 0.f;
   PnRing r;
   r.gbase = reinterpret_cast<const char*>(a.packed + nd.w2_off);
   r.ring = lds_raw;
@@ -614,16 +666,12 @@ __global__ __launch_bounds__(512, 2) void inr_siren_bf16_kernel(const NetDesc nd
   const int tpw = a.n_tiles > 256 ? 2 : 1;
   const int n_wtiles = (a.n_tiles + tpw - 1) / tpw;
   float loss_acc = 0.f, amax = 0.f;
-  if (w < 4) {
-    SirenTile<MODE, NH, false, true> t(nd, ld, a, r, bias_lds, encB_lds, lane, w, mult);
-    for (int wtile = blockIdx.x; wtile < n_wtiles; wtile += gridDim.x) t.run(tpw * wtile);
-    loss_acc = t.loss_acc, amax = t.amax;
-  } else if (tpw == 2) {
-    SirenTile<MODE, NH, true, true> t(nd, ld, a, r, bias_lds, encB_lds, lane, w, mult);
-    for (int wtile = blockIdx.x; wtile < n_wtiles; wtile += gridDim.x) t.run(tpw * wtile + 1);
+  if (w < 4 || tpw == 2) {
+    SirenTile<MODE, NH, true> t(nd, ld, a, r, bias_lds, encB_lds, lane, w, mult);
+    for (int wtile = blockIdx.x; wtile < n_wtiles; wtile += gridDim.x) t.run(tpw * wtile + (w >> 2));
     loss_acc = t.loss_acc, amax = t.amax;
   } else {
-    SirenTile<MODE, NH, true, false> t(nd, ld, a, r, bias_lds, encB_lds, lane, w, mult);
+    SirenTile<MODE, NH, false> t(nd, ld, a, r, bias_lds, encB_lds, lane, w, mult);
     for (int wtile = blockIdx.x; wtile < n_wtiles; wtile += gridDim.x) t.run(0);
   }
   // every DMA this wave issued has landed before the workgroup (and its LDS) goes away
@@ -657,7 +705,7 @@ __global__ __launch_bounds__(512, 2) void inr_siren_bf16_kernel(const NetDesc nd
 
 template <int MODE, int NH>
 inline hipError_t launch_siren_bf16_nh(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int grid, hipStream_t st) {
-  const size_t lds_bytes = (size_t)PN_SLOTS * W2_PANEL_BYTES + ((size_t)nd.D * 256 + 3 * (size_t)nd.E + PN_WAVES) * sizeof(float);
+  const size_t lds_bytes = (size_t)PN_SLOTS * W2_PANEL_BYTES + ((size_t)nd.D * 256 + 4 * (size_t)nd.E + PN_WAVES) * sizeof(float);
   if (lds_bytes > 160 * 1024 || a.save_by_block) return hipErrorInvalidValue;
   if (MODE != MODE_FWD && (a.save == nullptr || a.dz_state == nullptr)) return hipErrorInvalidValue;
   if (MODE == MODE_FUSED && a.slabs == nullptr) return hipErrorInvalidValue;
