@@ -44,9 +44,9 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-constexpr int PN_SLOTS = 8;   // ring slots of W2_PANEL_BYTES: seven panels in flight ahead of the one being multiplied
-constexpr int PN_LOOK = PN_SLOTS - 2;  // intervals in front whose stash operations lie behind a panel's request
-constexpr int PN_WAVES = 8;   // waves per workgroup; each issues 16 / 8 = 2 of a panel's 1 KB LDS-DMA pieces
+constexpr int PN_SLOTS = 8;   // ring slots of W2_PANEL_BYTES
+constexpr int PN_WAVES = 8;   // waves per workgroup; each moves 16 / 8 = 2 of a panel's 1 KB pieces
+constexpr int PN_FD = 6;      // A fragments read ahead of the MFMA that takes them
 #ifndef PN_PD_N
 #define PN_PD_N 3
 #endif
@@ -95,32 +95,31 @@ __device__ __forceinline__ void phase_byte(unsigned& word, float t, float magic)
 }
 
 // ---- the panel ring ---------------------------------------------------------------------------------------------
-// Stream position p lives in slot p & 7.  An INTERVAL consumes c panels (two per layer-0 chunk, one everywhere else):
-//   pn_begin<N>():  s_waitcnt vmcnt(N) -- this wave's pieces of the interval's panels have landed --, s_barrier --
-//   everybody's have, and everybody is done with the panels of the previous interval;
-//   pn_request():  up to position p + 7 into the slots that barrier freed -- issued BEHIND the interval's MFMAs, whose
-//   execution hides the 100-odd cycles an LDS-DMA instruction takes to issue (in front of them they were on the critical
-//   path of every interval).
-// N: the vector-memory counter retires IN ORDER, so "at most N operations outstanding" covers a panel when at least N
-// operations were issued after its pieces.  Behind the pieces of the interval's last panel lie the requests of the
-// panels after it: two pieces each, 8 - c_prev - c panels (c_prev: what the previous interval consumed) -- pn_n0().  On
-// top, where the intervals in front are known to have issued S stash operations each (the hidden layers: 4 stores
-// forward, 4 loads + 4 stores backward, instructions that are issued unconditionally), S for each of the h <= 6 such
-// intervals directly in front (a panel is requested at the END of the interval seven before its own: role B has nothing
-// behind that request in the same interval).  A smaller N only waits longer.
+// Stream position p lives in slot p & 7.  An INTERVAL consumes c panels (two per layer-0 chunk or pair of row blocks, one
+// for the last layer and for its transpose) between two barriers.  How a panel gets there:
+//   * the first four intervals' panels (eight positions; seven where the stream starts with a one-panel interval) by
+//     LDS-DMA from the kernel's prologue, waited for there;
+//   * every later one through REGISTERS: interval k loads the panels of interval k + 4 (two 16-byte global loads per
+//     wave and panel) and stores the ones it loaded an interval ago -- interval k + 3's -- into their slots (two
+//     ds_write_b128), which interval k - 1 was the last to read.  pn_stage<CW, CL>(): CW panels written, CL loaded.
+// Why not LDS-DMA all the way (rounds 2-3a): measured by knock-out, the 1056 DMA instructions a workgroup issues per tile
+// pair cost 32 of the kernel's 112 us at 65 536 rows -- ~350 cycles of a wave's issue per 1 KB piece beside MFMAs and LDS
+// reads -- against ~30 for a load + a store of the same piece, at 16 registers.
+//   pn_begin():  own LDS stores done, s_barrier -- everybody's are, and everybody is done with the interval before.
 struct PnRing {
   const char* gbase;  // panel 0 of the image
   char* ring;
   int first, len;     // the stream cycles through images [first, first + len)
   int p;              // next position to consume
-  int req, req_img;   // next position to request, its image (relative to first)
+  int req, req_img;   // next position to put into LDS; image (relative to first) of the next panel to LOAD
   int w, lane;
+  bool staged;        // st holds the panels of positions req ..
+  u32x4 st[2][2];     // staged panels: this wave's two 1 KB pieces of each
 };
-constexpr int pn_n0(int c_prev, int c) { return 2 * (PN_SLOTS - c_prev - c); }
 constexpr int pn_min(int a, int b) { return a < b ? a : b; }
 constexpr int pn_max(int a, int b) { return a > b ? a : b; }
 
-__device__ __forceinline__ void pn_issue(const PnRing& r, int img, int slot) {
+__device__ __forceinline__ void pn_issue(const PnRing& r, int img, int slot) {  // LDS-DMA (prologue)
   const char* src = r.gbase + (size_t)img * W2_PANEL_BYTES + (size_t)(2 * r.w) * 1024 + r.lane * 16;
   char* dst = r.ring + slot * W2_PANEL_BYTES + (2 * r.w) * 1024;
 #pragma unroll
@@ -128,18 +127,61 @@ __device__ __forceinline__ void pn_issue(const PnRing& r, int img, int slot) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + n * 1024),
                                      (__attribute__((address_space(3))) void*)(dst + n * 1024), 16, 0, 0);
 }
-__device__ __forceinline__ void pn_request(PnRing& r) {
-  while (r.req < r.p + PN_SLOTS) {
+__device__ __forceinline__ void pn_prime(PnRing& r, int n) {
+  for (int i = 0; i < n; ++i) {
     pn_issue(r, r.first + r.req_img, r.req & (PN_SLOTS - 1));
     ++r.req;
     if (++r.req_img == r.len) r.req_img = 0;
   }
+  r.staged = false;
 }
-template <int N>
+template <int CW, int CL>
+__device__ __forceinline__ void pn_stage(PnRing& r) {
+#ifdef EXP_NODMA  // timing experiment: the panels are never fetched (results meaningless)
+  return;
+#endif
+  if (r.staged) {
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+      char* dst = r.ring + (r.req & (PN_SLOTS - 1)) * W2_PANEL_BYTES + (2 * r.w) * 1024 + r.lane * 16;
+#ifdef EXP_NOPWRITE  // timing experiment: panels loaded, never stored to LDS
+      asm volatile("" ::"v"(r.st[c][0]), "v"(r.st[c][1]));
+#else
+      *reinterpret_cast<u32x4*>(dst) = r.st[c][0];
+      *reinterpret_cast<u32x4*>(dst + 1024) = r.st[c][1];
+#endif
+      ++r.req;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < CL; ++c) {
+    const char* src = r.gbase + (size_t)(r.first + r.req_img) * W2_PANEL_BYTES + (size_t)(2 * r.w) * 1024 + r.lane * 16;
+#ifdef EXP_NOPLOAD  // timing experiment: nothing loaded, whatever the registers hold is stored
+    asm volatile("" : "+v"(r.st[c][0]), "+v"(r.st[c][1]) : "v"(src));
+#else
+    r.st[c][0] = *reinterpret_cast<const u32x4*>(src);
+    r.st[c][1] = *reinterpret_cast<const u32x4*>(src + 1024);
+#endif
+    if (++r.req_img == r.len) r.req_img = 0;
+  }
+  r.staged = true;
+}
 __device__ __forceinline__ void pn_begin(PnRing& r) {
-  static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit field");
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifndef EXP_NOBARRIER  // timing experiment: no rendezvous (results meaningless)
   __builtin_amdgcn_s_barrier();
+#endif
+}
+// panels of the interval `idx` places behind hidden-layer interval 0 of the forward (bwd = false) or backward sequence:
+// 2, but 1 for the last layer and the first backward interval (MODE_FUSED: both, back to back behind the forward
+// intervals; MODE_FWD: the last layer only; MODE_BWD: the first backward interval of the NEXT tile behind the backward ones)
+template <int MODE, int NH>
+constexpr int pn_c(bool bwd, int idx) {
+  if (!bwd) {
+    if (MODE == MODE_FUSED) return idx < 4 * NH ? 2 : (idx < 4 * NH + 2 ? 1 : 2);
+    return idx == 4 * NH ? 1 : 2;
+  }
+  return (MODE == MODE_BWD && idx == 4 * NH) ? 1 : 2;
 }
 // fragment f of the panel at stream position p: ONE address register per panel (opaque to the compiler, which otherwise
 // forms the sixteen lane addresses up front, a register each, and adds the slot to every one of them) + f KB as an immediate
@@ -286,6 +328,9 @@ struct SirenTile {
   // slice T of 16 (RATE 1) or of 8 (RATE 2: two values, nothing behind slot 7)
   template <int L, int MM, int RATE, int T>
   __device__ __forceinline__ void fwd_slice(const f32x16& acc) {
+#ifdef EXP_NOSLICE  // timing experiment: no epilogue work behind the MFMAs of the hidden layers
+    return;
+#endif
     if constexpr (RATE == 1) {
       fwd_value<L, MM, T>(acc);
     } else if constexpr (T < 8) {
@@ -351,6 +396,9 @@ struct SirenTile {
   }
   template <int E, int RATE, int T>
   __device__ __forceinline__ void bwd_slice(const f32x16& acc) {
+#ifdef EXP_NOSLICE
+    return;
+#endif
     if constexpr (RATE == 1) {
       bwd_value<E, T>(acc);
     } else if constexpr (T < 8) {
@@ -364,19 +412,45 @@ struct SirenTile {
   }
 
   // -------- one row block: 16 K-steps of panel p against the 16 B operands b, MFMA t followed by slice(t).  The sixteen
-  // MFMAs are one dependent chain (a single accumulator).  Fragment reads: eight up front, then one per slot.
+  // MFMAs are one dependent chain (a single accumulator).  Fragment reads: PN_FD up front, then one per slot.
   template <class Slice>
   __device__ __forceinline__ void block(f32x16& acc, int p, const u32x4 (&b)[16], Slice&& slice) {
     bf16x8 A[16];
     const unsigned pb = pn_base(r, p);
-    static_for<0, 8>([&](auto tc) { A[decltype(tc)::value] = pn_frag(r, pb, decltype(tc)::value); });
+    static_for<0, PN_FD>([&](auto tc) { A[decltype(tc)::value] = pn_frag(r, pb, decltype(tc)::value); });
     acc = zero16();
     static_for<0, 16>([&](auto tc) {
       constexpr int t = decltype(tc)::value;
-      if constexpr (t < 8) A[t + 8] = pn_frag(r, pb, t + 8);
+      if constexpr (t + PN_FD < 16) A[t + PN_FD] = pn_frag(r, pb, t + PN_FD);
       acc = mfma_bf16(A[t], __builtin_bit_cast(bf16x8, b[t]), acc);
       slice(tc);
       __builtin_amdgcn_sched_barrier(0);
+    });
+  }
+  // -------- the two row blocks of an interval (panels p, p + 1; accumulators acc2[0], acc2[1]) as ONE stream of 32 slots:
+  // the second block's first fragments are read behind the first block's last MFMAs (a block that starts with its own
+  // reads waits out an LDS latency with the matrix pipe idle -- under eight waves' reads, some hundreds of cycles);
+  // `between` (the panel staging) runs behind slot 15.
+  template <class SliceA, class Between, class SliceB>
+  __device__ __forceinline__ void block_pair(int p, const u32x4 (&b)[16], SliceA&& slice_a, Between&& between, SliceB&& slice_b) {
+    bf16x8 A[32];
+    const unsigned pb0 = pn_base(r, p), pb1 = pn_base(r, p + 1);
+    static_for<0, PN_FD>([&](auto tc) { A[decltype(tc)::value] = pn_frag(r, pb0, decltype(tc)::value); });
+    static_for<0, 32>([&](auto qc) {
+      constexpr int q = decltype(qc)::value, nq = q + PN_FD;
+#ifdef EXP_NOFRAG  // timing experiment: one fragment read per interval, multiplied 32 times (results meaningless)
+      if constexpr (nq < 32) A[nq] = A[0];
+#else
+      if constexpr (nq < 32) A[nq] = pn_frag(r, nq < 16 ? pb0 : pb1, nq & 15);
+#endif
+      // (acc2[1] still feeds the first block's slices: it is cleared by its own first MFMA)
+      acc2[q >> 4] = mfma_bf16(A[q], __builtin_bit_cast(bf16x8, b[q & 15]), (q & 15) == 0 ? zero16() : acc2[q >> 4]);
+      if constexpr (q < 16)
+        slice_a(std::integral_constant<int, q>{});
+      else
+        slice_b(std::integral_constant<int, q - 16>{});
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (q == 15) between();
     });
   }
 
@@ -475,7 +549,7 @@ struct SirenTile {
             constexpr int hh = decltype(hc)::value;
             const int chh = ch + hh;
             if (chh < nq0) {
-              pn_begin<pn_n0(2, 2)>(r);  // (behind a pair of row blocks, a layer-0 chunk, or -- MODE_FWD -- the last layer: 8 <= 10)
+              pn_begin(r);
               if (ACTIVE) {
                 const int nxt = chh + 1 < nq0 ? chh + 1 : chh;  // (past the end: the last chunk again, never multiplied)
                 const int nxt2 = nxt + 1 < nq0 ? nxt + 1 : nxt;
@@ -487,12 +561,14 @@ struct SirenTile {
                     constexpr int m = decltype(mc)::value;
                     if constexpr (s < 3) A[(s + 1) & 1][m] = pn_frag(r, pb[(s + 1) >> 1], ((s + 1) & 1) * 8 + m);
                     acc8[m] = mfma_bf16(A[s & 1][m], __builtin_bit_cast(bf16x8, bq[hh][s]), acc8[m]);
+#ifndef EXP_NOGEN  // timing experiment: layer 0 multiplies the first chunk's features again and again
                     gen_value(nxt, nxt2, sc, mc, bq[hh ^ 1]);
+#endif
                     __builtin_amdgcn_sched_barrier(0);
                   });
                 });
               }
-              pn_request(r);
+              pn_stage<2, 2>(r);
               r.p += 2;
             }
           });
@@ -507,20 +583,18 @@ struct SirenTile {
       // Two row blocks (two panels) per barrier.  Row block i = 8 (l - 1) + m carries the epilogue of row block i - 1.
       static_for<0, 4 * NH>([&](auto ic) {
         constexpr int I = decltype(ic)::value, i0 = 2 * I, l = 1 + (i0 >> 3), m0 = i0 & 7;
-        // the requests behind the interval's panels (two consumed here, two by the interval in front, a layer-0 chunk or a
-        // pair of row blocks); + 8 stores for each of the (up to two) intervals in front, counted from the second one
-        // (the first interval's first row block carries no epilogue)
-        constexpr int N0 = pn_n0(2, 2);
-        pn_begin<(ACTIVE ? N0 + 8 * pn_min(2, pn_max(0, I - 1)) : N0)>(r);
+        pn_begin(r);
         if (ACTIVE) {
-          block(acc2[0], r.p, hb[(l - 1) & 1], [&](auto tc) {
-            // (m0 == 0: the epilogue of the layer below's last row block, whose B operands this block's last K-steps read)
-            if constexpr (i0 > 0) fwd_slice<1 + ((i0 - 1) >> 3), (i0 - 1) & 7, (m0 == 0 ? 2 : 1), decltype(tc)::value>(acc2[1]);
-          });
-          pn_request(r);
-          block(acc2[1], r.p + 1, hb[(l - 1) & 1], [&](auto tc) { fwd_slice<l, m0, 1, decltype(tc)::value>(acc2[0]); });
+          block_pair(
+              r.p, hb[(l - 1) & 1],
+              [&](auto tc) {
+                // (m0 == 0: the epilogue of the layer below's last row block, whose B operands this block's last K-steps read)
+                if constexpr (i0 > 0) fwd_slice<1 + ((i0 - 1) >> 3), (i0 - 1) & 7, (m0 == 0 ? 2 : 1), decltype(tc)::value>(acc2[1]);
+              },
+              [&]() { pn_stage<pn_c<MODE, NH>(false, I + 3), pn_c<MODE, NH>(false, I + 4)>(r); },
+              [&](auto tc) { fwd_slice<l, m0, 1, decltype(tc)::value>(acc2[0]); });
         } else {
-          pn_request(r);
+          pn_stage<pn_c<MODE, NH>(false, I + 3), pn_c<MODE, NH>(false, I + 4)>(r);
         }
         r.p += 2;
         if constexpr (m0 == 6) {
@@ -529,11 +603,11 @@ struct SirenTile {
       });
 
       // ================================ last layer: one row block (rows 0 .. out_f-1 live) ================================
-      pn_begin<(ACTIVE ? pn_n0(2, 1) + 8 * 2 : pn_n0(2, 1))>(r);
+      pn_begin(r);
       if (ACTIVE) {
         block(acc2[0], r.p, hb[NH & 1], [&](auto tc) { fwd_slice<NH, 7, 2, decltype(tc)::value>(acc2[1]); });
         const f32x16& accL = acc2[0];
-        pn_request(r);
+        pn_stage<2, 2>(r);
         float y[4], dy[4], g[4];
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
@@ -552,7 +626,7 @@ struct SirenTile {
           *reinterpret_cast<f32x4*>(sv + w2_stash_dy(D) + 4 * wcol) = d4;
         }
       } else {
-        pn_request(r);
+        pn_stage<2, 2>(r);
       }
       r.p += 1;
       INR_STAMP(si); ++si;
@@ -568,8 +642,8 @@ struct SirenTile {
         }
       }
       // ================================ dH_{D-2} = W_last^T dZ_last: one K-step, eight row blocks ================================
-      pn_begin<(MODE == MODE_BWD ? pn_n0(2, 1) : pn_n0(1, 1))>(r);  // behind the last layer, or the tile before's last pair
-      pn_request(r);
+      pn_begin(r);
+      pn_stage<2, 2>(r);
       if (ACTIVE) {
         // dZ_last rows (0,1), (2,3) of this coordinate as fp16 pairs: two dwords behind the 8-bit tensors
         if (half == 0 && ts_bytes != 0) {
@@ -598,18 +672,17 @@ struct SirenTile {
       // none: the eight epilogues of dZ_{D-2} ran above).
       static_for<0, 4 * NH>([&](auto jc) {
         constexpr int J = decltype(jc)::value, j0 = 2 * J, li = j0 >> 3, m0 = j0 & 7;
-        // + 16 stash operations for each of the (up to two) intervals in front, counted from the second (the first
-        // interval's first row block carries no epilogue)
-        constexpr int N0 = J == 0 ? pn_n0(1, 2) : pn_n0(2, 2);
-        pn_begin<(ACTIVE ? pn_min(63, N0 + 16 * pn_min(2, pn_max(0, J - 1))) : N0)>(r);
+        pn_begin(r);
         if (ACTIVE) {
-          block(acc2[0], r.p, hb[li & 1], [&](auto tc) {
-            if constexpr (j0 > 0) bwd_slice<8 + j0 - 1, (m0 == 0 ? 2 : 1), decltype(tc)::value>(acc2[1]);
-          });
-          pn_request(r);
-          block(acc2[1], r.p + 1, hb[li & 1], [&](auto tc) { bwd_slice<8 + j0, 1, decltype(tc)::value>(acc2[0]); });
+          block_pair(
+              r.p, hb[li & 1],
+              [&](auto tc) {
+                if constexpr (j0 > 0) bwd_slice<8 + j0 - 1, (m0 == 0 ? 2 : 1), decltype(tc)::value>(acc2[1]);
+              },
+              [&]() { pn_stage<pn_c<MODE, NH>(true, J + 3), pn_c<MODE, NH>(true, J + 4)>(r); },
+              [&](auto tc) { bwd_slice<8 + j0, 1, decltype(tc)::value>(acc2[0]); });
         } else {
-          pn_request(r);
+          pn_stage<pn_c<MODE, NH>(true, J + 3), pn_c<MODE, NH>(true, J + 4)>(r);
         }
         r.p += 2;
         if constexpr (m0 == 6) {
@@ -651,8 +724,9 @@ __global__ __launch_bounds__(512, 2) void inr_siren_bf16_kernel(const NetDesc nd
   r.len = MODE == MODE_FUSED ? w2_np(D, E) : (MODE == MODE_FWD ? w2_n_fwd(D, E) : w2_np(D, E) - w2_n_fwd(D, E));
   r.p = 0, r.req = 0, r.req_img = 0;
   r.w = w, r.lane = lane;
-  pn_request(r);    // prime the ring: positions 0 .. 7
-  __syncthreads();  // tables in LDS (the DMAs are waited for by the first interval)
+  pn_prime(r, MODE == MODE_BWD ? 7 : 8);  // the first four intervals' panels
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();  // tables and panels in LDS
 
   // gradient-scale state (inr_w2.h): fused steps and split steps keep their own
   float* st = a.dz_state != nullptr ? a.dz_state + (MODE == MODE_BWD ? 4 : 0) : nullptr;
