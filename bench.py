@@ -218,16 +218,22 @@ def config5_percoil(dev, steps=15, warmup=4):
         spe = tr.steps_per_epoch
         for i in range(warmup):
             tr.step(0, i % spe)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(steps):
-            tr.step(0, (warmup + i) % spe)
-        torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / steps * 1e3
+        # wall clock over `steps` steps, best of three rounds: a step is ~10 launches for 0.7-4 ms of GPU work, and on a
+        # freshly started box the host side of the first rounds has measured up to 10x that
+        rounds = []
+        for rep in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                tr.step(0, (warmup + i) % spe)
+            torch.cuda.synchronize()
+            rounds.append((time.perf_counter() - t0) / steps * 1e3)
+        ms = min(rounds)
         peak = BF16_MFMA_PEAK_TFLOPS if prec == "bf16" else F32_MFMA_PEAK_TFLOPS
         ach = FLOP_PER_SAMPLE * tr.bs / (ms * 1e-3) / 1e12
         out[prec] = {"ms_per_step": ms, "coord_samples_per_s": tr.bs / (ms * 1e-3), "achieved_tflops": ach, "peak": peak,
-                     "frac": ach / peak, "sampled_fraction": float(tr.mask_cpu.float().mean())}
+                     "frac": ach / peak, "sampled_fraction": float(tr.mask_cpu.float().mean()),
+                     "rounds_ms": rounds}
         del tr
     out["bf16_speedup"] = out["f32"]["ms_per_step"] / out["bf16"]["ms_per_step"]
     return out

@@ -1,0 +1,21 @@
+#!/bin/bash
+# Everything a round commits under profiles/ (run on the GPU box from the repo root): tools/round_profiles.sh r03
+# Each step writes under gpurun_out/; a failing step stops the script (no GPU step behind a failed one).
+set -o pipefail
+R=${1:-r03}
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+echo "== bench"; timeout -k 10 400 python bench.py > gpurun_out/${R}_bench.json 2> gpurun_out/${R}_bench.err || { tail -5 gpurun_out/${R}_bench.err; exit 1; }
+echo "== kernel trace + PMC of the bench command"; timeout -k 10 900 bash tools/pmc_round.sh $R > gpurun_out/${R}_pmc_round.log 2>&1 || { tail -5 gpurun_out/${R}_pmc_round.log; exit 1; }
+echo "== bench_models"; timeout -k 10 400 python tools/bench_models.py > gpurun_out/${R}_bench_models.json 2> gpurun_out/${R}_bench_models.err || { tail -5 gpurun_out/${R}_bench_models.err; exit 1; }
+echo "== bf16 kernel durations by batch"; timeout -k 10 300 bash tools/prof_bf16.sh ${R}_bf16 65536 25000 > gpurun_out/${R}_prof_bf16.log 2>&1 || { tail -5 gpurun_out/${R}_prof_bf16.log; exit 1; }
+echo "== bf16 PMC"; timeout -k 10 600 bash tools/pmc_bf16.sh ${R}_bf16 65536 > gpurun_out/${R}_pmc_bf16.log 2>&1 || { tail -5 gpurun_out/${R}_pmc_bf16.log; exit 1; }
+echo "== stamps"
+for a in "65536 bf16" "25000 bf16" "25000 f32"; do
+  set -- $a
+  timeout -k 10 200 python3 tools/stamps.py $1 $2 > gpurun_out/${R}_stamps_$2_$1.txt 2>&1 || { tail -3 gpurun_out/${R}_stamps_$2_$1.txt; exit 1; }
+done
+echo "== rounding oracle distances"; timeout -k 10 300 python3 tools/debug_bf16_oracle.py 127 4133 32845 > gpurun_out/${R}_bf16_oracle_distances.txt 2>&1 || { tail -3 gpurun_out/${R}_bf16_oracle_distances.txt; exit 1; }
+echo "== probes"
+timeout -k 10 60 tools/probes/overlap_probe > gpurun_out/${R}_probe_overlap.txt 2>&1 && timeout -k 10 60 tools/probes/sinf16_probe > gpurun_out/${R}_probe_sinf16.txt 2>&1
+echo done
