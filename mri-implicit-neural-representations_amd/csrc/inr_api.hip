@@ -550,7 +550,7 @@ static bool dw_gemm_setup(const inr_plan* plan, int64_t nt, inr::DwGemmArgs* g, 
 // bf16 plans with the "weights in LDS" fused kernel: every weight gradient comes from inr_dw_gemm_bf16.hip
 static bool w2_plan(const inr_plan* plan) { return plan->nd.bf16 != 0; }
 
-constexpr double kEncCost = 1.33;
+constexpr double kEncCost = 1.5;
 static void dw_gemm_bf16_setup(const inr_plan* plan, int64_t nt, inr::DwGemmBf16Args* g) {
   const NetDesc& nd = plan->nd;
   memset(g, 0, sizeof(*g));
@@ -573,7 +573,7 @@ static void dw_gemm_bf16_setup(const inr_plan* plan, int64_t nt, inr::DwGemmBf16
   g->TL = W2_TL, g->E = nd.E;
   g->save_floats_per_tile = nd.save_floats_per_tile, g->slab_floats = nd.slab_floats, g->n_tiles = (int)nt;
   // About one workgroup per CU, in two classes (inr_dw_gemm_bf16.h): a first-layer unit costs kEncCost x a hidden unit per
-  // tile (measured at 65 536 rows, depth 5: 72 us against 54 when each kind runs alone), so it gets that many times the
+  // tile (65 536 rows, depth 5: 68 us against 54 when each kind runs alone; factors 1.0 / 1.15 / 1.33 / 1.5 / 1.7 measured 72.6 / 70.6 / 69.3 / 66.8 / 67.9 us), so it gets that many times the
   // chunks.  Needs the first layer's weight and bias gradients to be one aligned run of the flat layout (the reduction
   // sums that run over another number of slabs); otherwise one class.
   const int n_enc = (nd.E + 127) / 128, others = k - n_enc;
@@ -585,9 +585,11 @@ static void dw_gemm_bf16_setup(const inr_plan* plan, int64_t nt, inr::DwGemmBf16
     *n = (int)((nt + *tpc - 1) / *tpc);
   };
   if (run0 && getenv("INR_GEMM_ONE_CLASS") == nullptr) {
-    const double per = 256.0 / (kEncCost * n_enc + others);  // chunks of a non-first-layer unit
+    double cost = kEncCost;
+    if (const char* e = getenv("INR_GEMM_ENC_COST")) cost = std::max(1.0, atof(e));  // (tuning aid)
+    const double per = 256.0 / (cost * n_enc + others);  // chunks of a non-first-layer unit
     g->n_enc_units = n_enc;
-    chunks((int)(per * kEncCost), &g->tiles_per_chunk_enc, &g->n_chunks_enc);
+    chunks((int)(per * cost), &g->tiles_per_chunk_enc, &g->n_chunks_enc);
     chunks((256 - n_enc * g->n_chunks_enc) / others, &g->tiles_per_chunk, &g->n_chunks);
   } else {
     g->n_enc_units = n_enc;

@@ -28,15 +28,42 @@ def rel_l2(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
-def _pair(dev, seed, width=256, depth=5):
+def _pair(dev, seed, width=256, depth=5, enc_size=256):
     import inr_mi355x as M
-    net = dict(FULL_NET, network_width=width, network_depth=depth)
+    net = dict(FULL_NET, network_width=width, network_depth=depth, network_input_size=2 * enc_size)
     torch.manual_seed(seed)
-    enc = M.Positional_Encoder(FULL_ENC, device=dev)
+    enc = M.Positional_Encoder(dict(FULL_ENC, embedding_size=enc_size), device=dev)
     m32 = M.SIREN(net).to(dev)
     m16 = M.SIREN(net).to(dev)
     m16.load_state_dict(m32.state_dict())
-    return enc, m32, m16, m32.fused_engine(256), m16.fused_engine(256, precision="bf16")
+    return enc, m32, m16, m32.fused_engine(enc_size), m16.fused_engine(enc_size, precision="bf16")
+
+
+@pytest.mark.parametrize("enc_size", [32, 96, 160, 384])
+def test_bf16_encoder_sizes(dev, enc_size):
+    """Encoder sizes other than the benchmark's 256: the first-layer units of the weight-gradient GEMM cover 128 frequencies
+    each (sine and cosine columns; partial last unit, 1 .. 3 units, chunk classes of their own), layer 0 of the fused kernel
+    runs enc_size / 32 chunks.  Per-tensor gradients against the fp32 engine, B chosen to leave a partial tile."""
+    import inr_mi355x as M
+    from inr_mi355x import _lib as L
+    B = 4133
+    enc, m32, m16, e32, e16 = _pair(dev, B + enc_size, 256, 4, enc_size)
+    g = torch.Generator().manual_seed(enc_size)
+    coords = (torch.rand(B, 3, generator=g) * 2 - 1).to(dev)
+    gt = (torch.randn(B, 2, generator=g) * 0.2).to(dev)
+    encB = enc.B.contiguous()
+    spec = M.LossSpec(L.LOSS_L2_HALF)
+    l32 = float(e32.train_step(coords, encB, gt, spec))
+    l16 = float(e16.train_step(coords, encB, gt, spec))
+    assert abs(l16 - l32) <= 2e-2 * abs(l32)
+    for (name, p_), (o, n, s_, c) in zip(m16.named_parameters(), m16._layout):
+        a, b = e16.grads[o:o + n], e32.grads[o:o + n]
+        assert rel_l2(a, b) < 1e-1, (name, rel_l2(a, b))
+    w0 = dict(m16.named_parameters())["model.0.linear.weight"]
+    o0 = [o for (nm, _), (o, n, s_, c) in zip(m16.named_parameters(), m16._layout) if nm == "model.0.linear.weight"][0]
+    a, b = e16.grads[o0:o0 + w0.numel()].view(256, 2 * enc_size), e32.grads[o0:o0 + w0.numel()].view(256, 2 * enc_size)
+    for c0 in range(0, 2 * enc_size, 32):  # every 32-column group of dW_0: sine and cosine halves, every unit
+        assert rel_l2(a[:, c0:c0 + 32], b[:, c0:c0 + 32]) < 1.5e-1, (c0, rel_l2(a[:, c0:c0 + 32], b[:, c0:c0 + 32]))
 
 
 @pytest.mark.parametrize("B", [1, 127, 128, 1000, 4133, 256 * 128 + 77])
