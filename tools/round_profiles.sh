@@ -18,4 +18,8 @@ done
 echo "== rounding oracle distances"; timeout -k 10 300 python3 tools/debug_bf16_oracle.py 127 4133 32845 > gpurun_out/${R}_bf16_oracle_distances.txt 2>&1 || { tail -3 gpurun_out/${R}_bf16_oracle_distances.txt; exit 1; }
 echo "== probes"
 timeout -k 10 60 tools/probes/overlap_probe > gpurun_out/${R}_probe_overlap.txt 2>&1 && timeout -k 10 60 tools/probes/sinf16_probe > gpurun_out/${R}_probe_sinf16.txt 2>&1
+
+echo "== kernel trace of the secondary workloads"
+(cd /tmp && timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${R}_models_kt -o m -- python3 $GRAFT_REPO_ROOT/tools/bench_models.py > $GRAFT_REPO_ROOT/gpurun_out/${R}_models_kt.log 2>&1) || { tail -5 gpurun_out/${R}_models_kt.log; exit 1; }
+python3 tools/kernel_stats_by_grid.py "$(find gpurun_out/${R}_models_kt -name '*kernel_trace.csv' | head -1)" > gpurun_out/${R}_kernel_stats_models_by_grid.csv && rm -rf gpurun_out/${R}_models_kt
 echo done
