@@ -95,93 +95,58 @@ __device__ __forceinline__ void phase_byte(unsigned& word, float t, float magic)
 }
 
 // ---- the panel ring ---------------------------------------------------------------------------------------------
-// Stream position p lives in slot p & 7.  An INTERVAL consumes c panels (two per layer-0 chunk or pair of row blocks, one
-// for the last layer and for its transpose) between two barriers.  How a panel gets there:
-//   * the first four intervals' panels (eight positions; seven where the stream starts with a one-panel interval) by
-//     LDS-DMA from the kernel's prologue, waited for there;
-//   * every later one through REGISTERS: interval k loads the panels of interval k + 4 (two 16-byte global loads per
-//     wave and panel) and stores the ones it loaded an interval ago -- interval k + 3's -- into their slots (two
-//     ds_write_b128), which interval k - 1 was the last to read.  pn_stage<CW, CL>(): CW panels written, CL loaded.
-// Why not LDS-DMA all the way (rounds 2-3a): measured by knock-out, the 1056 DMA instructions a workgroup issues per tile
-// pair cost 32 of the kernel's 112 us at 65 536 rows -- ~350 cycles of a wave's issue per 1 KB piece beside MFMAs and LDS
-// reads -- against ~30 for a load + a store of the same piece, at 16 registers.
-//   pn_begin():  own LDS stores done, s_barrier -- everybody's are, and everybody is done with the interval before.
+// Stream position p lives in slot p & 7.  An INTERVAL consumes c <= 4 panels between two barriers: two layer-0 chunks (one
+// at an odd tail), FOUR row blocks of a hidden layer, the last layer, its transpose.  The ring holds the interval being
+// multiplied and the next one: right behind barrier k every wave requests its two 1 KB pieces of each panel of interval
+// k + 1 by LDS-DMA (global_load_lds_dwordx4: no registers) into the slots interval k - 1 was the last to read; a whole
+// interval later, pn_begin<N>() = s_waitcnt vmcnt(N) -- this wave's pieces have landed -- + s_barrier -- everybody's have,
+// and everybody is done with interval k.  N: the vector-memory counter retires IN ORDER, so "at most N outstanding" covers
+// the requests when at least N operations were issued behind them; every interval of an active wave ends with the four
+// stash stores of an epilogue (N = 4: those may stay in flight), layer 0 and the idle waves of a one-tile workgroup issue
+// nothing else (N = 0).  A smaller N only waits longer.
+// (Round 3a had two row blocks per barrier and seven panels in flight; removing the barriers from that build took 10 us off
+// 112.  Panels through registers -- load an interval, ds_write the next -- measured the same as LDS-DMA within 1 % and cost
+// 16 registers: profiles/r03_fused_bf16_knockouts.txt.)
 struct PnRing {
   const char* gbase;  // panel 0 of the image
   char* ring;
   int first, len;     // the stream cycles through images [first, first + len)
   int p;              // next position to consume
-  int req, req_img;   // next position to put into LDS; image (relative to first) of the next panel to LOAD
+  int req, req_img;   // next position to request, its image (relative to first)
   int w, lane;
-  bool staged;        // st holds the panels of positions req ..
-  u32x4 st[2][2];     // staged panels: this wave's two 1 KB pieces of each
+  __amdgpu_buffer_rsrc_t rs;  // the whole panel image
+  int voff;                   // this lane's byte offset inside a panel: its wave's two pieces, 16 bytes a lane
 };
 constexpr int pn_min(int a, int b) { return a < b ? a : b; }
 constexpr int pn_max(int a, int b) { return a > b ? a : b; }
 
-__device__ __forceinline__ void pn_issue(const PnRing& r, int img, int slot) {  // LDS-DMA (prologue)
-  const char* src = r.gbase + (size_t)img * W2_PANEL_BYTES + (size_t)(2 * r.w) * 1024 + r.lane * 16;
+__device__ __forceinline__ void pn_issue(const PnRing& r, int img, int slot) {
+#ifdef EXP_NODMA  // timing experiment: the panels are never fetched (results meaningless)
+  return;
+#endif
+  // (through a buffer descriptor: scalar image offset + one 32-bit lane offset formed once -- as global_load_lds the
+  // compiler formed a 64-bit vector address per image up front, and spilled them)
   char* dst = r.ring + slot * W2_PANEL_BYTES + (2 * r.w) * 1024;
-#pragma unroll
-  for (int n = 0; n < 2; ++n)
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + n * 1024),
-                                     (__attribute__((address_space(3))) void*)(dst + n * 1024), 16, 0, 0);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r.rs, (__attribute__((address_space(3))) void*)dst, 16, r.voff, img * W2_PANEL_BYTES, 0, 0);
+  // (the second piece's +1 KB rides in the scalar offset: an immediate offset would move the LDS address as well)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r.rs, (__attribute__((address_space(3))) void*)(dst + 1024), 16, r.voff,
+                                           img * W2_PANEL_BYTES + 1024, 0, 0);
 }
-__device__ __forceinline__ void pn_prime(PnRing& r, int n) {
-  for (int i = 0; i < n; ++i) {
+// the next c panels of the stream
+__device__ __forceinline__ void pn_fetch(PnRing& r, int c) {
+  for (int i = 0; i < c; ++i) {
     pn_issue(r, r.first + r.req_img, r.req & (PN_SLOTS - 1));
     ++r.req;
     if (++r.req_img == r.len) r.req_img = 0;
   }
-  r.staged = false;
 }
-template <int CW, int CL>
-__device__ __forceinline__ void pn_stage(PnRing& r) {
-#ifdef EXP_NODMA  // timing experiment: the panels are never fetched (results meaningless)
-  return;
-#endif
-  if (r.staged) {
-#pragma unroll
-    for (int c = 0; c < CW; ++c) {
-      char* dst = r.ring + (r.req & (PN_SLOTS - 1)) * W2_PANEL_BYTES + (2 * r.w) * 1024 + r.lane * 16;
-#ifdef EXP_NOPWRITE  // timing experiment: panels loaded, never stored to LDS
-      asm volatile("" ::"v"(r.st[c][0]), "v"(r.st[c][1]));
-#else
-      *reinterpret_cast<u32x4*>(dst) = r.st[c][0];
-      *reinterpret_cast<u32x4*>(dst + 1024) = r.st[c][1];
-#endif
-      ++r.req;
-    }
-  }
-#pragma unroll
-  for (int c = 0; c < CL; ++c) {
-    const char* src = r.gbase + (size_t)(r.first + r.req_img) * W2_PANEL_BYTES + (size_t)(2 * r.w) * 1024 + r.lane * 16;
-#ifdef EXP_NOPLOAD  // timing experiment: nothing loaded, whatever the registers hold is stored
-    asm volatile("" : "+v"(r.st[c][0]), "+v"(r.st[c][1]) : "v"(src));
-#else
-    r.st[c][0] = *reinterpret_cast<const u32x4*>(src);
-    r.st[c][1] = *reinterpret_cast<const u32x4*>(src + 1024);
-#endif
-    if (++r.req_img == r.len) r.req_img = 0;
-  }
-  r.staged = true;
-}
+template <int N>
 __device__ __forceinline__ void pn_begin(PnRing& r) {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit field");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 #ifndef EXP_NOBARRIER  // timing experiment: no rendezvous (results meaningless)
   __builtin_amdgcn_s_barrier();
 #endif
-}
-// panels of the interval `idx` places behind hidden-layer interval 0 of the forward (bwd = false) or backward sequence:
-// 2, but 1 for the last layer and the first backward interval (MODE_FUSED: both, back to back behind the forward
-// intervals; MODE_FWD: the last layer only; MODE_BWD: the first backward interval of the NEXT tile behind the backward ones)
-template <int MODE, int NH>
-constexpr int pn_c(bool bwd, int idx) {
-  if (!bwd) {
-    if (MODE == MODE_FUSED) return idx < 4 * NH ? 2 : (idx < 4 * NH + 2 ? 1 : 2);
-    return idx == 4 * NH ? 1 : 2;
-  }
-  return (MODE == MODE_BWD && idx == 4 * NH) ? 1 : 2;
 }
 // fragment f of the panel at stream position p: ONE address register per panel (opaque to the compiler, which otherwise
 // forms the sixteen lane addresses up front, a register each, and adds the slot to every one of them) + f KB as an immediate
@@ -544,34 +509,33 @@ struct SirenTile {
           enc_row(0, 1, nb[1]);
           static_for<0, 4>([&](auto sc) { static_for<0, 8>([&](auto jc) { gen_value(0, nq0 > 1 ? 1 : 0, sc, jc, bq[0]); }); });
         }
-        for (int ch = 0; ch < nq0; ch += 2) {  // two chunks a trip: the B operand sets alternate at compile time
+        for (int ch = 0; ch < nq0; ch += 2) {  // an interval = two chunks (one at an odd tail); the B operand sets alternate
+          const int nch = nq0 - ch >= 2 ? 2 : 1, rem = nq0 - ch - nch;
+          pn_begin<0>(r);
+          pn_fetch(r, rem == 1 ? 2 : 4);  // the next interval: two chunks, the odd last one, or the first four hidden row blocks
           static_for<0, 2>([&](auto hc) {
             constexpr int hh = decltype(hc)::value;
             const int chh = ch + hh;
-            if (chh < nq0) {
-              pn_begin(r);
-              if (ACTIVE) {
-                const int nxt = chh + 1 < nq0 ? chh + 1 : chh;  // (past the end: the last chunk again, never multiplied)
-                const int nxt2 = nxt + 1 < nq0 ? nxt + 1 : nxt;
-                const unsigned pb[2] = {pn_base(r, r.p), pn_base(r, r.p + 1)};  // K-steps 0, 1 / 2, 3 of the chunk
-                static_for<0, 8>([&](auto mc) { A[0][decltype(mc)::value] = pn_frag(r, pb[0], decltype(mc)::value); });
-                static_for<0, 4>([&](auto sc) {
-                  constexpr int s = decltype(sc)::value;
-                  static_for<0, 8>([&](auto mc) {
-                    constexpr int m = decltype(mc)::value;
-                    if constexpr (s < 3) A[(s + 1) & 1][m] = pn_frag(r, pb[(s + 1) >> 1], ((s + 1) & 1) * 8 + m);
-                    acc8[m] = mfma_bf16(A[s & 1][m], __builtin_bit_cast(bf16x8, bq[hh][s]), acc8[m]);
+            if (hh < nch && ACTIVE) {
+              const int nxt = chh + 1 < nq0 ? chh + 1 : chh;  // (past the end: the last chunk again, never multiplied)
+              const int nxt2 = nxt + 1 < nq0 ? nxt + 1 : nxt;
+              const unsigned pb[2] = {pn_base(r, r.p + 2 * hh), pn_base(r, r.p + 2 * hh + 1)};  // K-steps 0, 1 / 2, 3 of the chunk
+              static_for<0, 8>([&](auto mc) { A[0][decltype(mc)::value] = pn_frag(r, pb[0], decltype(mc)::value); });
+              static_for<0, 4>([&](auto sc) {
+                constexpr int s = decltype(sc)::value;
+                static_for<0, 8>([&](auto mc) {
+                  constexpr int m = decltype(mc)::value;
+                  if constexpr (s < 3) A[(s + 1) & 1][m] = pn_frag(r, pb[(s + 1) >> 1], ((s + 1) & 1) * 8 + m);
+                  acc8[m] = mfma_bf16(A[s & 1][m], __builtin_bit_cast(bf16x8, bq[hh][s]), acc8[m]);
 #ifndef EXP_NOGEN  // timing experiment: layer 0 multiplies the first chunk's features again and again
-                    gen_value(nxt, nxt2, sc, mc, bq[hh ^ 1]);
+                  gen_value(nxt, nxt2, sc, mc, bq[hh ^ 1]);
 #endif
-                    __builtin_amdgcn_sched_barrier(0);
-                  });
+                  __builtin_amdgcn_sched_barrier(0);
                 });
-              }
-              pn_stage<2, 2>(r);
-              r.p += 2;
+              });
             }
           });
+          r.p += 2 * nch;
         }
         INR_STAMP(si); ++si;
         // epilogue of layer 0, all eight row blocks
@@ -580,10 +544,11 @@ struct SirenTile {
       }
 
       // ================================ hidden layers 1 .. D-2, row block by row block ================================
-      // Two row blocks (two panels) per barrier.  Row block i = 8 (l - 1) + m carries the epilogue of row block i - 1.
-      static_for<0, 4 * NH>([&](auto ic) {
-        constexpr int I = decltype(ic)::value, i0 = 2 * I, l = 1 + (i0 >> 3), m0 = i0 & 7;
-        pn_begin(r);
+      // Four row blocks (four panels) per barrier.  Row block i = 8 (l - 1) + m carries the epilogue of row block i - 1.
+      static_for<0, 2 * NH>([&](auto qc) {
+        constexpr int Q = decltype(qc)::value, i0 = 4 * Q, l = 1 + (i0 >> 3), m0 = i0 & 7;
+        pn_begin<(ACTIVE ? 4 : 0)>(r);
+        pn_fetch(r, Q + 1 < 2 * NH ? 4 : 1);
         if (ACTIVE) {
           block_pair(
               r.p, hb[(l - 1) & 1],
@@ -591,23 +556,23 @@ struct SirenTile {
                 // (m0 == 0: the epilogue of the layer below's last row block, whose B operands this block's last K-steps read)
                 if constexpr (i0 > 0) fwd_slice<1 + ((i0 - 1) >> 3), (i0 - 1) & 7, (m0 == 0 ? 2 : 1), decltype(tc)::value>(acc2[1]);
               },
-              [&]() { pn_stage<pn_c<MODE, NH>(false, I + 3), pn_c<MODE, NH>(false, I + 4)>(r); },
-              [&](auto tc) { fwd_slice<l, m0, 1, decltype(tc)::value>(acc2[0]); });
-        } else {
-          pn_stage<pn_c<MODE, NH>(false, I + 3), pn_c<MODE, NH>(false, I + 4)>(r);
+              [&]() {}, [&](auto tc) { fwd_slice<l, m0, 1, decltype(tc)::value>(acc2[0]); });
+          block_pair(
+              r.p + 2, hb[(l - 1) & 1], [&](auto tc) { fwd_slice<l, m0 + 1, 1, decltype(tc)::value>(acc2[1]); }, [&]() {},
+              [&](auto tc) { fwd_slice<l, m0 + 2, 1, decltype(tc)::value>(acc2[0]); });
         }
-        r.p += 2;
-        if constexpr (m0 == 6) {
+        r.p += 4;
+        if constexpr (m0 == 4) {
           INR_STAMP(si); ++si;
         }
       });
 
       // ================================ last layer: one row block (rows 0 .. out_f-1 live) ================================
-      pn_begin(r);
+      pn_begin<(ACTIVE ? 4 : 0)>(r);
+      pn_fetch(r, MODE == MODE_FUSED ? 1 : (nq0 >= 2 ? 4 : 2));  // the transpose, or (MODE_FWD) the next tile's first chunks
       if (ACTIVE) {
         block(acc2[0], r.p, hb[NH & 1], [&](auto tc) { fwd_slice<NH, 7, 2, decltype(tc)::value>(acc2[1]); });
         const f32x16& accL = acc2[0];
-        pn_stage<2, 2>(r);
         float y[4], dy[4], g[4];
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
@@ -625,8 +590,6 @@ struct SirenTile {
           f32x4 d4 = {dy[0], dy[1], dy[2], dy[3]};
           *reinterpret_cast<f32x4*>(sv + w2_stash_dy(D) + 4 * wcol) = d4;
         }
-      } else {
-        pn_stage<2, 2>(r);
       }
       r.p += 1;
       INR_STAMP(si); ++si;
@@ -642,8 +605,8 @@ struct SirenTile {
         }
       }
       // ================================ dH_{D-2} = W_last^T dZ_last: one K-step, eight row blocks ================================
-      pn_begin(r);
-      pn_stage<2, 2>(r);
+      pn_begin<(ACTIVE ? 4 : 0)>(r);  // (behind the last layer's interval, or the tile before's last epilogue)
+      pn_fetch(r, 4);
       if (ACTIVE) {
         // dZ_last rows (0,1), (2,3) of this coordinate as fp16 pairs: two dwords behind the 8-bit tensors
         if (half == 0 && ts_bytes != 0) {
@@ -670,22 +633,24 @@ struct SirenTile {
       // ================================ dH_{l-1} = W_l^T dZ_l, l = D-2 .. 1, row block by row block ================================
       // Row block j = 8 li + m carries backward epilogue 8 + j - 1 (row block j - 1 of this sequence; the first one has
       // none: the eight epilogues of dZ_{D-2} ran above).
-      static_for<0, 4 * NH>([&](auto jc) {
-        constexpr int J = decltype(jc)::value, j0 = 2 * J, li = j0 >> 3, m0 = j0 & 7;
-        pn_begin(r);
+      static_for<0, 2 * NH>([&](auto rc) {
+        constexpr int R = decltype(rc)::value, j0 = 4 * R, li = j0 >> 3, m0 = j0 & 7;
+        pn_begin<(ACTIVE ? 4 : 0)>(r);
+        // the next interval: four more row blocks; behind the last one the next tile's first chunks (or, MODE_BWD, its transpose)
+        pn_fetch(r, R + 1 < 2 * NH ? 4 : (MODE == MODE_BWD ? 1 : (E >= 64 ? 4 : 2)));
         if (ACTIVE) {
           block_pair(
               r.p, hb[li & 1],
               [&](auto tc) {
                 if constexpr (j0 > 0) bwd_slice<8 + j0 - 1, (m0 == 0 ? 2 : 1), decltype(tc)::value>(acc2[1]);
               },
-              [&]() { pn_stage<pn_c<MODE, NH>(true, J + 3), pn_c<MODE, NH>(true, J + 4)>(r); },
-              [&](auto tc) { bwd_slice<8 + j0, 1, decltype(tc)::value>(acc2[0]); });
-        } else {
-          pn_stage<pn_c<MODE, NH>(true, J + 3), pn_c<MODE, NH>(true, J + 4)>(r);
+              [&]() {}, [&](auto tc) { bwd_slice<8 + j0, 1, decltype(tc)::value>(acc2[0]); });
+          block_pair(
+              r.p + 2, hb[li & 1], [&](auto tc) { bwd_slice<8 + j0 + 1, 1, decltype(tc)::value>(acc2[1]); }, [&]() {},
+              [&](auto tc) { bwd_slice<8 + j0 + 2, 1, decltype(tc)::value>(acc2[0]); });
         }
-        r.p += 2;
-        if constexpr (m0 == 6) {
+        r.p += 4;
+        if constexpr (m0 == 4) {
           INR_STAMP(si); ++si;
         }
       });
@@ -724,7 +689,10 @@ __global__ __launch_bounds__(512, 2) void inr_siren_bf16_kernel(const NetDesc nd
   r.len = MODE == MODE_FUSED ? w2_np(D, E) : (MODE == MODE_FWD ? w2_n_fwd(D, E) : w2_np(D, E) - w2_n_fwd(D, E));
   r.p = 0, r.req = 0, r.req_img = 0;
   r.w = w, r.lane = lane;
-  pn_prime(r, MODE == MODE_BWD ? 7 : 8);  // the first four intervals' panels
+  r.rs = uniform_rsrc(r.gbase, 0x7ffffff0);
+  r.voff = (2 * w) * 1024 + lane * 16;
+  asm volatile("" : "+v"(r.voff));
+  pn_fetch(r, MODE == MODE_BWD ? 1 : (E >= 64 ? 4 : 2));  // the first interval's panels
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();  // tables and panels in LDS
 
