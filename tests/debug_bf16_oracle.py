@@ -1,4 +1,5 @@
-"""Diagnostic (GPU): the bf16 step against its rounding oracle, tensor by tensor.  python tools/debug_bf16_oracle.py [B ...]"""
+"""Checker script, not a test module (GPU): the bf16 step against its rounding oracle, tensor by tensor -- lives under tests/
+because it imports the oracle.  python tests/debug_bf16_oracle.py [B ...]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "mri-implicit-neural-representations_amd"))

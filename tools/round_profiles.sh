@@ -15,7 +15,7 @@ for a in "65536 bf16" "25000 bf16" "25000 f32"; do
   set -- $a
   timeout -k 10 200 python3 tools/stamps.py $1 $2 > gpurun_out/${R}_stamps_$2_$1.txt 2>&1 || { tail -3 gpurun_out/${R}_stamps_$2_$1.txt; exit 1; }
 done
-echo "== rounding oracle distances"; timeout -k 10 300 python3 tools/debug_bf16_oracle.py 127 4133 32845 > gpurun_out/${R}_bf16_oracle_distances.txt 2>&1 || { tail -3 gpurun_out/${R}_bf16_oracle_distances.txt; exit 1; }
+echo "== rounding oracle distances"; timeout -k 10 300 python3 tests/debug_bf16_oracle.py 127 4133 32845 > gpurun_out/${R}_bf16_oracle_distances.txt 2>&1 || { tail -3 gpurun_out/${R}_bf16_oracle_distances.txt; exit 1; }
 echo "== probes"
 timeout -k 10 60 tools/probes/overlap_probe > gpurun_out/${R}_probe_overlap.txt 2>&1 && timeout -k 10 60 tools/probes/sinf16_probe > gpurun_out/${R}_probe_sinf16.txt 2>&1
 
