@@ -78,8 +78,9 @@ flop = 8 * cmac * 3                            # 8 FLOP per complex MAC, fwd + d
 res["WIRE2D_3x256_L2_B25000"] = {"ms_per_step": ms, "samples_per_s": B / ms * 1e3, "TFLOPs": flop * B / ms / 1e9,
                                  "frac_f32_mfma": flop * B / ms / 1e9 / 157.3}
 # BASELINE config 5: radial acc-4 mask, per-coil batches (235 520 coordinates), total-variation term -- bench.py's object
+# (its timing loop repeats rounds until they agree: see there)
 import bench, gc
-del eng, model, coords, gt  # (the engines above hold gigabytes of stash; the per-coil trainer allocates its own)
+del eng, model, coords, gt
 gc.collect(); torch.cuda.empty_cache()
 res["config5_percoil_tv"] = bench.config5_percoil(dev)
 print(json.dumps(res, indent=1))
