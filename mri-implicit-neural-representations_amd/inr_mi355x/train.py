@@ -168,6 +168,12 @@ class INRTrainer:
         self.coords = coords.to(self.device).contiguous()
         self.image = image.to(self.device).contiguous()
         self.mask_cpu = mask
+        # sampled rows in front of every row, once: a batch's count is a difference of two entries.  (A `mask[lo:hi].sum()`
+        # per step is a multi-threaded CPU reduction whose worker threads spin on after it: on the GPU boxes that drove the
+        # container into its CPU quota -- 87 ms stalls every ~17 steps of the per-coil loop, profiles/r03_config5_steps.txt)
+        self._mask_cum = None
+        if mask is not None:
+            self._mask_cum = [0] + torch.cumsum(mask.to(torch.int64).flatten(), 0).tolist()
         self.mask = mask.to(torch.uint8).to(self.device).contiguous() if mask is not None else None
         # per-coil batches (MRICoilWrapperDataset, nerp_datasets.py:397-441; loader batch_size 1 = one coil,
         # models/utils.py:65-66) so that TV can see a whole coil grid
@@ -220,12 +226,13 @@ class INRTrainer:
             self._hdr_A[it] = float(torch.mean((1 - f) ** 2))
         return self._hdr_A[it]
 
+    def _count(self, lo: int, hi: int) -> int:
+        """sampled rows of [lo, hi) (all of them without a mask)"""
+        return hi - lo if self._mask_cum is None else self._mask_cum[hi] - self._mask_cum[lo]
+
     def step(self, epoch: int, it: int) -> torch.Tensor:
         lo, hi = it * self.bs, min((it + 1) * self.bs, self.n)
-        if self.mask_cpu is not None:
-            count = int(self.mask_cpu[lo:hi].sum())
-        else:
-            count = hi - lo
+        count = self._count(lo, hi)
         A = self._batch_hdr_A(it, lo, hi)
         if self.graph_steps:
             return self._graph_step(epoch, it, lo, hi, count, A)
@@ -296,7 +303,7 @@ class INRTrainer:
         lr = cfg["lr"] * lr_factor(epoch, cfg["max_epoch"])
         for it in range(self.steps_per_epoch):
             lo, hi = it * self.bs, min((it + 1) * self.bs, self.n)
-            count = int(self.mask_cpu[lo:hi].sum()) if self.mask_cpu is not None else hi - lo
+            count = self._count(lo, hi)
             A = self._batch_hdr_A(it, lo, hi)
             g = self._graphs.get(it)
             if g is None or g.stale:

@@ -79,6 +79,8 @@ class MultiscaleTrainer:
             masked, _, gm = Undersampler(method, seed=mask_seed).apply(image.reshape(C, H, W, 2).cpu(), uparams)
             image, mask = masked.reshape(-1, 2), gm[:, 0].contiguous()
         self.mask_cpu = mask
+        # (sampled rows in front of every row, once: no CPU reduction per step -- see INRTrainer)
+        self._mask_cum = None if mask is None else [0] + torch.cumsum(mask.to(torch.int64).flatten(), 0).tolist()
         self.mask = mask.to(torch.uint8).to(self.device).contiguous() if mask is not None else None
         self.per_coil = bool(config["per_coil"])
         self.use_tv = bool(config["use_tv"])  # here TV does not depend on a mask (train_kspace_multiscale.py:173)
@@ -137,7 +139,7 @@ class MultiscaleTrainer:
 
     def step(self, epoch: int, it: int) -> torch.Tensor:
         lo, hi = it * self.bs, min((it + 1) * self.bs, self.n)
-        count = hi - lo if self.mask_cpu is None else int(self.mask_cpu[lo:hi].sum())
+        count = hi - lo if self._mask_cum is None else self._mask_cum[hi] - self._mask_cum[lo]
         if self.use_tv:
             loss = self._tv_step(it, lo, hi, count)
         else:
