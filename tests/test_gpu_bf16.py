@@ -67,7 +67,7 @@ def test_bf16_encoder_sizes(dev, enc_size):
 
 
 @pytest.mark.parametrize("B", [1, 127, 128, 1000, 4133, 256 * 128 + 77])
-@pytest.mark.parametrize("width,depth", [(256, 5), (200, 3)])
+@pytest.mark.parametrize("width,depth", [(256, 5), (200, 3), (256, 8), (160, 6)])
 def test_bf16_step_close_to_fp32(dev, B, width, depth):
     import inr_mi355x as M
     from inr_mi355x import _lib as L
