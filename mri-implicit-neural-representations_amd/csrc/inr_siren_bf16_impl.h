@@ -1,7 +1,7 @@
 // inr_siren_bf16_impl.h -- SIREN on the bf16 matrix pipe, third design: "weight panels in LDS, activations in registers,
-// one row block at a time, two staggered wave groups".  Forward + pointwise loss + backward-to-inputs for tiles of 256
-// coordinates (MODE_FUSED), or the two halves of a split step (MODE_FWD: outputs + stash; MODE_BWD: from d(loss)/d(out));
-// the weight gradients are left to inr_dw_gemm_bf16.hip, which reads the 8-bit operands this kernel stashes.
+// one row block at a time, one interleaved MFMA + epilogue stream per wave".  Forward + pointwise loss + backward-to-inputs
+// for tiles of 256 coordinates (MODE_FUSED), or the two halves of a split step (MODE_FWD: outputs + stash; MODE_BWD: from
+// d(loss)/d(out)); the weight gradients are left to inr_dw_gemm_bf16.hip, which reads the 8-bit operands this kernel stashes.
 //
 // What the second design (round 2) measured, and what changed:
 //   * its stash -- z_l as fp16, dZ_l as bf16, 4 KB per coordinate, ~690 MB of HBM traffic per step at 65 536 rows --
@@ -13,11 +13,10 @@
 //     with the matrix pipe idle; 18.5 k cycles per layer for 8.2 k of MFMAs).  Now the hidden layers run OUTPUT ROW
 //     BLOCK outermost: a panel = the 16 K-steps of one 32-row block, so a block's accumulator (16 registers instead of
 //     128) is final after 16 MFMAs and its epilogue -- bias, sine, phase byte, stash, conversion into the next layer's B
-//     operand -- runs while the next block multiplies.  Waves 0-3 (role A) do [MFMAs of block m][epilogue of block m],
-//     waves 4-7 (role B, the SIMD partners) [epilogue of block m-1][MFMAs of block m] between the same barriers: at
-//     any time one wave of a SIMD is on the matrix pipe and the other on the vector ALUs;
-//   * weights still travel HBM/L2 -> LDS once per workgroup by LDS-DMA, now as 16 KB panels through an 8-slot ring with
-//     seven panels in flight ahead of the one being multiplied.
+//     operand -- is cut into 16 slices that ride behind the next block's MFMAs, one value a slot, in EVERY wave (see
+//     SirenTile; the first form of this design had the two waves of a SIMD take turns instead, which did not overlap);
+//   * weights still travel HBM/L2 -> LDS once per workgroup by LDS-DMA, now as 16 KB panels through an 8-slot ring that
+//     holds the interval being multiplied (four row blocks) and the next one.
 // Activations never touch LDS: the fp32 accumulator of layer l (features in registers, coordinates on lanes), after
 // bias + v_sin_f32 + v_cvt_pk_bf16_f32, IS the B operand of layer l+1 (element j of lane-half h of K-step (m, s) is
 // feature 32 m + 16 s + 8 (j >> 2) + 4 h + (j & 3); the fragments are packed in the same k order, inr_w2.h).

@@ -127,7 +127,7 @@ else:
         labels += [f"L{l} (row blocks: GEMM | epilogue)" for l in (1, 2, 3)]
         labels += ["last layer + loss", "dH last + dZ_3 epilogues"]
         labels += [f"dX L{l} (row blocks: GEMM | epilogue)" for l in (3, 2, 1)]
-        labels += ["role B's last epilogue"]
+        labels += ["the last epilogue (row block 7 of dZ_0)"]
         names = dict(enumerate(labels))
         order = list(range(len(labels)))
         last = len(labels) - 1
