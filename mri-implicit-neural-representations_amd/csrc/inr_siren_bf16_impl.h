@@ -45,7 +45,10 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 constexpr int PN_SLOTS = 8;   // ring slots of W2_PANEL_BYTES
 constexpr int PN_WAVES = 8;   // waves per workgroup; each moves 16 / 8 = 2 of a panel's 1 KB pieces
-constexpr int PN_FD = 6;      // A fragments read ahead of the MFMA that takes them
+#ifndef PN_FD_N
+#define PN_FD_N 6
+#endif
+constexpr int PN_FD = PN_FD_N;  // A fragments read ahead of the MFMA that takes them
 #ifndef PN_PD_N
 #define PN_PD_N 3
 #endif
