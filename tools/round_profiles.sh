@@ -17,7 +17,10 @@ for a in "65536 bf16" "25000 bf16" "25000 f32"; do
 done
 echo "== rounding oracle distances"; timeout -k 10 300 python3 tests/debug_bf16_oracle.py 127 4133 32845 > gpurun_out/${R}_bf16_oracle_distances.txt 2>&1 || { tail -3 gpurun_out/${R}_bf16_oracle_distances.txt; exit 1; }
 echo "== probes"
-timeout -k 10 60 tools/probes/overlap_probe > gpurun_out/${R}_probe_overlap.txt 2>&1 && timeout -k 10 60 tools/probes/sinf16_probe > gpurun_out/${R}_probe_sinf16.txt 2>&1
+for p in overlap_probe sinf16_probe stream_probe; do  # (binaries are not in the history: built where missing)
+  [ -x tools/probes/$p ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -Wno-unused-value tools/probes/$p.hip -o tools/probes/$p || exit 1
+done
+timeout -k 10 60 tools/probes/overlap_probe > gpurun_out/${R}_probe_overlap.txt 2>&1 && timeout -k 10 60 tools/probes/sinf16_probe > gpurun_out/${R}_probe_sinf16.txt 2>&1 && timeout -k 10 60 tools/probes/stream_probe > gpurun_out/${R}_probe_stream_run.txt 2>&1
 
 echo "== kernel trace of the secondary workloads"
 (cd /tmp && timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${R}_models_kt -o m -- python3 $GRAFT_REPO_ROOT/tools/bench_models.py > $GRAFT_REPO_ROOT/gpurun_out/${R}_models_kt.log 2>&1) || { tail -5 gpurun_out/${R}_models_kt.log; exit 1; }
