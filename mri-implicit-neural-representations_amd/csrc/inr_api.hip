@@ -443,10 +443,8 @@ int inr_plan_create(const inr_net_desc* d, inr_plan** out) {
     nd.w2_bias_off = (int)pk;
     pk += (int64_t)D * 256;
     nd.save_floats_per_tile = w2_stash_dwords(D);
-    if (dz_state_alloc(p) == nullptr) {
-      delete p;
-      return fail(INR_ERR_HIP, "inr_plan_create: no device memory for the gradient-scale state");
-    }
+    // (the gradient-scale state is allocated by the first call that needs it, on that call's device: creating and sizing
+    // a plan touches no GPU -- tests/test_host.py sizes bf16 workspaces on the CPU)
   }
   p->packed_floats = pk;
   *out = p;
@@ -769,8 +767,9 @@ int inr_plan_workspace(const inr_plan* plan, int64_t B, int64_t* step_save_slots
 
 int inr_plan_grad_scale_state(const inr_plan* plan, float* host_out, void* stream) {
   if (plan == nullptr || host_out == nullptr) return fail(INR_ERR_INVALID, "inr_plan_grad_scale_state: null argument");
-  if (!plan->nd.bf16 || plan->dz_state == nullptr)
-    return fail(INR_ERR_INVALID, "inr_plan_grad_scale_state: not an INR_PRECISION_BF16 plan");
+  if (!plan->nd.bf16) return fail(INR_ERR_INVALID, "inr_plan_grad_scale_state: not an INR_PRECISION_BF16 plan");
+  if (dz_state_alloc(plan) == nullptr)  // (before the first step: the initial state)
+    return fail(INR_ERR_HIP, "inr_plan_grad_scale_state: no gradient-scale state on this device");
   hipError_t e = hipStreamSynchronize((hipStream_t)stream);
   if (e == hipSuccess) e = hipMemcpy(host_out, plan->dz_state, W2_STATE_FLOATS * sizeof(float), hipMemcpyDeviceToHost);
   if (e != hipSuccess) return hip_fail(e, "inr_plan_grad_scale_state");

@@ -117,6 +117,11 @@ class MLPEngine:
         self.packed = torch.zeros(self.packed_floats, device=dev)  # padding entries stay zero forever
         self._loss = torch.zeros(L.LOSS_WORDS, device=dev)
         self.step = 0
+        if self.desc.precision == L.PRECISION_BF16:
+            # the plan's gradient-scale state is allocated by the first call that needs it: make that call here, not inside
+            # a training step (which may be under graph capture)
+            with torch.cuda.device(dev):
+                self.grad_scale_state()
         self.pack()
 
     def launch_dims(self, B: int):

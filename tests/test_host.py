@@ -135,6 +135,51 @@ def test_plan_validation_and_sizes():
     assert lib.inr_adam_step(None, None, None, None, None, None, 1e-3, .9, .999, 1e-8, 0, 0, 0, 1, None) < 0
 
 
+def test_bf16_plan_sizes_and_chunk_classes(monkeypatch):
+    """A bf16 plan is created and sized without a GPU.  Workspace of a step = one stash slot per 128-row tile + the fused
+    kernel's slabs (one per workgroup, two tiles each above 256 tiles) + the weight-gradient GEMM's chunk slabs: the larger
+    of its two chunk classes (csrc/inr_api.hip: dw_gemm_bf16_setup -- first-layer units 1.5 x the chunks of the others,
+    about 256 workgroups in all)."""
+    from inr_mi355x import _lib as L
+    lib = L.load()
+    monkeypatch.delenv("INR_GEMM_ONE_CLASS", raising=False)
+    monkeypatch.delenv("INR_GEMM_ENC_COST", raising=False)
+    plan = C.c_void_p()
+    d = L.NetDesc(kind=L.KIND_SIREN, in_features=512, width=256, depth=5, out_features=2, last_act=L.ACT_TANH,
+                  input=L.INPUT_GAUSS, enc_size=256, w0=30.0, precision=L.PRECISION_BF16)
+    assert lib.inr_plan_create(C.byref(d), C.byref(plan)) == 0, L.last_error()
+    sz = L.Sizes()
+    assert lib.inr_plan_sizes(plan, C.byref(sz)) == 0
+    assert sz.tile_rows == 128 and sz.save_bytes_per_tile == 4 * (2 * 4 * 8192 + 2 * 128 + 4 * 128)  # 8-bit stash: inr_w2.h
+    nt, nb, slots, slabs = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+    assert lib.inr_plan_launch_dims(plan, 65536, C.byref(nt), C.byref(nb)) == 0 and (nt.value, nb.value) == (512, 256)
+    assert lib.inr_plan_launch_dims(plan, 25000, C.byref(nt), C.byref(nb)) == 0 and (nt.value, nb.value) == (196, 196)
+
+    def chunks(nt, target):
+        tpc = -(-nt // max(1, target))
+        return -(-nt // tpc)
+
+    for B, ntiles, nblocks in ((65536, 512, 256), (25000, 196, 196), (100, 1, 1)):
+        per = 256.0 / (1.5 * 2 + 4)  # two first-layer units (256 frequencies), three hidden + the last layer
+        n_enc = chunks(ntiles, int(per * 1.5))
+        n_oth = chunks(ntiles, (256 - 2 * n_enc) // 4)
+        assert lib.inr_plan_workspace(plan, B, C.byref(slots), C.byref(slabs)) == 0
+        assert (slots.value, slabs.value) == (ntiles, nblocks + max(n_enc, n_oth)), (B, slabs.value, n_enc, n_oth)
+        assert 2 * n_enc + 4 * n_oth <= 256
+    monkeypatch.setenv("INR_GEMM_ONE_CLASS", "1")
+    assert lib.inr_plan_workspace(plan, 65536, C.byref(slots), C.byref(slabs)) == 0
+    assert slabs.value == 256 + chunks(512, 256 // 6)
+    lib.inr_plan_destroy(plan)
+    # what the bf16 kernels do not cover is refused at plan creation, not run on something else
+    for bad, frag in ((dict(width=512), "bf16"), (dict(width=64, in_features=512), "bf16"), (dict(depth=9), "bf16"),
+                      (dict(enc_size=40, in_features=80), "bf16"), (dict(input=L.INPUT_X), "bf16")):
+        kw = dict(kind=L.KIND_SIREN, in_features=512, width=256, depth=5, out_features=2, last_act=L.ACT_TANH,
+                  input=L.INPUT_GAUSS, enc_size=256, w0=30.0, precision=L.PRECISION_BF16)
+        kw.update(bad)
+        rc = lib.inr_plan_create(C.byref(L.NetDesc(**kw)), C.byref(plan))
+        assert rc < 0 and frag in L.last_error().lower(), (bad, rc, L.last_error())
+
+
 def test_short_workspaces_are_invalid_arguments():
     """A stash or slab buffer shorter than inr_plan_workspace reports is INR_ERR_INVALID at the ABI -- checked on the
     host, before any launch -- never an out-of-bounds GPU write (pointers here are never dereferenced)."""
