@@ -251,6 +251,7 @@ static int create_mfn_plan(const inr_net_desc* d, inr_plan** out) {
     }
     L.pbias_off = (int)pk;
     pk += (mu ? 2 : 1) * L.Mblk * 32;  // LT_GABOR_MU: [gamma | |mu_j|^2]
+    L.rf_off = L.rb_off = -1;
   }
   nd.slab_loss_off = goff;
   nd.slab_floats = round_up(goff + 4, 64);
@@ -436,6 +437,21 @@ int inr_plan_create(const inr_net_desc* d, inr_plan** out) {
                             (d->input == INR_INPUT_GAUSS ? nd.L[0].Kblk * 32 * TL : 0) +
                             (wire2d ? NB * 32 * TL : 0);  // WIRE2D: copy of a layer's output gradient
   nd.w2_off = nd.w2_bias_off = -1;
+  // Row-split fused step (inr_mlp_rs_impl.h): SIREN / FFN behind the fused gauss encoder, hidden width 129..256, encoder
+  // size a multiple of 32 that leaves room in LDS.  Such plans carry a second set of fragment images (16x16x4 MFMA
+  // operands); forward / backward calls keep inr_mlp_kernel and its images.
+  for (int t = 0; t < INR_MAX_LAYERS; ++t) nd.L[t].rf_off = nd.L[t].rb_off = -1;
+  if (!nd.bf16 && !wire && NB == 8 && d->input == INR_INPUT_GAUSS && (d->enc_size % 32) == 0 && d->enc_size <= 512) {
+    nd.rs = 1;
+    for (int l = 0; l <= D - 2; ++l) {
+      nd.L[l].rf_off = (int)pk;
+      pk += (int64_t)256 * (l == 0 ? 2 * d->enc_size : 256);
+      if (l >= 1) {
+        nd.L[l].rb_off = (int)pk;
+        pk += (int64_t)256 * 256;
+      }
+    }
+  }
   if (nd.bf16) {
     // the images of the bf16 plans: the "weight panels in LDS" stream (inr_w2.h) + fp32 biases; 8-bit stash
     nd.w2_off = (int)pk;  // (0: 16-byte aligned, the panels are read by 16-byte LDS-DMA pieces)
@@ -685,6 +701,67 @@ static bool step_schedule(const inr_plan* plan, int64_t nt, int64_t nb, StepSche
   return true;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Row-split fused step: how the 16-coordinate column blocks of a batch are dealt to workgroups.  The stash is read by the
+// batch GEMM in whole 128-coordinate slots, so all 8 blocks of every slot are computed (rows past B masked).  `grid`
+// workgroups run `rounds` tiles each; tile t has `hi` blocks if t < x, else `lo`; a tile's block count is the kernel's
+// NCB, or even (the kernel pairs column blocks: inr_mlp_rs_impl.h rs_active).  Rounds are chosen by cost: a round costs
+// its widest tile plus about one block of fixed work (epilogues, barriers, the weight stream's start).
+// ---------------------------------------------------------------------------------------------
+struct RsSchedule {
+  int grid, rounds, ncb, hi, lo, x;
+};
+static RsSchedule rs_schedule(int64_t nt) {
+  const int64_t nblk = 8 * nt;
+  RsSchedule s;
+  s.grid = (int)std::min<int64_t>(kMaxBlocks, nblk);
+  double best = 1e30;
+  s.rounds = 1, s.ncb = 8;
+  const int64_t rmax = nblk / s.grid + 1;
+  for (int64_t R = 1; R <= rmax; ++R) {
+    const int64_t T = s.grid * R, a = nblk / T, rem = nblk % T, ncb = rem ? a + 1 : a;
+    if (ncb > 8 || ncb < 1) continue;
+    const double cost = (double)R * ((double)ncb + 1.0);
+    if (cost < best - 1e-9) best = cost, s.rounds = (int)R, s.ncb = (int)ncb;
+  }
+  const int64_t T = (int64_t)s.grid * s.rounds, a = nblk / T, rem = nblk % T;
+  if (rem == 0) {
+    s.hi = s.lo = (int)a, s.x = (int)T;
+  } else if (a % 2 == 0) {  // NCB = a + 1 odd: full tiles and even ones
+    s.hi = (int)a + 1, s.lo = (int)a, s.x = (int)rem;
+  } else {                  // NCB = a + 1 even: the others give up a pair
+    s.hi = (int)a + 1, s.lo = (int)a - 1, s.x = (int)((nblk - (a - 1) * T) / 2);
+  }
+  return s;
+}
+
+static bool rs_plan(const inr_plan* plan) { return plan->nd.rs != 0; }
+static bool rs_enabled() {  // (read per call: tests compare the two fused kernels in one process)
+  const char* e = getenv("INR_RS");
+  return !(e != nullptr && e[0] == '0');
+}
+
+static int launch_rs(const inr_plan* plan, const LossDesc& ld, inr::MlpArgs a, int64_t nt, const RsSchedule& sc,
+                     hipStream_t st) {
+  a.n_tiles = (int)nt;
+  a.rs_hi = sc.hi, a.rs_lo = sc.lo, a.rs_x = sc.x, a.rs_rounds = sc.rounds;
+  a.tile0 = 0, a.accumulate = 0;
+  hipError_t e;
+  const NetDesc& nd = plan->nd;
+  switch (sc.ncb) {
+    case 1: e = inr::launch_mlp_rs_n1(nd, ld, a, sc.grid, st); break;
+    case 2: e = inr::launch_mlp_rs_n2(nd, ld, a, sc.grid, st); break;
+    case 3: e = inr::launch_mlp_rs_n3(nd, ld, a, sc.grid, st); break;
+    case 4: e = inr::launch_mlp_rs_n4(nd, ld, a, sc.grid, st); break;
+    case 5: e = inr::launch_mlp_rs_n5(nd, ld, a, sc.grid, st); break;
+    case 6: e = inr::launch_mlp_rs_n6(nd, ld, a, sc.grid, st); break;
+    case 7: e = inr::launch_mlp_rs_n7(nd, ld, a, sc.grid, st); break;
+    default: e = inr::launch_mlp_rs_n8(nd, ld, a, sc.grid, st); break;
+  }
+  if (e != hipSuccess) return hip_fail(e, "inr row-split kernel launch");
+  return INR_OK;
+}
+
 static hipStream_t side_stream(const inr_plan* plan) {
   std::lock_guard<std::mutex> lock(plan->side_mu);
   int dev = 0;
@@ -760,7 +837,9 @@ int inr_plan_workspace(const inr_plan* plan, int64_t B, int64_t* step_save_slots
     dw_gemm_setup(plan, nt, &g, &split);
     StepSchedule sc;
     step_schedule(plan, nt, nb, &sc);  // (a split step has its own chunking; the unfused backward keeps the plain one)
-    *n_slabs = nb + std::max(g.n_chunks, sc.red.n2);
+    // (row-split fused steps run rs_schedule's grid -- more workgroups than tiles while the batch is under 256 slots)
+    const int64_t nb_rs = rs_plan(plan) ? std::max<int64_t>(nb, rs_schedule(nt).grid) : nb;
+    *n_slabs = nb_rs + std::max(g.n_chunks, sc.red.n2);
   }
   return INR_OK;
 }
@@ -985,6 +1064,15 @@ int inr_backward(const inr_plan* plan, const float* params, const float* packed,
 static int run_fused_step(const inr_plan* plan, const LossDesc& ld, const inr::MlpArgs& a, int64_t nt, int64_t nb,
                           float* grads, float* loss_out, const float* params, const float* packed, hipStream_t st,
                           const char* who, const AdamFuse* af = nullptr) {
+  if (a.dw_gemm == 1 && rs_plan(plan) && rs_enabled()) {
+    // row-split kernel: one launch of whole rounds (no partial round to overlap), then the batch GEMM and the reduction
+    // over its grid's slabs
+    const RsSchedule rs = rs_schedule(nt);
+    int rc = launch_rs(plan, ld, a, nt, rs, st);
+    if (rc != INR_OK) return rc;
+    if (grads == nullptr) return INR_OK;
+    return finish_gradients(plan, a, nt, rs.grid, grads, loss_out, params, packed, st, who, af);
+  }
   StepSchedule sc;
   hipStream_t side = nullptr;
   if (grads != nullptr && a.dw_gemm == 1 && step_schedule(plan, nt, nb, &sc) && sc.split) side = side_stream(plan);

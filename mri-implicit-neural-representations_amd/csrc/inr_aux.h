@@ -65,6 +65,15 @@ hipError_t launch_siren_bf16_fwd(const NetDesc& nd, const LossDesc& ld, const Ml
 hipError_t launch_siren_bf16_bwd(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int grid, hipStream_t st);
 hipError_t launch_siren_bf16_fused(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int grid, hipStream_t st);
 hipError_t launch_mlp_nb16(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int mode, int grid, hipStream_t st);
+// row-split fused step, tiles of N column blocks of 16 coordinates (inr_mlp_rs_n*.hip)
+hipError_t launch_mlp_rs_n1(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int grid, hipStream_t st);
+hipError_t launch_mlp_rs_n2(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int grid, hipStream_t st);
+hipError_t launch_mlp_rs_n3(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int grid, hipStream_t st);
+hipError_t launch_mlp_rs_n4(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int grid, hipStream_t st);
+hipError_t launch_mlp_rs_n5(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int grid, hipStream_t st);
+hipError_t launch_mlp_rs_n6(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int grid, hipStream_t st);
+hipError_t launch_mlp_rs_n7(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int grid, hipStream_t st);
+hipError_t launch_mlp_rs_n8(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int grid, hipStream_t st);
 hipError_t launch_mlp_nb8(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int mode, int grid, hipStream_t st);
 hipError_t launch_wire_nb2(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int mode, int grid, hipStream_t st);
 hipError_t launch_wire_nb4(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int mode, int grid, hipStream_t st);

@@ -257,6 +257,22 @@ __device__ __forceinline__ void put_tr(const LayerDesc& L, float* packed, int ro
   packed[L.pb_off + ((size_t)((s >> 2) * L.Kblk + (k >> 5)) * 64 + h * 32 + (k & 31)) * 4 + (s & 3)] = v;
 }
 
+// Fragment images of the row-split fused step (inr_mlp_rs_impl.h): v_mfma_f32_16x16x4_f32 A operands, one float4 per lane
+// and k-step = the four 16-row blocks of a wave's 64 rows: W[row][k] -> float4 ((k >> 2) * 4 + (row >> 6)) * 64 +
+// (k & 3) * 16 + (row & 15), component (row >> 4) & 3.  Layer 0 keeps its k in CHUNK order: 32 encoder phases at a time,
+// their sines then their cosines (the kernel generates the features chunk by chunk).
+__device__ __forceinline__ void put_rs(const NetDesc& nd, const LayerDesc& L, int l, float* packed, int row, int k, float v) {
+  if (l >= nd.D - 1) return;  // the last layer's rows are read from the flat parameters
+  int kk = k;
+  if (l == 0) {
+    const int trig = k >= nd.E, sp = trig ? k - nd.E : k;
+    kk = (sp >> 5) * 64 + trig * 32 + (sp & 31);
+  }
+  packed[L.rf_off + ((size_t)(((kk >> 2) * 4 + (row >> 6)) * 64 + (kk & 3) * 16 + (row & 15))) * 4 + ((row >> 4) & 3)] = v;
+  if (l >= 1)  // transposed image A'[i = k][k' = row]
+    packed[L.rb_off + ((size_t)(((row >> 2) * 4 + (k >> 6)) * 64 + (row & 3) * 16 + (k & 15))) * 4 + ((k >> 4) & 3)] = v;
+}
+
 // "Weight panels in LDS" images of the bf16 path (inr_siren_bf16_impl.h; layout and the constant factors that ride in the
 // images: inr_w2.h): weight W_l[row][k] goes into the forward panels of layer l -- times w0 / 2 pi for the sine layers, so
 // that their accumulators are phases in revolutions -- and, for l >= 1, into the transposed panels (out index = k,
@@ -333,6 +349,7 @@ __device__ __forceinline__ void adam_pack_entry(const NetDesc& nd, int i, float 
         }
         put_fwd(nd, L, l, packed, row, k, p);
         if (L.pb_off >= 0) put_tr(L, packed, row, k, p);
+        if (nd.rs) put_rs(nd, L, l, packed, row, k, p);
         return;
       }
       const int ob = i - L.b_off;

@@ -58,12 +58,15 @@ struct LayerDesc {
   float omega, s0;   // activation constants of this layer's OUTPUT (SIREN w0 / WIRE omega_0, scale_0)
   int live;          // 0: dead layer of MultiscaleKFourier (never gets a gradient; Adam skips it)
   int korder;        // k order of the forward image: 0 natural (k = 2s+half), 1 gauss split (half ? E+s : s)
+  int rf_off, rb_off;// row-split plans (inr_mlp_rs_impl.h): offsets into packed of the 16x16x4 fragment images, forward
+                     // A[i=out][k=in] and transposed A[i=in][k=out]; -1: none
 };
 
 struct NetDesc {
   int D;             // number of Linear layers the network chains (MFN: all descriptors)
   int ND;            // number of LayerDesc entries in L[] (== D except WIRE2D: D + D - 1)
   int orth0;         // WIRE2D: L[orth0 + l] = scale_orth of layer l (0 <= l < D - 1)
+  int rs;            // 1: fused steps run the row-split kernel (inr_mlp_rs_impl.h): L[l].rf_off / rb_off are valid
   int bf16;          // 1: bf16 throughput path: the packed images are the panel stream of inr_siren_bf16_impl.h
   int w2_off;        // bf16 plans: offset (floats) into packed of the "weight panels in LDS" stream (inr_w2.h); -1: none
   int w2_bias_off;   // ... and of its fp32 bias table [D][256]

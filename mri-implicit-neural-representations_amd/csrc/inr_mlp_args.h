@@ -31,6 +31,9 @@ struct MlpArgs {
   float* dz_state;     // bf16 plans: the plan's gradient-scale state (inr_w2.h), W2_STATE_FLOATS floats on the device
   int tile0;           // first tile of this launch (tiles [tile0, n_tiles)); accumulate: the workgroups' slabs and loss
   int accumulate;      // words already hold an earlier launch's sums of the same step -- add to them
+  // row-split fused step (inr_mlp_rs_impl.h): tile t = round * grid + workgroup owns rs_hi column blocks of 16
+  // coordinates if t < rs_x, else rs_lo, blocks in tile order; n_tiles = 128-coordinate stash slots
+  int rs_hi, rs_lo, rs_x, rs_rounds;
 };
 
 
