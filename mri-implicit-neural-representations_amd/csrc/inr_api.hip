@@ -711,17 +711,24 @@ static bool step_schedule(const inr_plan* plan, int64_t nt, int64_t nb, StepSche
 struct RsSchedule {
   int grid, rounds, ncb, hi, lo, x;
 };
+// Tiles are at most 7 column blocks wide: the kernel keeps 16 NCB accumulators and 16 NCB act' values per lane in AGPRs,
+// and at NCB = 8 that is all 256 of them -- the compiler's own AGPR copies then push act' into scratch (measured: the
+// forward GEMMs at 88-98 k cycles instead of 71 k).
+constexpr int kRsMaxNcb = 7;
 static RsSchedule rs_schedule(int64_t nt) {
   const int64_t nblk = 8 * nt;
   RsSchedule s;
   s.grid = (int)std::min<int64_t>(kMaxBlocks, nblk);
   double best = 1e30;
-  s.rounds = 1, s.ncb = 8;
+  s.rounds = 1, s.ncb = kRsMaxNcb;
   const int64_t rmax = nblk / s.grid + 1;
   for (int64_t R = 1; R <= rmax; ++R) {
     const int64_t T = s.grid * R, a = nblk / T, rem = nblk % T, ncb = rem ? a + 1 : a;
-    if (ncb > 8 || ncb < 1) continue;
-    const double cost = (double)R * ((double)ncb + 1.0);
+    if (ncb > kRsMaxNcb || ncb < 1) continue;
+    // the busiest workgroup's blocks (workgroup 0: the `hi` tiles come first) + a block's worth of fixed work per round
+    const int64_t lo = rem == 0 ? a : (a % 2 == 0 ? a : a - 1), x = rem == 0 ? T : (a % 2 == 0 ? rem : (nblk - (a - 1) * T) / 2);
+    const int64_t nhi = std::min<int64_t>(R, (x + s.grid - 1) / s.grid);
+    const double cost = (double)(nhi * ncb + (R - nhi) * lo) + 0.9 * (double)R;
     if (cost < best - 1e-9) best = cost, s.rounds = (int)R, s.ncb = (int)ncb;
   }
   const int64_t T = (int64_t)s.grid * s.rounds, a = nblk / T, rem = nblk % T;
@@ -736,9 +743,16 @@ static RsSchedule rs_schedule(int64_t nt) {
 }
 
 static bool rs_plan(const inr_plan* plan) { return plan->nd.rs != 0; }
-static bool rs_enabled() {  // (read per call: tests compare the two fused kernels in one process)
+// Which fused kernel runs a batch of nt 128-coordinate slots?  The row-split kernel, unless inr_mlp_kernel's rounds of 256
+// tiles are (all but) full: then both do the same MFMA work and the row-split kernel only adds a round (65 536 rows:
+// 6 + 6 + 4 column blocks per workgroup, 649 us against 629 us; 25 000 rows: 266 us against 316 us).
+// INR_RS=0 / 1 in the environment forces one or the other (read per call: tests compare the two in one process).
+static bool rs_enabled(int64_t nt) {
   const char* e = getenv("INR_RS");
-  return !(e != nullptr && e[0] == '0');
+  if (e != nullptr && e[0] == '0') return false;
+  if (e != nullptr && e[0] == '1') return true;
+  const int64_t rounds = (nt + kMaxBlocks - 1) / kMaxBlocks;
+  return (double)nt < 0.97 * (double)(rounds * kMaxBlocks);
 }
 
 static int launch_rs(const inr_plan* plan, const LossDesc& ld, inr::MlpArgs a, int64_t nt, const RsSchedule& sc,
@@ -755,8 +769,7 @@ static int launch_rs(const inr_plan* plan, const LossDesc& ld, inr::MlpArgs a, i
     case 4: e = inr::launch_mlp_rs_n4(nd, ld, a, sc.grid, st); break;
     case 5: e = inr::launch_mlp_rs_n5(nd, ld, a, sc.grid, st); break;
     case 6: e = inr::launch_mlp_rs_n6(nd, ld, a, sc.grid, st); break;
-    case 7: e = inr::launch_mlp_rs_n7(nd, ld, a, sc.grid, st); break;
-    default: e = inr::launch_mlp_rs_n8(nd, ld, a, sc.grid, st); break;
+    default: e = inr::launch_mlp_rs_n7(nd, ld, a, sc.grid, st); break;
   }
   if (e != hipSuccess) return hip_fail(e, "inr row-split kernel launch");
   return INR_OK;
@@ -1064,7 +1077,7 @@ int inr_backward(const inr_plan* plan, const float* params, const float* packed,
 static int run_fused_step(const inr_plan* plan, const LossDesc& ld, const inr::MlpArgs& a, int64_t nt, int64_t nb,
                           float* grads, float* loss_out, const float* params, const float* packed, hipStream_t st,
                           const char* who, const AdamFuse* af = nullptr) {
-  if (a.dw_gemm == 1 && rs_plan(plan) && rs_enabled()) {
+  if (a.dw_gemm == 1 && rs_plan(plan) && rs_enabled(nt)) {
     // row-split kernel: one launch of whole rounds (no partial round to overlap), then the batch GEMM and the reduction
     // over its grid's slabs
     const RsSchedule rs = rs_schedule(nt);

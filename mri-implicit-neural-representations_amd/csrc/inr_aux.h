@@ -73,7 +73,6 @@ hipError_t launch_mlp_rs_n4(const NetDesc& nd, const LossDesc& ld, const MlpArgs
 hipError_t launch_mlp_rs_n5(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int grid, hipStream_t st);
 hipError_t launch_mlp_rs_n6(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int grid, hipStream_t st);
 hipError_t launch_mlp_rs_n7(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int grid, hipStream_t st);
-hipError_t launch_mlp_rs_n8(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int grid, hipStream_t st);
 hipError_t launch_mlp_nb8(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int mode, int grid, hipStream_t st);
 hipError_t launch_wire_nb2(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int mode, int grid, hipStream_t st);
 hipError_t launch_wire_nb4(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int mode, int grid, hipStream_t st);

@@ -39,6 +39,7 @@ constexpr int RS_CP = 32;                         // encoder phases per chunk: 6
 constexpr int RS_CHUNK_FLOATS = 2 * RS_CP * RS_PITCH;
 constexpr int RS_CHUNK_STEPS = 2 * RS_CP / 4;     // k-steps of 4 per chunk
 constexpr int RS_PF = 8;                          // weight fragments are requested this many k-steps ahead
+constexpr int RS_LR = 8;                          // act' loads of the backward GEMMs in flight (8-byte accesses)
 constexpr int RS_OOB = 0x7ffffff0;                // per-lane offset of a column block that does not exist: loads 0, stores dropped
 constexpr int RS_HSZ = 256 * 128;                 // floats per stashed tensor of a slot
 
@@ -86,6 +87,31 @@ __device__ __forceinline__ float rs_load1(__amdgpu_buffer_rsrc_t rs, int voff, i
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
 }
 
+// act' (16 NCB values per lane) lives in AGPRs for its whole life, explicitly: with the accumulators (16 NCB AGPRs) that is
+// the whole accumulator file at NCB = 8 and leaves the 256 arch VGPRs to everything else.  Left to the register allocator
+// the array sat in VGPRs (the budget then holds by a handful of registers and any edit tips it into scratch, with an
+// s_waitcnt vmcnt(0) per k-step) or in AGPRs used directly as vector-memory data -- which stalls the matrix pipe (42 cycles
+// per MFMA instead of 35: profiles/r04_rs_agpr_stores.txt).  So: v_accvgpr_write where a value is formed,
+// v_accvgpr_read into a VGPR right before it is stored or multiplied; loads land in VGPRs and move over later.
+// (NCB = 8 would be all 256 AGPRs: the compiler's own AGPR copies then push act' into scratch.  Keeping four of the 16 rows
+// in VGPRs instead -- in_agpr = false -- was tried and lost them to scratch in the backward GEMM all the same: tiles stop
+// at 7 column blocks, inr_api.hip kRsMaxNcb.)
+__device__ __forceinline__ float rs_dk_put(bool in_agpr, float v) {  // (in_agpr folds once the row loops are unrolled)
+  if (!in_agpr) return v;
+  float a;
+  asm("v_accvgpr_write_b32 %0, %1" : "=a"(a) : "v"(v));
+  return a;
+}
+__device__ __forceinline__ float rs_dk_get(bool in_agpr, float a) {
+  if (!in_agpr) return a;
+  float v;
+  asm("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a));
+  return v;
+}
+// is act' of row (rb, reg) of an NCB-wide tile kept in AGPRs?
+template <int NCB>
+constexpr bool rs_dk_agpr(int rb, int reg) { return true; }
+
 // column block c of a lane's B fragment: b0 = column blocks 0..3, b1 = 4..7
 __device__ __forceinline__ float rs_bval(const f32x4& b0, const f32x4& b1, int c) { return c < 4 ? b0[c] : b1[c - 4]; }
 
@@ -122,22 +148,28 @@ __device__ __forceinline__ void rs_store_crow(const RsAddr<NCB>& ad, int soff, c
 // ---------------------------------------------------------------------------------------------
 // One GEMM: acc[rb][c] += A[rows of this wave][k] . B[k][coordinates], NSTEPS k-steps of 4, fully unrolled.
 //   Ar: ring of RS_PF weight fragments, holding k-steps 0 .. RS_PF-1 on entry and the first RS_PF k-steps of the NEXT
-//       GEMM (image at byte offset asoff_next) on exit -- the weight stream never restarts.
+//       GEMM (image at byte offset asoff_next) on exit -- the weight stream does not restart between GEMMs.
 //   Bl: the lane's base into the LDS image: region + kq PITCH + 8 jj.
 //   soffB: where the B rows go (KIND FEAT: sines; soffB2: cosines), row 0 of the region; soffD: act' tensor, row 64 w.
-//   ZERO: the accumulators start at zero (the first k-step's MFMAs take a constant C: nothing is zeroed or kept live).
+//   INIT: 0: accumulate into acc; 1: the accumulators start at zero (the first k-step's MFMAs take a constant C: nothing is
+//   zeroed or kept live); 2: they start at cinit[rb] (the layer's bias of the lane's rows: z = b + W h in one chain).
 // ---------------------------------------------------------------------------------------------
-template <int NCB, int NSTEPS, int KIND, bool ZERO>
+template <int NCB, int NSTEPS, int KIND, int INIT>
 __device__ __forceinline__ void rs_gemm(f32x4 (&acc)[4][NCB], f32x4 (&Ar)[RS_PF], const __amdgpu_buffer_rsrc_t ars,
                                         const int avoff, const int asoff, const int asoff_next, const lfloat* Bl,
                                         const RsAddr<NCB>& ad, const int w, const int soffB, const int soffB2,
-                                        f32x2 (&dk)[4][4][(NCB + 1) / 2], const int soffD) {
+                                        f32x2 (&dk)[4][4][(NCB + 1) / 2], const int soffD, const f32x4 (&cinit)[4]) {
   constexpr int NP = (NCB + 1) / 2;
   constexpr int NQ = (NCB + 3) / 4;
   static_assert(NSTEPS % RS_PF == 0, "the fragment ring must be in phase at the start of every GEMM");
+  f32x2 lr[RS_LR];  // (KIND BWD) act' pairs on their way from memory to the AGPRs
   f32x4 b0, b1 = {0.f, 0.f, 0.f, 0.f};
   b0 = *(const lf32x4*)(Bl);
   if (NQ > 1) b1 = *(const lf32x4*)(Bl + 4);
+  const lfloat* Blw = Bl + w * 4 * RS_PITCH;  // rows of k-step s + w
+  f32x4 st0, st1 = {0.f, 0.f, 0.f, 0.f};
+  st0 = *(const lf32x4*)(Blw);
+  if (NQ > 1) st1 = *(const lf32x4*)(Blw + 4);
 #pragma unroll
   for (int s = 0; s < NSTEPS; ++s) {
     const f32x4 afr = Ar[s % RS_PF];
@@ -150,12 +182,18 @@ __device__ __forceinline__ void rs_gemm(f32x4 (&acc)[4][NCB], f32x4 (&Ar)[RS_PF]
       n0 = *(const lf32x4*)(Bl + (s + 1) * 4 * RS_PITCH);
       if (NQ > 1) n1 = *(const lf32x4*)(Bl + (s + 1) * 4 * RS_PITCH + 4);
     }
-    // stash traffic of this k-step
-    if ((s & 3) == w) {  // (wave-uniform) every fourth k-step is this wave's to store
-      if (KIND == RS_KIND_FEAT)
-        rs_store_brows<NCB>(ad, (s < NSTEPS / 2 ? soffB + 4 * s * 512 : soffB2 + 4 * (s - NSTEPS / 2) * 512), b0, b1);
-      else
-        rs_store_brows<NCB>(ad, soffB + 4 * s * 512, b0, b1);
+    // stash traffic of this k-step.  B rows: at every fourth k-step each wave stores the rows of k-step s + w, which it reads
+    // from the image for that purpose one k-step earlier (two more LDS reads per four k-steps) -- storing from the operand
+    // registers needed a branch on the wave number in every k-step, and a GEMM that is one basic block can have its loads
+    // and stores placed between the MFMAs.
+    if ((s & 3) == 0) {
+      const int rowb = KIND == RS_KIND_FEAT ? (s < NSTEPS / 2 ? soffB + 4 * s * 512 : soffB2 + 4 * (s - NSTEPS / 2) * 512)
+                                            : soffB + 4 * s * 512;
+      rs_store_brows<NCB>(ad, rowb + w * 2048, st0, st1);
+    }
+    if ((s & 3) == 3 && s + 1 < NSTEPS) {  // rows of k-step (s + 1) + w, stored at the next k-step
+      st0 = *(const lf32x4*)(Blw + (s + 1) * 4 * RS_PITCH);
+      if (NQ > 1) st1 = *(const lf32x4*)(Blw + (s + 1) * 4 * RS_PITCH + 4);
     }
     if (KIND == RS_KIND_FWD || KIND == RS_KIND_BWD) {
       // accesses j of 16 NP spread over the k-steps; j -> (rb, reg, p)
@@ -167,36 +205,56 @@ __device__ __forceinline__ void rs_gemm(f32x4 (&acc)[4][NCB], f32x4 (&Ar)[RS_PF]
         const int so = soffD + (16 * rb + reg) * 512;
         const bool single = (NCB & 1) && p == NP - 1;
         if (KIND == RS_KIND_FWD) {
-          // act' must sit in arch VGPRs here.  Left alone, the NCB = 8 build kept it in AGPRs (256 + 256 registers, the
-          // accumulators take half of the AGPRs) and stored straight from them: a vector-memory instruction with AGPR
-          // data stalled the matrix pipe -- 42 cycles per MFMA instead of 35, the backward loads likewise (measured:
-          // profiles/r04_rs_agpr_stores.txt).  The empty statement pins the pair to VGPRs for its whole life.
-          asm volatile("" : "+v"(dk[rb][reg][p]));
           if (single)
-            rs_store1(ad.rs, ad.cC[p], so, dk[rb][reg][p][0]);
+            rs_store1(ad.rs, ad.cC[p], so, rs_dk_get(rs_dk_agpr<NCB>(rb, reg), dk[rb][reg][p][0]));
           else
-            rs_store2(ad.rs, ad.cC[p], so, dk[rb][reg][p][0], dk[rb][reg][p][1]);
+            rs_store2(ad.rs, ad.cC[p], so, rs_dk_get(rs_dk_agpr<NCB>(rb, reg), dk[rb][reg][p][0]),
+                      rs_dk_get(rs_dk_agpr<NCB>(rb, reg), dk[rb][reg][p][1]));
         } else {
+          // the load of RS_LR accesses ago has arrived (it is RS_LR / NP .. k-steps old): to its AGPRs
+          if (j >= RS_LR) {
+            const int jo = j - RS_LR, ro = jo / NP, po = jo % NP;
+            dk[ro >> 2][ro & 3][po][0] = rs_dk_put(rs_dk_agpr<NCB>(ro >> 2, ro & 3), lr[jo % RS_LR][0]);
+            if (!((NCB & 1) && po == NP - 1))
+              dk[ro >> 2][ro & 3][po][1] = rs_dk_put(rs_dk_agpr<NCB>(ro >> 2, ro & 3), lr[jo % RS_LR][1]);
+          }
           if (single) {
-            dk[rb][reg][p][0] = rs_load1(ad.rs, ad.cC[p], so);
-            dk[rb][reg][p][1] = 0.f;
+            lr[j % RS_LR][0] = rs_load1(ad.rs, ad.cC[p], so);
+            lr[j % RS_LR][1] = 0.f;
           } else {
-            dk[rb][reg][p] = rs_load2(ad.rs, ad.cC[p], so);
+            lr[j % RS_LR] = rs_load2(ad.rs, ad.cC[p], so);
           }
         }
       }
     }
-    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int c = 0; c < NCB; ++c) {
       const float bv = rs_bval(b0, b1, c);
 #pragma unroll
       for (int rb = 0; rb < 4; ++rb)
-        acc[rb][c] = mfma16(afr[rb], bv, (ZERO && s == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[rb][c]);
+        acc[rb][c] = mfma16(afr[rb], bv,
+                            (INIT == 1 && s == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : ((INIT == 2 && s == 0) ? cinit[rb] : acc[rb][c]));
+    }
+    // one memory / LDS / vector instruction behind each of the first MFMAs: they issue while the matrix pipe works
+    // (bunched in front of the MFMAs they cost the pipe ~100 idle cycles per k-step)
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+      __builtin_amdgcn_sched_group_barrier(0x1b6, 1, 0);  // one of: VALU, SALU, vector memory, LDS
     }
     __builtin_amdgcn_sched_barrier(0);
     b0 = n0;
     b1 = n1;
+  }
+  if (KIND == RS_KIND_BWD) {  // the last RS_LR loads
+    constexpr int TOT = 16 * NP;
+#pragma unroll
+    for (int jo = TOT - RS_LR; jo < TOT; ++jo) {
+      const int ro = jo / NP, po = jo % NP;
+      dk[ro >> 2][ro & 3][po][0] = rs_dk_put(rs_dk_agpr<NCB>(ro >> 2, ro & 3), lr[jo % RS_LR][0]);
+      if (!((NCB & 1) && po == NP - 1))
+        dk[ro >> 2][ro & 3][po][1] = rs_dk_put(rs_dk_agpr<NCB>(ro >> 2, ro & 3), lr[jo % RS_LR][1]);
+    }
   }
 }
 
@@ -228,10 +286,38 @@ __device__ __forceinline__ void rs_gen(lfloat* buf, const lfloat* encB_lds, int 
   }
 }
 
+// What the last hidden layer parks in LDS across the loss section instead of (h, act'): the sine's reduced argument in
+// revolutions (SIREN: h = sin, act' = w0 cos are one transcendental each from it) or z itself (FFN).
+template <int HACT>
+__device__ __forceinline__ float rs_act_park(float z, float w0, float& h) {
+  if (HACT == ACT_SIN) {
+    constexpr float c_hi = 0.15915494309189535f;
+    constexpr float c_lo = (float)(0.15915494309189533576888 - (double)c_hi);
+    const float t = w0 * z;  // (as act_fwd / sincos_cw: the same roundings)
+    const float k = rintf(t * c_hi);
+    const float rev = fmaf(t, c_lo, fmaf(t, c_hi, -k));
+    h = __builtin_amdgcn_sinf(rev);
+    return rev;
+  }
+  float d;
+  act_fwd<HACT>(z, w0, h, d);
+  return z;
+}
+template <int HACT>
+__device__ __forceinline__ void rs_act_unpark(float p, float w0, float& h, float& d) {
+  if (HACT == ACT_SIN) {
+    h = __builtin_amdgcn_sinf(p);
+    d = w0 * __builtin_amdgcn_cosf(p);
+  } else {
+    act_fwd<HACT>(p, w0, h, d);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Epilogue of the LAST hidden layer + the last layer (MO = 2 or 4 output rows computed) + the pointwise loss + their
-// adjoint, all on the vector ALUs.  In: acc = z_{D-2} - bias of the lane's rows (C layout); the image is free.
-// h_{D-2} goes to the lane's own rows of the image (only this lane reads them back), act' stays in dk.
+// adjoint, all on the vector ALUs.  In: acc = z_{D-2} of the lane's rows (C layout); the image is free.
+// The parked form of z_{D-2} (rs_act_park) goes to the lane's own rows of the image -- only this lane reads them back,
+// after the barriers, and forms h_{D-2} and act' again: no register array lives across the section.
 // Out: dZ_{D-2} in the lane's rows of the image; dW_last / db_last added to the workgroup's slab; returns this thread's
 // loss contribution.  Two workgroup barriers inside; the caller syncs before the image is read.
 // ---------------------------------------------------------------------------------------------
@@ -245,9 +331,10 @@ struct RsLast {
 
   template <int MO>
   __device__ __forceinline__ float run(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, const f32x4 (&acc)[4][NCB],
-                                       f32x2 (&dk)[4][4][(NCB + 1) / 2], const float (&gt_pre)[4],
-                                       const float (&lb_pre)[4], const float* bias, float w0) {
-    constexpr int NQ = (NCB + 3) / 4, NP = (NCB + 1) / 2;
+                                       const float (&gt_pre)[4], const float (&lb_pre)[4], float w0) {
+    constexpr int NQ = (NCB + 3) / 4;
+    constexpr int NW = 4;
+    (void)NW;  // (INR_STAMP)
     const LayerDesc& LL = nd.L[nd.D - 1];
     float loss = 0.f;
     // h = act(z), act'; partial outputs over the lane's 16 rows: W_last[o][64 w + 16 rb + 4 kq + (0..3)] . h
@@ -256,29 +343,28 @@ struct RsLast {
     for (int o = 0; o < MO; ++o) yp[o][0] = yp[o][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) {
-      const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + 16 * rb);
       f32x4 wv[MO];
 #pragma unroll
       for (int o = 0; o < MO; ++o) wv[o] = *(const lf32x4*)(wl_lds + o * 256 + 64 * w + 16 * rb + 4 * kq);
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
-        f32x4 hq[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        f32x4 hq[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, pq[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
         for (int c = 0; c < NCB; ++c) {
-          float h, d;
-          act_fwd<HACT>(acc[rb][c][reg] + b4[reg], w0, h, d);
+          float h;
+          pq[c >> 2][c & 3] = rs_act_park<HACT>(acc[rb][c][reg], w0, h);
           hq[c >> 2][c & 3] = h;
-          dk[rb][reg][c >> 1][c & 1] = d;
         }
-        if (NCB & 1) dk[rb][reg][NP - 1][1] = 0.f;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-          *(lf32x4*)(Cl + (16 * rb + reg) * RS_PITCH + 4 * q) = hq[q];
+          *(lf32x4*)(Cl + (16 * rb + reg) * RS_PITCH + 4 * q) = pq[q];
 #pragma unroll
           for (int o = 0; o < MO; ++o) yp[o][q] += wv[o][reg] * hq[q];
         }
+        __builtin_amdgcn_sched_barrier(0);  // one row at a time: hoisting the rows' reads over each other ran into scratch
       }
     }
+    INR_STAMP(50);
     // the four lane quarters (kq) hold different rows: add them (fixed tree), quarter 0 writes part[w][o][jj][c]
 #pragma unroll
     for (int o = 0; o < MO; ++o)
@@ -286,6 +372,8 @@ struct RsLast {
       for (int q = 0; q < 2; ++q)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
+          // (v_permlane16_swap / v_permlane32_swap would do this without LDS round trips; as clang builtins they returned
+          // wrong sums inside this kernel though not alone -- tools/probes/permlane_swap_probe.hip -- and are not used)
           float v = yp[o][q][e];
           v += __shfl_xor(v, 16);
           v += __shfl_xor(v, 32);
@@ -299,7 +387,9 @@ struct RsLast {
         *(lf32x4*)(pp + 4) = yp[o][1];
       }
     }
+    INR_STAMP(51);
     __syncthreads();
+    INR_STAMP(52);
     if (tid < 128) {  // one coordinate per thread: the four waves' partials in wave order, activation, loss, dZ_last
       float zl[4], y[4], dy[4], g[4] = {0.f, 0.f, 0.f, 0.f}, dz[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -310,7 +400,12 @@ struct RsLast {
               part[(3 * MO + o) * 128 + tid];
         zl[o] = o < nd.out_f ? s + lb_pre[o] : 0.f;
       }
-      const int nrows = last_layer_act(nd.last_act, nd.out_f, nd.w0, zl, y, dy);
+      const int nrows = nd.out_f;  // (real last activations only: INR_ACT_CTANH is WIRE2D's)
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        y[o] = dy[o] = 0.f;
+        if (o < nd.out_f) act_fwd_rt(nd.last_act, zl[o], nd.w0, y[o], dy[o]);
+      }
       if (lvalid) {
 #pragma unroll
         for (int o = 0; o < 4; ++o)
@@ -321,20 +416,11 @@ struct RsLast {
           if (o < nrows) dz[o] = g[o] * dy[o];
       }
 #pragma unroll
-      for (int o = 0; o < MO; ++o) {
-        dzl[o * 128 + tid] = dz[o];
-        float sdz = dz[o];  // db_last: sum over the wave's 64 coordinates, fixed tree
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) sdz += __shfl_xor(sdz, off);
-        if (lane == 0) red[4 * w + o] = sdz;
-      }
+      for (int o = 0; o < MO; ++o) dzl[o * 128 + tid] = dz[o];
     }
+    INR_STAMP(53);
     __syncthreads();
-    if (tid < MO && tid < LL.M) {
-      const float tot = red[tid] + red[4 + tid];
-      float* sb = slab + LL.gb_off + tid;
-      *sb = first ? tot : *sb + tot;
-    }
+    INR_STAMP(54);
     // dZ_last of this lane's coordinates
     f32x4 dzv[MO][2];
 #pragma unroll
@@ -342,20 +428,56 @@ struct RsLast {
 #pragma unroll
       for (int q = 0; q < 2; ++q)
         dzv[o][q] = q < NQ ? *(const lf32x4*)(dzl + o * 128 + jj * 8 + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
-    typedef __attribute__((address_space(1))) float gfloat;
-    gfloat* sw = (gfloat*)(slab + LL.gw_off);
+    // db_last[o] = sum of dZ_last[o] over the tile: this lane's NCB blocks, then the 16 jj (wave 0, quarter 0 stores).
+    // All slab entries of this section are stored together at its end: a store followed by anything that waits on the
+    // vector-memory counter (a spilled register coming back, say) costs the store's whole round trip.
+    const __amdgpu_buffer_rsrc_t rsb = uniform_rsrc(slab + LL.gb_off, LL.M * 4);
+    float db_mine, dw_mine[4];
+    {
+      float sb[MO];
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb) {
+      for (int o = 0; o < MO; ++o) {
+        sb[o] = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) sb[o] += dzv[o][c >> 2][c & 3];
+      }
+      group_sum_n<16, MO>(sb);
+      float mine = sb[0];
+#pragma unroll
+      for (int o = 1; o < MO; ++o) mine = jj == o ? sb[o] : mine;
+      db_mine = mine;
+    }
+    // dW_last: one slab entry per lane and row block -- lane jj of a 16-lane row keeps entry (o, reg) = (jj >> 2, jj & 3)
+    const __amdgpu_buffer_rsrc_t rsw = uniform_rsrc(slab + LL.gw_off, LL.M * LL.K * 4);
+    {
+      // the lane's 16 rows, one at a time, the next row's parked values requested while this one is worked on
+      f32x4 nx[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) nx[q] = *(const lf32x4*)(Cl + 4 * q);
       f32x4 wv[MO];
-#pragma unroll
-      for (int o = 0; o < MO; ++o) wv[o] = *(const lf32x4*)(wl_lds + o * 256 + 64 * w + 16 * rb + 4 * kq);
       float pw[MO * 4];
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
+      for (int rr = 0; rr < 16; ++rr) {
+        const int rb = rr >> 2, reg = rr & 3;
         lfloat* row = Cl + (16 * rb + reg) * RS_PITCH;
-        f32x4 hq[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, dq[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        if (reg == 0) {
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) hq[q] = *(const lf32x4*)(row + 4 * q);
+          for (int o = 0; o < MO; ++o) wv[o] = *(const lf32x4*)(wl_lds + o * 256 + 64 * w + 16 * rb + 4 * kq);
+        }
+        f32x4 hq[2] = {nx[0], nx[1]}, dq[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        f32x4 dd[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        if (rr + 1 < 16) {
+#pragma unroll
+          for (int q = 0; q < NQ; ++q)
+            nx[q] = *(const lf32x4*)(Cl + (16 * ((rr + 1) >> 2) + ((rr + 1) & 3)) * RS_PITCH + 4 * q);
+        }
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) {  // h_{D-2} and act' again, from the parked form
+          float h, d;
+          rs_act_unpark<HACT>(hq[c >> 2][c & 3], w0, h, d);
+          hq[c >> 2][c & 3] = h;
+          dd[c >> 2][c & 3] = d;
+        }
         // dW_last[o][row] = sum over the tile's coordinates of dZ_last[o] h[row]: the lane's NCB blocks here, the 16 jj below
 #pragma unroll
         for (int o = 0; o < MO; ++o) {
@@ -364,31 +486,49 @@ struct RsLast {
           for (int c = 0; c < NCB; ++c) sp = fmaf(dzv[o][c >> 2][c & 3], hq[c >> 2][c & 3], sp);
           pw[o * 4 + reg] = sp;
         }
-        // dZ_{D-2} = (W_last^T dZ_last) * act'(z_{D-2}) over h in the lane's own row of the image
+        // dZ_{D-2} = (W_last^T dZ_last) * act'(z_{D-2}) -> the lane's own row of the image
 #pragma unroll
         for (int c = 0; c < NCB; ++c) {
           float sd = 0.f;
 #pragma unroll
           for (int o = 0; o < MO; ++o) sd = fmaf(wv[o][reg], dzv[o][c >> 2][c & 3], sd);
-          dq[c >> 2][c & 3] = sd * dk[rb][reg][c >> 1][c & 1];
+          dq[c >> 2][c & 3] = sd * dd[c >> 2][c & 3];
         }
 #pragma unroll
         for (int q = 0; q < NQ; ++q) *(lf32x4*)(row + 4 * q) = dq[q];
-      }
-      group_sum_n<16, MO * 4>(pw);
-      if (jj == 0) {  // (every lane of a 16-lane row holds the row's sums)
+        if (reg == 3) {
+          group_sum_n<16, MO * 4>(pw);  // (every lane of a 16-lane row now holds the row's sums)
+          float mine = pw[0];
 #pragma unroll
-        for (int o = 0; o < MO; ++o)
-#pragma unroll
-          for (int reg = 0; reg < 4; ++reg) {
-            const int rowi = 64 * w + 16 * rb + 4 * kq + reg;
-            if (o < LL.M && rowi < LL.K) {
-              gfloat* q = sw + o * LL.K + rowi;
-              *q = first ? pw[o * 4 + reg] : *q + pw[o * 4 + reg];
-            }
-          }
+          for (int i = 1; i < MO * 4; ++i) mine = jj == i ? pw[i] : mine;
+          dw_mine[rb] = mine;
+        }
+        __builtin_amdgcn_sched_barrier(0);  // one row at a time: hoisting the rows' reads over each other ran into scratch
       }
     }
+    {
+      const int so_ = jj >> 2;
+      int off[5];
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) {
+        const int rowi = 64 * w + 16 * rb + 4 * kq + (jj & 3);
+        off[rb] = (jj < MO * 4 && so_ < LL.M && rowi < LL.K) ? (so_ * LL.K + rowi) * 4 : RS_OOB;
+      }
+      off[4] = (w == 0 && kq == 0 && jj < MO && jj < LL.M) ? jj * 4 : RS_OOB;
+      if (!first) {  // a later tile of this workgroup: add to the slab (all five loads in flight together)
+        float old[5];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) old[rb] = rs_load1(rsw, off[rb], 0);
+        old[4] = rs_load1(rsb, off[4], 0);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) dw_mine[rb] += old[rb];
+        db_mine += old[4];
+      }
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) rs_store1(rsw, off[rb], 0, dw_mine[rb]);
+      rs_store1(rsb, off[4], 0, db_mine);
+    }
+    INR_STAMP(55);
     return loss;
   }
 };
@@ -497,76 +637,89 @@ __global__ __launch_bounds__(256) void inr_mlp_rs_kernel(const NetDesc nd, const
     __syncthreads();  // the previous tile's last GEMM has read the image; encB / W_last are staged
     f32x4 acc[4][NCB];
     f32x2 dk[4][4][NP];
+    f32x4 bnext[4];  // the bias of the lane's rows (C layout) of the layer whose GEMM comes next: its accumulators start there
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb)
+    for (int rb = 0; rb < 4; ++rb) {
+      bnext[rb] = *reinterpret_cast<const f32x4*>(a.packed + nd.L[0].pbias_off + 64 * w + 4 * kq + 16 * rb);
 #pragma unroll
-      for (int c = 0; c < NCB; ++c) acc[rb][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int c = 0; c < NCB; ++c) acc[rb][c] = bnext[rb];
+    }
     // ================================ layer 0: encoder features by chunks ================================
     rs_gen<NCB>(img, encB_lds, 0, xs, tid);
     __syncthreads();
     for (int ch = 0; ch < nch; ++ch) {
+      if (ch == 1) INR_STAMP(56);
       if (ch + 1 < nch) rs_gen<NCB>(img + ((ch + 1) & 1) * RS_CHUNK_FLOATS, encB_lds, ch + 1, xs, tid);
+      if (ch == 1) INR_STAMP(57);
       const int ao = (nd.L[0].rf_off + ch * RS_CHUNK_STEPS * 1024) * 4;
       const int an = ch + 1 < nch ? ao + RS_CHUNK_STEPS * 4096 : (D > 2 ? nd.L[1].rf_off : nd.L[0].rf_off) * 4;
       const int sb = enc_off + ch * RS_CP * 512;
-      rs_gemm<NCB, RS_CHUNK_STEPS, RS_KIND_FEAT, false>(acc, Ar, ars, avoff, ao, an, Bl + (ch & 1) * RS_CHUNK_FLOATS, ad,
-                                                        w, sb, sb + E * 512, dk, 0);
+      rs_gemm<NCB, RS_CHUNK_STEPS, RS_KIND_FEAT, 0>(acc, Ar, ars, avoff, ao, an, Bl + (ch & 1) * RS_CHUNK_FLOATS, ad, w, sb,
+                                                    sb + E * 512, dk, 0, bnext);
+      if (ch == 1) INR_STAMP(58);
       __syncthreads();  // chunk buffer (ch & 1) may be refilled; after the last chunk: the image is free
+      if (ch == 1) INR_STAMP(59);
     }
     INR_STAMP(1);
-    // ================================ forward epilogues and hidden layers ================================
-    for (int l = 0; l <= D - 2; ++l) {
-      if (l > 0) {
-        const LayerDesc& Ll = nd.L[l];
-        const int an = l < D - 2 ? nd.L[l + 1].rf_off * 4 : nd.L[D - 2].rb_off * 4;  // (D - 2 >= 1 here)
-        rs_gemm<NCB, 64, RS_KIND_FWD, true>(acc, Ar, ars, avoff, Ll.rf_off * 4, an, Bl, ad, w,
-                                            (2 * (l - 1)) * RS_HSZ * 4, 0, dk,
-                                            ((2 * (l - 1) + 1) * RS_HSZ + 64 * w * 128) * 4);
-        INR_STAMP(1 + l);
-        __syncthreads();  // every wave has read h_{l-1}: the owners may overwrite their rows
-      }
-      const float* bias = a.packed + nd.L[l].pbias_off + 64 * w + 4 * kq;
-      const float w0 = nd.L[l].omega;
-      if (l < D - 2) {
-        // z = acc + bias, h = act(z) -> the owner's rows of the image, act'(z) -> dk (stored during the next GEMM)
+    // ================================ forward: epilogue of layer l-1, GEMM of layer l ================================
+    // (the loop is rotated -- epilogue first -- so that the last hidden layer's section below sits BEHIND it: inside the
+    // loop the compiler must assume another iteration follows and keeps act' alive across everything in the body)
+    for (int l = 1; l <= D - 2; ++l) {
+      {
+        // (requested now, used by this iteration's first MFMAs)
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+          bnext[rb] = *reinterpret_cast<const f32x4*>(a.packed + nd.L[l].pbias_off + 64 * w + 4 * kq + 16 * rb);
+        // z_{l-1} = acc (bias included), h = act(z) -> the owner's rows of the image, act'(z) -> dk (stored during the GEMM)
+        const float w0 = nd.L[l - 1].omega;
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) {
-          const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + 16 * rb);
 #pragma unroll
           for (int reg = 0; reg < 4; ++reg) {
             f32x4 hq[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
             for (int c = 0; c < NCB; ++c) {
               float h, d;
-              act_fwd<HACT>(acc[rb][c][reg] + b4[reg], w0, h, d);
+              act_fwd<HACT>(acc[rb][c][reg], w0, h, d);
               hq[c >> 2][c & 3] = h;
-              dk[rb][reg][c >> 1][c & 1] = d;
+              dk[rb][reg][c >> 1][c & 1] = rs_dk_put(rs_dk_agpr<NCB>(rb, reg), d);
             }
-            if (NCB & 1) dk[rb][reg][NP - 1][1] = 0.f;
 #pragma unroll
             for (int q = 0; q < NQ; ++q) *(lf32x4*)(Cl + (16 * rb + reg) * RS_PITCH + 4 * q) = hq[q];
+            __builtin_amdgcn_sched_barrier(0);
           }
         }
-      } else {
-        // ======================== last hidden layer, last layer, loss, adjoint of the last layer ========================
-        INR_STAMP(10);
-        RsLast<NCB, HACT> ls{wl_lds, dzl, red, part, Cl, slab, lvalid, sampled_pre, first, lrow, w, kq, jj, tid, lane};
-        if (LL.M > 2)
-          loss_acc += ls.template run<4>(nd, ld, a, acc, dk, gt_pre, lb_pre, bias, w0);
-        else
-          loss_acc += ls.template run<2>(nd, ld, a, acc, dk, gt_pre, lb_pre, bias, w0);
       }
-      __syncthreads();  // the image holds h_l (l < D-2) or dZ_{D-2}
-      INR_STAMP(20 + l);
+      if (l == 1) INR_STAMP(60);
+      __syncthreads();  // the image holds h_{l-1}
+      INR_STAMP(20 + l - 1);
+      const LayerDesc& Ll = nd.L[l];
+      const int an = l < D - 2 ? nd.L[l + 1].rf_off * 4 : nd.L[D - 2].rb_off * 4;
+      rs_gemm<NCB, 64, RS_KIND_FWD, 2>(acc, Ar, ars, avoff, Ll.rf_off * 4, an, Bl, ad, w, (2 * (l - 1)) * RS_HSZ * 4, 0, dk,
+                                       ((2 * (l - 1) + 1) * RS_HSZ + 64 * w * 128) * 4, bnext);
+      INR_STAMP(1 + l);
+      __syncthreads();  // every wave has read h_{l-1}: the owners may overwrite their rows
+      if (l == 1) INR_STAMP(61);
     }
+    // ======================== last hidden layer, last layer, loss, adjoint of the last layer ========================
+    INR_STAMP(10);
+    {
+      RsLast<NCB, HACT> ls{wl_lds, dzl, red, part, Cl, slab, lvalid, sampled_pre, first, lrow, w, kq, jj, tid, lane};
+      if (LL.M > 2)
+        loss_acc += ls.template run<4>(nd, ld, a, acc, gt_pre, lb_pre, nd.L[D - 2].omega);
+      else
+        loss_acc += ls.template run<2>(nd, ld, a, acc, gt_pre, lb_pre, nd.L[D - 2].omega);
+    }
+    __syncthreads();  // the image holds dZ_{D-2}
+    INR_STAMP(20 + D - 2);
     INR_STAMP(11);
     // ================================ backward ================================
     // the image holds dZ_l; l = D-2 .. 1: dH_{l-1} = W_l^T dZ_l, dZ_{l-1} = dH_{l-1} * act'(z_{l-1})
     for (int l = D - 2; l >= 1; --l) {
       const LayerDesc& Ll = nd.L[l];
       const int an = (l > 1 ? nd.L[l - 1].rb_off : nd.L[0].rf_off) * 4;  // (last GEMM of the tile: the next tile's layer 0)
-      rs_gemm<NCB, 64, RS_KIND_BWD, true>(acc, Ar, ars, avoff, Ll.rb_off * 4, an, Bl, ad, w, (2 * l + 1) * RS_HSZ * 4, 0,
-                                          dk, ((2 * (l - 1) + 1) * RS_HSZ + 64 * w * 128) * 4);
+      rs_gemm<NCB, 64, RS_KIND_BWD, 1>(acc, Ar, ars, avoff, Ll.rb_off * 4, an, Bl, ad, w, (2 * l + 1) * RS_HSZ * 4, 0, dk,
+                                       ((2 * (l - 1) + 1) * RS_HSZ + 64 * w * 128) * 4, bnext);
       INR_STAMP(12 + l);
       if (l > 1) {
         __syncthreads();  // every wave has read dZ_l
@@ -576,7 +729,7 @@ __global__ __launch_bounds__(256) void inr_mlp_rs_kernel(const NetDesc nd, const
           for (int reg = 0; reg < 4; ++reg) {
             f32x4 dq[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-            for (int c = 0; c < NCB; ++c) dq[c >> 2][c & 3] = acc[rb][c][reg] * dk[rb][reg][c >> 1][c & 1];
+            for (int c = 0; c < NCB; ++c) dq[c >> 2][c & 3] = acc[rb][c][reg] * rs_dk_get(rs_dk_agpr<NCB>(rb, reg), dk[rb][reg][c >> 1][c & 1]);
 #pragma unroll
             for (int q = 0; q < NQ; ++q) *(lf32x4*)(Cl + (16 * rb + reg) * RS_PITCH + 4 * q) = dq[q];
           }
@@ -595,7 +748,7 @@ __global__ __launch_bounds__(256) void inr_mlp_rs_kernel(const NetDesc nd, const
           f32x4 dq[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
           if (D > 2) {
 #pragma unroll
-            for (int c = 0; c < NCB; ++c) dq[c >> 2][c & 3] = acc[rb][c][reg] * dk[rb][reg][c >> 1][c & 1];
+            for (int c = 0; c < NCB; ++c) dq[c >> 2][c & 3] = acc[rb][c][reg] * rs_dk_get(rs_dk_agpr<NCB>(rb, reg), dk[rb][reg][c >> 1][c & 1]);
           } else {
 #pragma unroll
             for (int q = 0; q < NQ; ++q) dq[q] = *(const lf32x4*)(Cl + (16 * rb + reg) * RS_PITCH + 4 * q);

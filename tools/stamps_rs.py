@@ -65,3 +65,22 @@ for i, name in order[1:]:
     seg = d[:, :, i] - d[:, :, prev]
     print(f"  {name:>52s}: mean {seg.mean():9.0f}  per-wave {[round(float(seg[:, w].mean())) for w in range(4)]}  max {seg.max():.0f}")
     prev = i
+
+def seg(a, b, name):
+    x = d[:, :, b] - d[:, :, a]
+    print(f"  {name:>52s}: mean {x.mean():9.0f}  per-wave {[round(float(x[:, w].mean())) for w in range(4)]}  max {x.max():.0f}")
+print("inside the last-layer section:")
+seg(10, 50, "last hidden epilogue + partial outputs")
+seg(50, 51, "quarter sums (shuffles) + partials -> LDS")
+seg(51, 52, "barrier")
+seg(52, 53, "loss lanes")
+seg(53, 54, "barrier")
+seg(54, 55, "dW_last, dZ_{D-2} -> image")
+print("layer 0, chunk 1:")
+seg(56, 57, "features of chunk 2")
+seg(57, 58, "GEMM of chunk 1 (16 k-steps)")
+seg(58, 59, "barrier")
+print("hidden layer 1 epilogue:")
+seg(2, 61, "barrier")
+seg(61, 60, "activation + image rows")
+seg(60, 21, "barrier")
