@@ -8,13 +8,17 @@
  *   - every function returns 0 on success, <0 on error; inr_last_error() gives the message
  *     (thread-local); nothing throws or aborts across the ABI;
  *   - all tensor arguments are DEVICE pointers to contiguous row-major fp32 buffers owned by the
- *     caller; the library never allocates device memory and retains no pointer across calls;
+ *     caller; the library retains no pointer across calls and allocates no device memory -- with ONE exception:
+ *     an INR_PRECISION_BF16 plan owns 32 bytes of device memory, its gradient-scale state (inr_plan_grad_scale_state),
+ *     allocated with hipMalloc and initialised with a synchronous hipMemcpy by the first call that needs it on a device
+ *     (a step, a backward, or inr_plan_grad_scale_state), freed by inr_plan_destroy.  That first call must therefore run
+ *     OUTSIDE stream capture;
  *   - all work is ordered on the hipStream_t passed as `stream` (void*); no implicit sync.  One exception to
  *     "enqueued on": a fused step whose tiles leave the last round of the persistent grid partly empty runs part of
  *     its weight-gradient GEMM on a low-priority side stream the plan creates on first use, forked from and joined
  *     back into `stream` with events inside the call (csrc/inr_api.hip step_schedule; INR_OVERLAP=0 disables it) --
  *     to the caller the call still behaves as work on `stream`, including under stream capture;
- *   - a plan's description is immutable after creation (that side stream is its only state) and it may be shared
+ *   - a plan's description is immutable after creation (that side stream, and a bf16 plan's scale state, are its only state) and it may be shared
  *     between threads and streams as long as each in-flight call has its own workspace buffers.
  *
  * Parameter layout ("flat params", P floats): layer k's weight [M_k, K_k] (PyTorch [out,in]
@@ -35,7 +39,7 @@
 extern "C" {
 #endif
 
-#define INR_ABI_VERSION 5
+#define INR_ABI_VERSION 6
 
 /* error codes */
 #define INR_OK 0
@@ -178,6 +182,16 @@ int inr_plan_launch_dims(const inr_plan* plan, int64_t B, int64_t* n_tiles, int6
  * (inr_sizes.step_save_by_tile), n_blocks otherwise -- and the number of slabs (of slab_floats) behind `slabs` for
  * the step and backward entry points: n_blocks, plus one per K-chunk of that GEMM. */
 int inr_plan_workspace(const inr_plan* plan, int64_t B, int64_t* step_save_slots, int64_t* n_slabs);
+/* (v6) Which kernel runs the fused step (inr_train_step*) of a batch of B rows, for benchmarks and tests; no reference
+ * counterpart.  row_split = 1: inr_mlp_rs_kernel<ncb, .> -- the four waves of a workgroup split the OUTPUT rows of every layer
+ * and share the tile's coordinates, dealt in column blocks of 16 (SIREN / FFN behind the fused gauss encoder, hidden width
+ * 129..256): `grid` workgroups run `rounds` tiles each, tile t = round * grid + workgroup holds `hi` blocks if t < n_hi, else
+ * `lo`.  row_split = 0: the plan's per-coordinate-tile kernel (inr_mlp_kernel, inr_mfn_kernel, inr_siren_bf16_kernel, ...):
+ * grid = n_blocks of inr_plan_launch_dims, rounds = ceil(n_tiles / grid), the other fields 0. */
+typedef struct inr_step_info {
+  int32_t row_split, ncb, grid, rounds, hi, lo, n_hi, reserved;
+} inr_step_info;
+int inr_plan_step_info(const inr_plan* plan, int64_t B, inr_step_info* out);
 /* INR_PRECISION_BF16 plans (v5).  Their backward pass stashes dZ in 8 bits under a power-of-two scale that follows the
  * gradient's magnitude from step to step; the eight words of that state live on the device with the plan (layout:
  * csrc/inr_w2.h -- [0..3] fused steps, [4..7] split steps: next scale, bits of the last step's largest scaled |dZ|, the

@@ -857,6 +857,22 @@ int inr_plan_workspace(const inr_plan* plan, int64_t B, int64_t* step_save_slots
   return INR_OK;
 }
 
+int inr_plan_step_info(const inr_plan* plan, int64_t B, inr_step_info* out) {
+  if (plan == nullptr || out == nullptr) return fail(INR_ERR_INVALID, "inr_plan_step_info: null argument");
+  int64_t nt, nb;
+  const int rc = inr_plan_launch_dims(plan, B, &nt, &nb);
+  if (rc != INR_OK) return rc;
+  memset(out, 0, sizeof(*out));
+  if (rs_plan(plan) && dw_gemm_plan(plan) && rs_enabled(nt)) {
+    const RsSchedule s = rs_schedule(nt);
+    out->row_split = 1, out->ncb = s.ncb, out->grid = s.grid, out->rounds = s.rounds;
+    out->hi = s.hi, out->lo = s.lo, out->n_hi = s.x;
+  } else {
+    out->grid = (int32_t)nb, out->rounds = (int32_t)((nt + nb - 1) / nb);
+  }
+  return INR_OK;
+}
+
 int inr_plan_grad_scale_state(const inr_plan* plan, float* host_out, void* stream) {
   if (plan == nullptr || host_out == nullptr) return fail(INR_ERR_INVALID, "inr_plan_grad_scale_state: null argument");
   if (!plan->nd.bf16) return fail(INR_ERR_INVALID, "inr_plan_grad_scale_state: not an INR_PRECISION_BF16 plan");

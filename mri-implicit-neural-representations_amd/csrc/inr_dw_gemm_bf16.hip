@@ -411,12 +411,6 @@ __global__ __launch_bounds__(GB_NT, 2) void dw_gemm_bf16_kernel(const DwGemmBf16
     kc = b / others, u = a.n_enc_units + b - kc * others, tpc = a.tiles_per_chunk;
   }
   const DwGemmBf16Unit& it = a.unit[u];
-#ifdef GB_EXP_NOENC  // timing experiment: the first-layer units leave at once
-  if (it.z_off < 0) return;
-#endif
-#ifdef GB_EXP_ONLYENC  // ... or all the others
-  if (it.z_off >= 0) return;
-#endif
   if (it.z_off < 0) {
     if (it.n0 == 0)
       dwgb_body<TL, true, true, false>(a, it, kc, tpc, lds_raw);

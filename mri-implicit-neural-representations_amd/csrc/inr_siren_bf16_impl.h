@@ -123,9 +123,6 @@ constexpr int pn_min(int a, int b) { return a < b ? a : b; }
 constexpr int pn_max(int a, int b) { return a > b ? a : b; }
 
 __device__ __forceinline__ void pn_issue(const PnRing& r, int img, int slot) {
-#ifdef EXP_NODMA  // timing experiment: the panels are never fetched (results meaningless)
-  return;
-#endif
   // (through a buffer descriptor: scalar image offset + one 32-bit lane offset formed once -- as global_load_lds the
   // compiler formed a 64-bit vector address per image up front, and spilled them)
   char* dst = r.ring + slot * W2_PANEL_BYTES + (2 * r.w) * 1024;
@@ -146,9 +143,7 @@ template <int N>
 __device__ __forceinline__ void pn_begin(PnRing& r) {
   static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit field");
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-#ifndef EXP_NOBARRIER  // timing experiment: no rendezvous (results meaningless)
   __builtin_amdgcn_s_barrier();
-#endif
 }
 // fragment f of the panel at stream position p: ONE address register per panel (opaque to the compiler, which otherwise
 // forms the sixteen lane addresses up front, a register each, and adds the slot to every one of them) + f KB as an immediate
@@ -295,9 +290,6 @@ struct SirenTile {
   // slice T of 16 (RATE 1) or of 8 (RATE 2: two values, nothing behind slot 7)
   template <int L, int MM, int RATE, int T>
   __device__ __forceinline__ void fwd_slice(const f32x16& acc) {
-#ifdef EXP_NOSLICE  // timing experiment: no epilogue work behind the MFMAs of the hidden layers
-    return;
-#endif
     if constexpr (RATE == 1) {
       fwd_value<L, MM, T>(acc);
     } else if constexpr (T < 8) {
@@ -363,9 +355,6 @@ struct SirenTile {
   }
   template <int E, int RATE, int T>
   __device__ __forceinline__ void bwd_slice(const f32x16& acc) {
-#ifdef EXP_NOSLICE
-    return;
-#endif
     if constexpr (RATE == 1) {
       bwd_value<E, T>(acc);
     } else if constexpr (T < 8) {
@@ -405,11 +394,7 @@ struct SirenTile {
     static_for<0, PN_FD>([&](auto tc) { A[decltype(tc)::value] = pn_frag(r, pb0, decltype(tc)::value); });
     static_for<0, 32>([&](auto qc) {
       constexpr int q = decltype(qc)::value, nq = q + PN_FD;
-#ifdef EXP_NOFRAG  // timing experiment: one fragment read per interval, multiplied 32 times (results meaningless)
-      if constexpr (nq < 32) A[nq] = A[0];
-#else
       if constexpr (nq < 32) A[nq] = pn_frag(r, nq < 16 ? pb0 : pb1, nq & 15);
-#endif
       // (acc2[1] still feeds the first block's slices: it is cleared by its own first MFMA)
       acc2[q >> 4] = mfma_bf16(A[q], __builtin_bit_cast(bf16x8, b[q & 15]), (q & 15) == 0 ? zero16() : acc2[q >> 4]);
       if constexpr (q < 16)
@@ -438,14 +423,7 @@ struct SirenTile {
       ts_bytes = (tile_ok && a.save != nullptr) ? w2_stash_dwords(D) * 4 : 0;  // 0: every stash access is a no-op
       // the lane's byte offset inside an 8-bit tensor (inr_w2.h): its half tile, quad parity = lane half, own coordinate
       voff = ((wcol >> 6) * (W2_TENSOR_DWORDS / 2) + half * W2_HALF + (wcol & (W2_HALF - 1))) * 4;
-#ifdef EXP_NOSTASH  // timing experiment: no stash traffic at all (results meaningless)
-      ts_bytes = 0;
-#endif
-#ifdef EXP_NOSTORE  // timing experiment: the stash stores are dropped, the loads stay
-      rs_tile = uniform_rsrc(sv, 0);
-#else
       rs_tile = uniform_rsrc(sv, ts_bytes);
-#endif
       if (BWD) rz_tile = w2_rsrc_words(sv, ts_bytes);
       if (FWD) {  // coordinates, sampling mask and target row in one batch of loads (row 0 where the lane has none)
         const long long cr = valid ? crow : 0;
@@ -529,9 +507,7 @@ struct SirenTile {
                   constexpr int m = decltype(mc)::value;
                   if constexpr (s < 3) A[(s + 1) & 1][m] = pn_frag(r, pb[(s + 1) >> 1], ((s + 1) & 1) * 8 + m);
                   acc8[m] = mfma_bf16(A[s & 1][m], __builtin_bit_cast(bf16x8, bq[hh][s]), acc8[m]);
-#ifndef EXP_NOGEN  // timing experiment: layer 0 multiplies the first chunk's features again and again
                   gen_value(nxt, nxt2, sc, mc, bq[hh ^ 1]);
-#endif
                   __builtin_amdgcn_sched_barrier(0);
                 });
               });
@@ -674,9 +650,6 @@ __global__ __launch_bounds__(512, 2) void inr_siren_bf16_kernel(const NetDesc nd
   // MODE.FP16_OVFL: conversions to fp16 and bf8 saturate at the largest finite value instead of overflowing to infinity
   // (tools/probes/bf8_clamp_probe.hip) -- a dZ beyond the gradient scale's headroom is clipped, not turned into NaNs
   if (MODE != MODE_FWD) asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1");
-#ifdef EXP_SETPRIO
-  if (w >= 4) __builtin_amdgcn_s_setprio(1);
-#endif
   float* bias_lds = reinterpret_cast<float*>(lds_raw + PN_SLOTS * W2_PANEL_BYTES);  // [D][256]
   float* encB_lds = bias_lds + D * 256;                                             // [E][4]
   float* red_lds = encB_lds + 4 * nd.E;                                             // [8]

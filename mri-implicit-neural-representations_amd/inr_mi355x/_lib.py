@@ -36,7 +36,7 @@ class LossDesc(C.Structure):
                 ("cons_inv", C.c_float * 4)]
 
 
-ABI_VERSION = 5  # INR_ABI_VERSION of include/inr_abi.h
+ABI_VERSION = 6  # INR_ABI_VERSION of include/inr_abi.h
 
 
 class Workspace(C.Structure):
@@ -50,6 +50,12 @@ class Sizes(C.Structure):
                 ("step_save_by_tile", C.c_int64)]
 
 
+class StepInfo(C.Structure):
+    """inr_step_info: which kernel runs a batch's fused step, and how its tiles are dealt"""
+    _fields_ = [("row_split", C.c_int32), ("ncb", C.c_int32), ("grid", C.c_int32), ("rounds", C.c_int32),
+                ("hi", C.c_int32), ("lo", C.c_int32), ("n_hi", C.c_int32), ("reserved", C.c_int32)]
+
+
 # every symbol include/inr_abi.h declares: (name, restype, argtypes)
 _P = C.c_void_p
 SYMBOLS = {
@@ -60,6 +66,7 @@ SYMBOLS = {
     "inr_plan_sizes": (C.c_int, [_P, C.POINTER(Sizes)]),
     "inr_plan_launch_dims": (C.c_int, [_P, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "inr_plan_workspace": (C.c_int, [_P, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "inr_plan_step_info": (C.c_int, [_P, C.c_int64, C.POINTER(StepInfo)]),
     "inr_plan_grad_scale_state": (C.c_int, [_P, C.POINTER(C.c_float), _P]),
     "inr_pack_params": (C.c_int, [_P, _P, _P, _P]),
     "inr_encode_gauss": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P]),

@@ -21,6 +21,7 @@ import os
 import time
 from typing import Optional
 
+import numpy as np
 import torch
 import yaml
 
@@ -173,7 +174,10 @@ class INRTrainer:
         # container into its CPU quota -- 87 ms stalls every ~17 steps of the per-coil loop, profiles/r03_config5_steps.txt)
         self._mask_cum = None
         if mask is not None:
-            self._mask_cum = [0] + torch.cumsum(mask.to(torch.int64).flatten(), 0).tolist()
+            # (a numpy int64 array, not a Python list: 15 coils are 3.5 M entries -- a list of ints of that length is > 100 MB)
+            cum = np.zeros(mask.numel() + 1, dtype=np.int64)
+            np.cumsum(mask.flatten().to(torch.int64).numpy(), out=cum[1:])
+            self._mask_cum = cum
         self.mask = mask.to(torch.uint8).to(self.device).contiguous() if mask is not None else None
         # per-coil batches (MRICoilWrapperDataset, nerp_datasets.py:397-441; loader batch_size 1 = one coil,
         # models/utils.py:65-66) so that TV can see a whole coil grid
@@ -228,7 +232,7 @@ class INRTrainer:
 
     def _count(self, lo: int, hi: int) -> int:
         """sampled rows of [lo, hi) (all of them without a mask)"""
-        return hi - lo if self._mask_cum is None else self._mask_cum[hi] - self._mask_cum[lo]
+        return hi - lo if self._mask_cum is None else int(self._mask_cum[hi] - self._mask_cum[lo])
 
     def step(self, epoch: int, it: int) -> torch.Tensor:
         lo, hi = it * self.bs, min((it + 1) * self.bs, self.n)

@@ -23,7 +23,7 @@ def test_abi_header_symbols_exported():
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.inr_abi_version() == _lib.ABI_VERSION == 5
+    assert lib.inr_abi_version() == _lib.ABI_VERSION == 6
 
 
 def test_adam_schedule_table():
@@ -113,6 +113,24 @@ def test_plan_validation_and_sizes():
     assert (slots.value, slabs.value) == (196, 256 + 25)
     assert lib.inr_plan_workspace(plan, 65536, C.byref(slots), C.byref(slabs)) == 0
     assert slots.value == 512 and 256 < slabs.value <= 256 + 52
+    # which fused kernel: 25 000 rows = 1568 column blocks on 256 workgroups, 32 tiles of 7 and 224 of 6; 65 536 rows fill
+    # inr_mlp_kernel's two rounds of 256 tiles exactly and stay there; INR_RS forces either
+    info = L.StepInfo()
+    assert lib.inr_plan_step_info(plan, 25000, C.byref(info)) == 0
+    assert (info.row_split, info.ncb, info.grid, info.rounds, info.hi, info.lo, info.n_hi) == (1, 7, 256, 1, 7, 6, 32)
+    assert lib.inr_plan_step_info(plan, 65536, C.byref(info)) == 0
+    assert (info.row_split, info.grid, info.rounds) == (0, 256, 2)
+    os.environ["INR_RS"] = "1"
+    try:
+        assert lib.inr_plan_step_info(plan, 65536, C.byref(info)) == 0
+        assert (info.row_split, info.ncb, info.rounds, info.hi, info.lo, info.n_hi) == (1, 6, 3, 6, 4, 512)
+        for B in (1, 100, 129, 4133, 100000, 235520, 3532800):  # every block of every slot is dealt exactly once
+            assert lib.inr_plan_step_info(plan, B, C.byref(info)) == 0
+            T = info.grid * info.rounds
+            assert 1 <= info.ncb <= 7 and info.hi == info.ncb and (info.lo == info.hi or info.lo % 2 == 0)
+            assert info.n_hi * info.hi + (T - info.n_hi) * info.lo == 8 * ((B + 127) // 128)
+    finally:
+        del os.environ["INR_RS"]
     assert lib.inr_plan_workspace(plan, 100, C.byref(slots), C.byref(slabs)) == 0
     assert (slots.value, slabs.value) == (1, 8 + 1)  # one slot = 8 column blocks = 8 workgroups; one GEMM chunk
     assert lib.inr_plan_workspace(plan, 0, C.byref(slots), C.byref(slabs)) < 0

@@ -10,6 +10,11 @@ for tu in inr_siren_bf16_m0 inr_siren_bf16_m1 inr_siren_bf16_m2 inr_dw_gemm_bf16
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function $FLAGS -DINR_ONLY_NH=3 -c $tu.hip -o ../build_exp_$NAME/$tu.o &
 done
 wait
+# no experiment object reaches a GPU with a register of an in-flight load touched (the fault of round 3: a knock-out had
+# removed the waits of inline-assembly loads but not the loads)
+for o in ../build_exp_$NAME/*.o; do
+  python3 ../../tools/check_inflight_regs.py $o kernel || { echo "check_inflight_regs: $o fails -- not linked"; rm -rf ../build_exp_$NAME; exit 1; }
+done
 objs=$(ls ../build/*.o | grep -v "inr_siren_bf16_m\|inr_dw_gemm_bf16.o")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/libinr_exp_$NAME.so $objs ../build_exp_$NAME/*.o
 rm -rf ../build_exp_$NAME

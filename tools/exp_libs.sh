@@ -10,7 +10,8 @@ for v in "$@"; do
   if [ "$v" = base ]; then export INR_LIB_PATH=$ROOT/mri-implicit-neural-representations_amd/lib/libinr_mi355x.so
   else export INR_LIB_PATH=$ROOT/mri-implicit-neural-representations_amd/lib/libinr_exp_$v.so; fi
   rm -rf /tmp/exp_$v
-  (cd /tmp && timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/exp_$v -o x -- python3 $ROOT/tools/time_bf16.py $B ${PREC:-bf16} > /tmp/exp_$v.log 2>&1) || { echo "$v failed"; tail -5 /tmp/exp_$v.log; exit 1; }
+  # (the run's output is kept under gpurun_out/ whatever happens: a faulting experiment leaves its log behind)
+  (cd /tmp && timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/exp_$v -o x -- python3 $ROOT/tools/time_bf16.py $B ${PREC:-bf16} > $ROOT/gpurun_out/exp_$v.log 2>&1) || { echo "$v failed"; tail -5 $ROOT/gpurun_out/exp_$v.log; exit 1; }
   f=$(find /tmp/exp_$v -name '*kernel_stats.csv' | head -1)
   echo "== $v"; python3 - "$f" <<'PY'
 import csv,sys

@@ -18,6 +18,7 @@ import torch
 REF = "/root/reference/src"
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 
+sys.dont_write_bytecode = True  # the reference tree is read-only: importing it must not leave __pycache__ behind
 sys.path.insert(0, REF)
 # metrics/losses.py imports fastmri at module scope but only RadialL2Loss (unused) calls it.
 _fm = types.ModuleType("fastmri")
