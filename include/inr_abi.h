@@ -192,11 +192,13 @@ typedef struct inr_step_info {
   int32_t row_split, ncb, grid, rounds, hi, lo, n_hi, reserved;
 } inr_step_info;
 int inr_plan_step_info(const inr_plan* plan, int64_t B, inr_step_info* out);
-/* INR_PRECISION_BF16 plans (v5).  Their backward pass stashes dZ in 8 bits under a power-of-two scale that follows the
- * gradient's magnitude from step to step; the eight words of that state live on the device with the plan (layout:
+/* INR_PRECISION_BF16 plans (v5; 16 words since v6).  Their backward pass stashes dZ in 8 bits under a power-of-two scale that
+ * follows the gradient's magnitude from step to step; the sixteen words of that state live on the device with the plan (layout:
  * csrc/inr_w2.h -- [0..3] fused steps, [4..7] split steps: next scale, bits of the last step's largest scaled |dZ|, the
- * factor the last step multiplied d(loss)/d(out) by, the scale inside it).  This call waits for the work queued on
- * `stream` and copies them to host_out[8]: for tests and diagnostics (no reference counterpart).  Because of this state a
+ * factor the last step multiplied d(loss)/d(out) by, the scale inside it; [8], [9] fused steps so far whose gradients were
+ * clipped at bf8's largest finite value / mostly flushed under its subnormals, [10], [11] the same for split steps -- the scale
+ * lags the gradient by one step and has 2^10.8 of headroom; [12..15] zero).  This call waits for the work queued on
+ * `stream` and copies them to host_out[16]: for tests and diagnostics (no reference counterpart).  Because of this state a
  * bf16 plan is to be stepped from one stream at a time; the plan's first step of a kind, and a step whose loss or batch
  * size makes the remembered scale meaningless, runs the kernel twice (once to find the scale). */
 int inr_plan_grad_scale_state(const inr_plan* plan, float* host_out, void* stream);

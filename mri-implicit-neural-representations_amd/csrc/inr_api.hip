@@ -70,6 +70,10 @@ struct inr_plan {
   mutable bool dz_ready[2] = {false, false};
   mutable int64_t dz_rows[2] = {0, 0};
   mutable int dz_loss[2] = {-1, -1};
+  // bf16 GEMM chunking knobs (tuning aids), read from the environment ONCE, when the plan is created: workspace sizes must
+  // not depend on what the environment holds at the time of a later call
+  bool gemm_one_class = false;
+  double gemm_enc_cost = 0.0;  // 0: kEncCost
 };
 
 // gradient-scale state of a bf16 plan on the current device (inr_w2.h): S = mult = S_used = 1, amax = 0 for both kinds of
@@ -81,7 +85,7 @@ static float* dz_state_alloc(const inr_plan* p) {
   if (p->dz_state != nullptr) (void)hipFree(p->dz_state);
   p->dz_state = nullptr;
   p->dz_ready[0] = p->dz_ready[1] = false;
-  const float init[W2_STATE_FLOATS] = {1.f, 0.f, 1.f, 1.f, 1.f, 0.f, 1.f, 1.f};
+  const float init[W2_STATE_FLOATS] = {1.f, 0.f, 1.f, 1.f, 1.f, 0.f, 1.f, 1.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (hipMalloc(reinterpret_cast<void**>(&p->dz_state), sizeof(init)) != hipSuccess) {
     p->dz_state = nullptr;
     return nullptr;
@@ -99,14 +103,17 @@ static float* dz_state_alloc(const inr_plan* p) {
 // Yes for a plan's first step of a kind, and when what the remembered scale was derived from no longer applies: another
 // loss (fused steps normalise the batch size away, not the loss), or -- split steps, whose d(loss)/d(out) carries the
 // 1 / count -- a batch more than twice or less than half as large.  From then on the scale follows the gradient from step
-// to step (dz_state_roll) with 2^7.8 of headroom.
+// to step (dz_state_roll) with 2^10.8 of headroom above the window it aims for (inr_w2.h W2_DZ_TARGET_EXP) -- a calibration
+// pass is not counted as a clipped / flushed step (its roll gets no counters).
 static bool dz_needs_calibration(const inr_plan* p, int kind, int64_t rows, int loss_kind) {
-  const bool need = !p->dz_ready[kind] || (kind == 0 ? p->dz_loss[0] != loss_kind
-                                                      : (rows > 2 * p->dz_rows[1] || 2 * rows < p->dz_rows[1]));
+  return !p->dz_ready[kind] || (kind == 0 ? p->dz_loss[0] != loss_kind
+                                          : (rows > 2 * p->dz_rows[1] || 2 * rows < p->dz_rows[1]));
+}
+// ... remembered once the kernels that use (or found) the scale have been launched
+static void dz_mark(const inr_plan* p, int kind, int64_t rows, int loss_kind) {
   p->dz_ready[kind] = true;
   p->dz_rows[kind] = rows;
   p->dz_loss[kind] = loss_kind;
-  return need;
 }
 
 // Multiplicative filter networks (models/mfn.py).  L[] = filters 0..n | linears 0..n-1 | heads; flat
@@ -463,6 +470,8 @@ int inr_plan_create(const inr_net_desc* d, inr_plan** out) {
     // a plan touches no GPU -- tests/test_host.py sizes bf16 workspaces on the CPU)
   }
   p->packed_floats = pk;
+  p->gemm_one_class = getenv("INR_GEMM_ONE_CLASS") != nullptr;
+  if (const char* e = getenv("INR_GEMM_ENC_COST")) p->gemm_enc_cost = std::max(1.0, atof(e));
   *out = p;
   return INR_OK;
 }
@@ -598,9 +607,8 @@ static void dw_gemm_bf16_setup(const inr_plan* plan, int64_t nt, inr::DwGemmBf16
     *tpc = (int)((nt + target - 1) / target);
     *n = (int)((nt + *tpc - 1) / *tpc);
   };
-  if (run0 && getenv("INR_GEMM_ONE_CLASS") == nullptr) {
-    double cost = kEncCost;
-    if (const char* e = getenv("INR_GEMM_ENC_COST")) cost = std::max(1.0, atof(e));  // (tuning aid)
+  if (run0 && !plan->gemm_one_class) {
+    const double cost = plan->gemm_enc_cost > 0.0 ? plan->gemm_enc_cost : kEncCost;
     const double per = 256.0 / (cost * n_enc + others);  // chunks of a non-first-layer unit
     g->n_enc_units = n_enc;
     chunks((int)(per * cost), &g->tiles_per_chunk_enc, &g->n_chunks_enc);
@@ -1027,6 +1035,7 @@ static int finish_gradients(const inr_plan* plan, const inr::MlpArgs& a, int64_t
     g.encB = a.encB;
     g.B = a.B;
     g.dz_state = a.dz_state + (a.dout != nullptr ? 4 : 0);  // split steps keep their own scale
+    g.dz_count = a.dz_state + 8 + (a.dout != nullptr ? 2 : 0);
     hipError_t e = inr::launch_dw_gemm_bf16(g, st);
     if (e != hipSuccess) return hip_fail(e, (std::string(who) + ": bf16 weight-gradient GEMM").c_str());
     split = dw_gemm_bf16_split(plan, g);
@@ -1080,12 +1089,13 @@ int inr_backward(const inr_plan* plan, const float* params, const float* packed,
     if (dz_needs_calibration(plan, 1, B, 0)) {  // a pass for the scale (the forward half's stash is not touched)
       int rc = launch(plan, ld, a, 1, (int)nb, (hipStream_t)stream);
       if (rc != INR_OK) return rc;
-      hipError_t e = inr::launch_dz_roll(a.dz_state + 4, (hipStream_t)stream);
+      hipError_t e = inr::launch_dz_roll(a.dz_state + 4, nullptr, (hipStream_t)stream);
       if (e != hipSuccess) return hip_fail(e, "inr_backward: gradient-scale calibration");
     }
   }
   int rc = launch(plan, ld, a, 1, (int)nb, (hipStream_t)stream);
   if (rc != INR_OK) return rc;
+  if (w2_plan(plan)) dz_mark(plan, 1, B, 0);
   return finish_gradients(plan, a, nt, nb, grads, nullptr, params, packed, (hipStream_t)stream, "inr_backward");
 }
 
@@ -1108,12 +1118,13 @@ static int run_fused_step(const inr_plan* plan, const LossDesc& ld, const inr::M
   if (a.dw_gemm == 2 && dz_needs_calibration(plan, 0, a.B, ld.kind)) {  // bf16: a pass of the kernel for the scale
     int rc = launch(plan, ld, a, 2, (int)nb, st);
     if (rc != INR_OK) return rc;
-    hipError_t e = inr::launch_dz_roll(a.dz_state, st);
+    hipError_t e = inr::launch_dz_roll(a.dz_state, nullptr, st);
     if (e != hipSuccess) return hip_fail(e, (std::string(who) + ": gradient-scale calibration").c_str());
   }
   if (side == nullptr) {
     int rc = launch(plan, ld, a, 2, (int)nb, st);
     if (rc != INR_OK) return rc;
+    if (a.dw_gemm == 2) dz_mark(plan, 0, a.B, ld.kind);
     if (grads == nullptr) return INR_OK;  // profiling: leave the per-block slabs unreduced
     return finish_gradients(plan, a, nt, nb, grads, loss_out, params, packed, st, who, af);
   }

@@ -1,6 +1,7 @@
 // inr_dw_gemm_bf16.h -- arguments of the bf16 path's batch-level weight-gradient GEMM (inr_dw_gemm_bf16.hip)
 #pragma once
 #include <hip/hip_runtime.h>
+#include "inr_w2.h"
 
 namespace inr {
 
@@ -24,6 +25,7 @@ struct DwGemmBf16Args {
   const float* coords; // [B,3] (first-layer units)
   const float* encB;   // [E,3]
   float* dz_state;     // the 4 gradient-scale words of this kind of step (inr_w2.h); nullptr: sums leave as they are
+  float* dz_count;     // its two counters of clipped / flushed steps (nullptr: not counted)
   long long B;
   long long save_floats_per_tile;
   int slab_floats;
@@ -40,23 +42,28 @@ struct DwGemmBf16Args {
 
 hipError_t launch_dw_gemm_bf16(const DwGemmBf16Args& a, hipStream_t st);
 // the roll alone (after a calibration pass of the fused kernel: inr_api.hip)
-hipError_t launch_dz_roll(float* st, hipStream_t stream);
+hipError_t launch_dz_roll(float* st, float* cnt, hipStream_t stream);
 
 #if defined(__HIPCC__)
 // Next step's gradient scale from what this step saw: st[1] = bits of max |dZ * mult|, st[3] = the power of two S inside
 // mult.  amax / S is the step's largest |dZ| in units of the loss gradient's own normalisation (fused steps: of
-// d(loss)/d(out) * count); the next S puts it into [2^4, 2^5): 2^10.8 of headroom below bf8's largest finite value 57 344
+// d(loss)/d(out) * count); the next S puts it into [2^4, 2^5) (inr_w2.h W2_DZ_TARGET_EXP): 2^10.8 of headroom below bf8's largest finite value 57 344
 // -- sequential batches of a k-space differ by two orders of magnitude in their largest gradient (the centre of a coil
 // against its periphery); beyond the headroom the conversion saturates (the kernel runs with MODE.FP16_OVFL set: a
 // clipped step, not an infinity) --, 2^18 above bf8's smallest normal value, 2^20 above its smallest subnormal.  A step
-// whose gradient is exactly zero keeps the scale.
-__device__ __forceinline__ void dz_state_roll(float* st) {
+// whose gradient is exactly zero keeps the scale.  `cnt` (two words of the plan's state, inr_w2.h): steps whose gradients
+// were clipped / mostly flushed are counted.
+__device__ __forceinline__ void dz_state_roll(float* st, float* cnt) {
   const float amax = __builtin_bit_cast(float, reinterpret_cast<unsigned*>(st)[1]);
   if (amax > 0.f && amax < 3.0e38f) {
     int ex;
     (void)frexpf(amax / st[3], &ex);  // amax / S = f * 2^ex, f in [0.5, 1)
     ex = ex < -100 ? -100 : (ex > 100 ? 100 : ex);
-    st[0] = ldexpf(1.0f, 5 - ex);
+    st[0] = ldexpf(1.0f, W2_DZ_TARGET_EXP - ex);
+    if (cnt != nullptr) {
+      if (amax > W2_BF8_MAX) cnt[0] += 1.f;
+      if (amax < W2_DZ_LOW) cnt[1] += 1.f;
+    }
   }
   reinterpret_cast<unsigned*>(st)[1] = 0u;
 }

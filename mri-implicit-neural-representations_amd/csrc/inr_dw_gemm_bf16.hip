@@ -422,13 +422,13 @@ __global__ __launch_bounds__(GB_NT, 2) void dw_gemm_bf16_kernel(const DwGemmBf16
     dwgb_body<TL, false, true, false>(a, it, kc, tpc, lds_raw);  // hidden layers: one column tile (K <= 256), always with db
   }
   // the next step's gradient scale (inr_w2.h): nothing in this launch reads words 0 and 1
-  if (a.dz_state != nullptr && blockIdx.x == 0 && threadIdx.x == 0) dz_state_roll(a.dz_state);
+  if (a.dz_state != nullptr && blockIdx.x == 0 && threadIdx.x == 0) dz_state_roll(a.dz_state, a.dz_count);
 }
 
-__global__ void dz_roll_kernel(float* st) { dz_state_roll(st); }
+__global__ void dz_roll_kernel(float* st, float* cnt) { dz_state_roll(st, cnt); }
 
-hipError_t launch_dz_roll(float* st, hipStream_t stream) {
-  hipLaunchKernelGGL(dz_roll_kernel, dim3(1), dim3(1), 0, stream, st);
+hipError_t launch_dz_roll(float* st, float* cnt, hipStream_t stream) {
+  hipLaunchKernelGGL(dz_roll_kernel, dim3(1), dim3(1), 0, stream, st, cnt);
   return hipGetLastError();
 }
 

@@ -68,4 +68,13 @@ INR_HD inline int w2_stash_dwords(int D) { return w2_stash_dy(D) + 4 * W2_TL; }
 //   [1] amax   (uint bits of) max |dZ * mult| the last kernel saw, accumulated with atomicMax
 //   [2] mult   what the last kernel multiplied the loss gradient by (S / inv_count; S in split steps): the GEMM divides by it
 //   [3] S_used the S inside [2]
-#define W2_STATE_FLOATS 8
+//   [8 + 2 kind], [9 + 2 kind]  (kind 0 fused, 1 split) steps so far whose largest |dZ * mult| was past bf8's largest finite
+//        value (some gradients were CLIPPED) / under W2_DZ_LOW (the bulk of the gradient fell under bf8's subnormals): the
+//        scale lags the gradient by one step, and a batch whose gradient jumps by more than the headroom either way is
+//        rounded coarsely -- these counters say whether that ever happened in a fit (inr_plan_grad_scale_state)
+#define W2_STATE_FLOATS 16
+// The next step's scale puts this step's largest |dZ * mult| into [2^(W2_DZ_TARGET_EXP - 1), 2^W2_DZ_TARGET_EXP): the ONE
+// place the window is defined.  Headroom above it: log2(57344) - 5 = 10.8 binary orders before bf8 saturates.
+#define W2_DZ_TARGET_EXP 5
+#define W2_BF8_MAX 57344.0f
+#define W2_DZ_LOW 0.015625f  // 2^-6: values 2^10 below such a maximum are under bf8's smallest subnormal 2^-16

@@ -136,9 +136,10 @@ class MLPEngine:
         return int(ss.value), int(ns.value)
 
     def grad_scale_state(self):
-        """bf16 plans: the eight gradient-scale words (include/inr_abi.h: inr_plan_grad_scale_state) as a list of floats,
-        after the stream's queued work (synchronises).  Tests and diagnostics."""
-        buf = (C.c_float * 8)()
+        """bf16 plans: the sixteen gradient-scale words (include/inr_abi.h: inr_plan_grad_scale_state) as a list of floats --
+        [0..3] fused steps, [4..7] split steps, [8..11] counts of clipped / flushed steps -- after the stream's queued work
+        (synchronises).  Tests and diagnostics."""
+        buf = (C.c_float * 16)()
         L.check(self.lib.inr_plan_grad_scale_state(self.plan, buf, self._stream()))
         return [float(v) for v in buf]
 

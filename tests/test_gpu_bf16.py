@@ -99,15 +99,15 @@ def test_bf16_step_close_to_fp32(dev, B, width, depth):
     assert torch.equal(g1, e16.grads)
 
 
-def _oracle_inputs(dev, B, seed, masked):
+def _oracle_inputs(dev, B, seed, masked, depth=5, width=256, enc_size=256):
     import inr_mi355x as M
-    net = dict(FULL_NET)
+    net = dict(FULL_NET, network_depth=depth, network_width=width, network_input_size=2 * enc_size)
     torch.manual_seed(seed)
-    enc = M.Positional_Encoder(FULL_ENC, device=dev)
+    enc = M.Positional_Encoder(dict(FULL_ENC, embedding_size=enc_size), device=dev)
     model = M.SIREN(net)
     sd = {k: v.clone() for k, v in model.state_dict().items()}
     model = model.to(dev)
-    eng = model.fused_engine(256, precision="bf16")
+    eng = model.fused_engine(enc_size, precision="bf16")
     g = torch.Generator().manual_seed(seed + 1)
     coords = torch.rand(B, 3, generator=g) * 2 - 1
     gt = torch.randn(B, 2, generator=g) * 0.2
@@ -192,6 +192,98 @@ def test_bf16_split_step_matches_rounding_oracle(dev, B):
     # (the perturbation enters at the top of the chain here -- act'(z_last) of the device's own output against the oracle's --
     # and small batches show twice the fused step's distances: floors x 2)
     _check_against_rounding_oracle(model, eng, ref, ref_wide, f"split B={B}", floors=2.0)
+
+
+# every depth the kernel is instantiated for (NH = depth - 2 = 1 .. 6), padded widths, encoder sizes of one to three
+# first-layer GEMM units -- each shape held to the rounding oracle, not only the benchmark's 5 x 256 / 256
+SHAPES = [(3, 256, 256), (4, 200, 160), (6, 160, 32), (8, 256, 384), (5, 200, 96), (7, 256, 256), (4, 256, 32)]
+
+
+@pytest.mark.parametrize("depth,width,enc_size", SHAPES)
+def test_bf16_step_matches_rounding_oracle_shapes(dev, depth, width, enc_size):
+    """test_bf16_step_matches_rounding_oracle over the shapes that ship: fused step, masked and ragged (4133 rows = 33 tiles)."""
+    import oracle as O
+    import inr_mi355x as M
+    from inr_mi355x import _lib as L
+    from conftest import record_parity
+    B = 4133
+    net, enc, model, sd, eng, coords, gt, mask = _oracle_inputs(dev, B, 7 * depth + width + enc_size, True, depth, width, enc_size)
+    cnt = int(mask.sum())
+    encB = enc.B.contiguous()
+    out = eng.forward(coords.to(dev), encB).cpu()
+    loss = float(eng.train_step(coords.to(dev), encB, gt.to(dev), M.LossSpec(L.LOSS_L2_HALF), count=cnt, mask=mask.to(dev)))
+    mult = eng.grad_scale_state()[2]
+    dldy, mk = (lambda yy: (yy - gt) / (cnt * 2.0)), mask.bool()
+    y, ref, amax = O.bf16.siren_bf16_step(sd, coords, enc.B.cpu(), net, dldy, mult, mask=mk)
+    _, ref_wide, _ = O.bf16.siren_bf16_step(sd, coords, enc.B.cpu(), net, dldy, mult, mask=mk, wide_sums=True)
+    assert 2.0 ** 3 <= amax <= 2.0 ** 6, amax
+    assert float((out - y).abs().max()) < 2e-3, float((out - y).abs().max())
+    ref_loss = float(0.5 * ((y - gt)[mk] ** 2).mean())
+    assert abs(loss - ref_loss) <= 2e-3 * abs(ref_loss), (loss, ref_loss)
+    rows = _check_against_rounding_oracle(model, eng, ref, ref_wide, f"fused {depth}x{width}/E{enc_size}")
+    record_parity("bf16_shapes", depth=depth, width=width, enc_size=enc_size,
+                  e_dev_max=max(r[1] for r in rows), e_self_max=max(r[2] for r in rows))
+
+
+@pytest.mark.parametrize("depth,width,enc_size", [(3, 256, 256), (6, 160, 32), (8, 256, 384)])
+def test_bf16_split_step_matches_rounding_oracle_shapes(dev, depth, width, enc_size):
+    """the split step (forward | loss | backward, config 5's form) over shallow / narrow / deep shapes"""
+    import oracle as O
+    import inr_mi355x as M
+    from inr_mi355x import _lib as L
+    B = 4133
+    net, enc, model, sd, eng, coords, gt, mask = _oracle_inputs(dev, B, 11 * depth + width, True, depth, width, enc_size)
+    cnt = int(mask.sum())
+    encB = enc.B.contiguous()
+    out = eng.forward(coords.to(dev), encB, save=True)
+    loss, dout = eng.loss_grad(M.LossSpec(L.LOSS_L2_HALF), out, gt.to(dev), cnt, mask=mask.to(dev))
+    eng.backward(coords.to(dev), encB, dout)
+    mult = eng.grad_scale_state()[6]
+    y, ref, amax = O.bf16.siren_bf16_step(sd, coords, enc.B.cpu(), net, lambda yy: dout.cpu(), mult)
+    _, ref_wide, _ = O.bf16.siren_bf16_step(sd, coords, enc.B.cpu(), net, lambda yy: dout.cpu(), mult, wide_sums=True)
+    assert float((out.cpu() - y).abs().max()) < 2e-3
+    _check_against_rounding_oracle(model, eng, ref, ref_wide, f"split {depth}x{width}/E{enc_size}", floors=2.0)
+
+
+def test_bf16_forced_clipping_and_flushing_match_the_saturating_oracle(dev):
+    """The gradient scale lags the gradient by one step.  Three consecutive fused steps on the same rows whose loss gradients
+    differ by 2^12 and then by 2^-12 (targets scaled by 4096 in the middle step): the middle step's largest gradients are
+    CLIPPED at bf8's 57 344 (its scale still expects the first step's magnitudes), the third step's gradients sit 2^12
+    under the window and the small ones are flushed.  Both must be exactly what the rounding oracle does with a saturating
+    bf8 and the multiplier the device used -- a wrong clamp or roll is O(1) here and invisible in calibrated steps --,
+    the plan's counters must say so (inr_plan_grad_scale_state words 8, 9), and the scale must recover."""
+    import oracle as O
+    import inr_mi355x as M
+    from inr_mi355x import _lib as L
+    B = 4133
+    net, enc, model, sd, eng, coords, gt, mask = _oracle_inputs(dev, B, 4242, False)
+    encB, spec, x = enc.B.contiguous(), M.LossSpec(L.LOSS_L2_HALF), coords.to(dev)
+    big = gt * 4096.0
+
+    def step(target):
+        eng.train_step(x, encB, target.to(dev), spec)
+        st = eng.grad_scale_state()
+        dldy = lambda yy: (yy - target) / (B * 2.0)
+        y, ref, amax = O.bf16.siren_bf16_step(sd, coords, enc.B.cpu(), net, dldy, st[2])
+        _, ref_wide, _ = O.bf16.siren_bf16_step(sd, coords, enc.B.cpu(), net, dldy, st[2], wide_sums=True)
+        return st, ref, ref_wide, amax
+
+    st1, ref, wide, amax1 = step(gt)            # calibrated: in the window
+    assert 2.0 ** 3 <= amax1 <= 2.0 ** 6 and st1[8] == 0 and st1[9] == 0
+    _check_against_rounding_oracle(model, eng, ref, wide, "step 1 (calibrated)")
+    st2, ref, wide, amax2 = step(big)           # the scale of step 1 against gradients 2^11 .. 2^12 larger: clipped
+    assert amax2 > 57344.0, amax2
+    assert st2[8] == 1 and st2[9] == 0, st2
+    _check_against_rounding_oracle(model, eng, ref, wide, "step 2 (clipped)", floors=2.0)
+    st3, ref, wide, amax3 = step(gt)            # the scale of step 2 against the small gradients again: flushed
+    assert amax3 < 2.0 ** -6, amax3
+    assert st3[8] == 1 and st3[9] == 1, st3
+    # (most of the gradient is under bf8's subnormals here: the device must flush exactly what the oracle flushes; the
+    # self-distance of the oracle is large for such a step and the floors are not what bounds it)
+    _check_against_rounding_oracle(model, eng, ref, wide, "step 3 (flushed)", floors=4.0)
+    st4, ref, wide, amax4 = step(gt)            # ... and the scale is back in the window one step later
+    assert 2.0 ** 3 <= amax4 <= 2.0 ** 6 and st4[8] == 1 and st4[9] == 1, (amax4, st4)
+    _check_against_rounding_oracle(model, eng, ref, wide, "step 4 (recovered)")
 
 
 @pytest.mark.parametrize("B", [25000, 65536])

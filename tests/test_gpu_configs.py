@@ -113,6 +113,37 @@ def test_config5_bf16_tracks_fp32(dev, c5_data):
     np.testing.assert_allclose(np.array(l2b), np.array(l2a), rtol=5e-2)
 
 
+def test_config5_bf16_first_step_matches_rounding_oracle(dev, c5_data):
+    """Config 5's first per-coil step at full size (640 x 368 = 235 520 rows through forward and backward, loss on the
+    radial-4 mask's ~59 k rows, TV on the whole grid) on the bf16 kernels against the rounding oracle
+    (oracle/inr_oracle_bf16.py) -- the tight net of tests/test_gpu_bf16.py at the size and in the split form that ships;
+    the comparison with the fp32 engine above stays as the loose one.  d(loss)/d(out) (pointwise + TV) is taken from the
+    device: what is held to the oracle is the network's forward and the whole backward."""
+    from inr_mi355x.train import INRTrainer
+    from test_gpu_bf16 import _check_against_rounding_oracle
+    image, coords, shape = c5_data
+    tr = INRTrainer(_config5("bf16"), image, coords, shape, dev, seed=0, mask_seed=7)
+    H, W = shape[1], shape[2]
+    sd = {k: v.detach().cpu().clone() for k, v in tr.model.state_dict().items()}
+    eng = tr.engine
+    count = int(tr.mask_cpu[:tr.bs].sum())
+    x = tr._inputs(0, tr.bs)
+    out = eng.forward(x, tr.enc_B, save=True)
+    loss, dout = eng.loss_grad(tr.loss, out, tr.image[:tr.bs], count, mask=tr.mask[:tr.bs])
+    eng.tv_grad(out, dout, H, W, H)
+    eng.backward(x, tr.enc_B, dout)
+    mult = eng.grad_scale_state()[6]
+    net = tr.config["net"]
+    y, ref, amax = O.bf16.siren_bf16_step(sd, coords[:tr.bs], tr.encoder.B.cpu(), net, lambda yy: dout.cpu(), mult)
+    _, ref_wide, _ = O.bf16.siren_bf16_step(sd, coords[:tr.bs], tr.encoder.B.cpu(), net, lambda yy: dout.cpu(), mult,
+                                            wide_sums=True)
+    assert float((out.cpu() - y).abs().max()) < 2e-3
+    assert 2.0 ** 3 <= amax <= 2.0 ** 6, amax
+    rows = _check_against_rounding_oracle(tr.model, eng, ref, ref_wide, "config 5, first per-coil step", floors=2.0)
+    record_parity("config5:bf16", what="first step vs rounding oracle", e_dev_max=max(r[1] for r in rows),
+                  e_self_max=max(r[2] for r in rows))
+
+
 @pytest.mark.parametrize("precision", ["f32", "bf16"])
 @pytest.mark.parametrize("world", [2, 3])
 def test_config5_halo_shards_sum_to_single_rank(dev, c5_data, world, precision):

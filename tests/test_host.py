@@ -185,9 +185,15 @@ def test_bf16_plan_sizes_and_chunk_classes(monkeypatch):
         assert lib.inr_plan_workspace(plan, B, C.byref(slots), C.byref(slabs)) == 0
         assert (slots.value, slabs.value) == (ntiles, nblocks + max(n_enc, n_oth)), (B, slabs.value, n_enc, n_oth)
         assert 2 * n_enc + 4 * n_oth <= 256
+    # the chunking knobs are read when a plan is CREATED: an existing plan's workspace sizes do not follow the environment
     monkeypatch.setenv("INR_GEMM_ONE_CLASS", "1")
     assert lib.inr_plan_workspace(plan, 65536, C.byref(slots), C.byref(slabs)) == 0
+    assert slabs.value == 256 + max(chunks(512, int(256.0 / 7 * 1.5)), chunks(512, (256 - 2 * chunks(512, int(256.0 / 7 * 1.5))) // 4))
+    plan1 = C.c_void_p()
+    assert lib.inr_plan_create(C.byref(d), C.byref(plan1)) == 0, L.last_error()
+    assert lib.inr_plan_workspace(plan1, 65536, C.byref(slots), C.byref(slabs)) == 0
     assert slabs.value == 256 + chunks(512, 256 // 6)
+    lib.inr_plan_destroy(plan1)
     lib.inr_plan_destroy(plan)
     # what the bf16 kernels do not cover is refused at plan creation, not run on something else
     for bad, frag in ((dict(width=512), "bf16"), (dict(width=64, in_features=512), "bf16"), (dict(depth=9), "bf16"),
