@@ -256,6 +256,15 @@ int inr_loss_grad_multi(const inr_loss_desc* loss, const float* outs, const floa
 int inr_tv_grad(const float* out, int64_t R, int64_t R_own, int64_t W, int64_t H, float weight,
                 float* loss_out, float* dout, void* stream);
 
+/* (v6) inr_loss_grad + inr_tv_grad of one coil's rows in one pass -- the per-coil step of train.py:163-189 with use_tv:
+ * the masked pointwise loss (train.py:176-182) on the rows the caller owns (r < R_own; a data-parallel rank's halo row stays
+ * with its owner: no zeroed copy of the mask is needed) plus tv_loss (metrics/losses.py:326-343, arguments as inr_tv_grad).
+ * out / gt / dout [R][W][2], mask [R][W] bytes or NULL.  WRITES dout (does not add) and loss_out[0] = pointwise + TV loss;
+ * loss_out[1..256] is scratch: a loss_out buffer holds INR_LOSS_WORDS floats. */
+#define INR_LOSS_WORDS 512
+int inr_loss_tv_grad(const inr_loss_desc* loss, const float* out, const float* gt, const uint8_t* mask, int64_t R,
+                     int64_t R_own, int64_t W, int64_t H, float tv_weight, float* loss_out, float* dout, void* stream);
+
 /* Replaces the random-pair ("centre") term of CenterLoss.forward (metrics/losses.py:175-199; 'LSL' of train.py:87-88,
  * called at train.py:178-180) for ONE radial band: the caller draws the n row pairs (idx_a[p] from the inner mask, idx_b[p]
  * from the ring outside it) with torch.randperm exactly as the reference does (losses.py:193-194) and passes global row

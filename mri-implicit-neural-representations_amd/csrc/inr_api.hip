@@ -1214,6 +1214,24 @@ int inr_tv_grad(const float* out, int64_t R, int64_t R_own, int64_t W, int64_t H
   return INR_OK;
 }
 
+int inr_loss_tv_grad(const inr_loss_desc* loss, const float* out, const float* gt, const uint8_t* mask, int64_t R,
+                     int64_t R_own, int64_t W, int64_t H, float tv_weight, float* loss_out, float* dout, void* stream) {
+  if (loss == nullptr || out == nullptr || gt == nullptr || loss_out == nullptr || dout == nullptr)
+    return fail(INR_ERR_INVALID, "inr_loss_tv_grad: null argument");
+  if (loss->kind < INR_LOSS_L2_HALF || loss->kind > INR_LOSS_CENTER)
+    return fail(INR_ERR_INVALID, "inr_loss_tv_grad: loss kind %d", loss->kind);
+  if (R <= 0 || R_own <= 0 || R_own > R || R > R_own + 1 || W < 2 || H < 2 || R > H)
+    return fail(INR_ERR_INVALID, "inr_loss_tv_grad: R %lld R_own %lld W %lld H %lld", (long long)R, (long long)R_own,
+                (long long)W, (long long)H);
+  LossDesc ld;
+  to_loss_desc(loss, &ld);
+  const float cw = (float)((double)tv_weight / ((double)H * (double)(W - 1) * 2.0));
+  const float ch = (float)((double)tv_weight / ((double)(H - 1) * (double)W * 2.0));
+  hipError_t e = inr::launch_loss_tv_grad(ld, out, gt, mask, R, R_own, W, cw, ch, loss_out, dout, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "inr_loss_tv_grad");
+  return INR_OK;
+}
+
 int inr_center_pairs_grad(const float* out, const float* gt, const int64_t* idx_a, const int64_t* idx_b, int64_t n,
                           int64_t B, float weight, float* loss_out, float* dout, void* stream) {
   if (out == nullptr || gt == nullptr || idx_a == nullptr || idx_b == nullptr || loss_out == nullptr || dout == nullptr)

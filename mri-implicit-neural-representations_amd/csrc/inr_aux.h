@@ -53,6 +53,9 @@ hipError_t launch_loss_grad_multi(const LossDesc& ld, const float* outs, const f
 // CenterLoss random-pair term (losses.py:175-199): adds w * sum_p r_p^2 to loss_out[0] and its gradient to dout
 hipError_t launch_center_pairs(const float* out, const float* gt, const long long* ia, const long long* ib, long long n,
                                long long B, float w, float* loss_out, float* dout, hipStream_t st);
+hipError_t launch_loss_tv_grad(const LossDesc& ld, const float* out, const float* gt, const uint8_t* mask, long long R,
+                               long long R_own, long long W, float cw, float ch, float* loss_out, float* dout,
+                               hipStream_t st);
 hipError_t launch_tv_grad(const float* out, long long R, long long R_own, long long W, float cw, float ch,
                           float* loss_out, float* dout, hipStream_t st);
 

@@ -687,6 +687,95 @@ hipError_t launch_tv_grad(const float* out, long long R, long long R_own, long l
 }
 
 // ---------------------------------------------------------------------------------------------
+// inr_loss_grad + inr_tv_grad of one coil's rows in ONE pass (the per-coil step of train.py:163-189 with use_tv): a thread
+// per coordinate, 256 workgroups over the R x W grid (the two kernels above are 64 workgroups each for 6 MB of traffic:
+// 18 + 40 us of a 0.58 ms step, plus two single-thread folds and the copy that zeroed the halo rows' mask).  Pointwise loss
+// on the sampled rows the caller OWNS (r < R_own: a data-parallel rank's halo row below its slab stays with its owner),
+// TV as tv_grad_kernel.  dout is WRITTEN (not added to).  Partial sums: loss_out[1 + block], fixed order within a thread
+// (its coordinates in order), fixed tree within a block; loss_tv_fold_kernel sums the 256 partials by a fixed tree.
+// ---------------------------------------------------------------------------------------------
+#define LOSS_TV_BLOCKS 256
+
+__global__ __launch_bounds__(256) void loss_tv_grad_kernel(const LossDesc ld, const float* __restrict__ out,
+                                                           const float* __restrict__ gt, const uint8_t* __restrict__ mask,
+                                                           long long R, long long R_own, long long W, float cw, float ch,
+                                                           float* __restrict__ loss_out, float* __restrict__ dout) {
+  __shared__ float red[256];
+  const long long n = R * W;
+  const long long per = (n + LOSS_TV_BLOCKS - 1) / LOSS_TV_BLOCKS;
+  const long long lo = (long long)blockIdx.x * per;
+  const long long hi = lo + per < n ? lo + per : n;
+  const float2* __restrict__ o2 = reinterpret_cast<const float2*>(out);
+  float acc = 0.f;
+  for (long long c = lo + threadIdx.x; c < hi; c += 256) {
+    const long long r = c / W, x = c - r * W;
+    const float2 v = o2[c];
+    float g[2] = {0.f, 0.f};
+    if (r < R_own && (mask == nullptr || mask[c] != 0)) {
+      const float y[2] = {v.x, v.y};
+      const float2 tt = reinterpret_cast<const float2*>(gt)[c];
+      const float t[2] = {tt.x, tt.y};
+      acc += loss_row(ld, 2, y, t, g);
+    }
+    if (r < R_own) {
+      if (x + 1 < W) {
+        const float2 e = o2[c + 1];
+        const float d0 = v.x - e.x, d1 = v.y - e.y;
+        acc += (fabsf(d0) + fabsf(d1)) * cw;
+        g[0] += cw * sgn(d0);
+        g[1] += cw * sgn(d1);
+      }
+      if (x > 0) {
+        const float2 e = o2[c - 1];
+        g[0] -= cw * sgn(e.x - v.x);
+        g[1] -= cw * sgn(e.y - v.y);
+      }
+      if (r + 1 < R) {
+        const float2 e = o2[c + W];
+        const float d0 = v.x - e.x, d1 = v.y - e.y;
+        acc += (fabsf(d0) + fabsf(d1)) * ch;
+        g[0] += ch * sgn(d0);
+        g[1] += ch * sgn(d1);
+      }
+    }
+    if (r > 0 && r - 1 < R_own) {
+      const float2 e = o2[c - W];
+      g[0] -= ch * sgn(e.x - v.x);
+      g[1] -= ch * sgn(e.y - v.y);
+    }
+    reinterpret_cast<float2*>(dout)[c] = float2{g[0], g[1]};
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s >= 1; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss_out[1 + blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(256) void loss_tv_fold_kernel(float* loss_out) {
+  __shared__ float red[256];
+  red[threadIdx.x] = loss_out[1 + threadIdx.x];
+  __syncthreads();
+  for (int s = 128; s >= 1; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss_out[0] = red[0];
+}
+
+hipError_t launch_loss_tv_grad(const LossDesc& ld_in, const float* out, const float* gt, const uint8_t* mask, long long R,
+                               long long R_own, long long W, float cw, float ch, float* loss_out, float* dout,
+                               hipStream_t st) {
+  LossDesc ld = ld_in;
+  hipLaunchKernelGGL(loss_tv_grad_kernel, dim3(LOSS_TV_BLOCKS), dim3(256), 0, st, ld, out, gt, mask, R, R_own, W, cw, ch,
+                     loss_out, dout);
+  hipLaunchKernelGGL(loss_tv_fold_kernel, dim3(1), dim3(256), 0, st, loss_out);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // CenterLoss, random-pair term of one band (metrics/losses.py:175-199): for pairs p < n of rows (a_p, b_p) -- drawn by the
 // caller with torch.randperm exactly as the reference draws them -- r_p = (|t_a| - |t_b|) - (|y_a| - |y_b|), the band adds
 // w * sum_p r_p^2 (w = 0.1 / n) to the loss and  -2 w r_p y_a / |y_a|  to dout[a_p],  +2 w r_p y_b / |y_b|  to dout[b_p].

@@ -18,7 +18,7 @@ ACT_ID, ACT_SIN, ACT_TANH, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3, 4
 ACT_CTANH = 7  # WIRE2D last_tanh: complex Tanh before .real
 INPUT_X, INPUT_GAUSS = 0, 1
 LOSS_L2_HALF, LOSS_L1_HALF, LOSS_TANH, LOSS_LOGSPACE, LOSS_HDR, LOSS_MSLE_HALF, LOSS_CENTER = 0, 1, 2, 3, 4, 5, 6
-LOSS_WORDS = 128  # floats a loss_out buffer must hold (word 0 = loss, 1..64 = ordered partials)
+LOSS_WORDS = 512  # INR_LOSS_WORDS: floats a loss_out buffer must hold (word 0 = loss, the rest ordered partial sums)
 
 
 class NetDesc(C.Structure):
@@ -75,6 +75,8 @@ SYMBOLS = {
     "inr_backward": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, _P, C.POINTER(Workspace), _P, _P]),
     "inr_loss_grad": (C.c_int, [C.POINTER(LossDesc), _P, _P, _P, _P, C.c_int64, _P, _P, _P]),
     "inr_loss_grad_multi": (C.c_int, [C.POINTER(LossDesc), _P, _P, _P, _P, C.c_int32, C.c_int64, _P, _P, _P]),
+    "inr_loss_tv_grad": (C.c_int, [C.POINTER(LossDesc), _P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_float,
+                                   _P, _P, _P]),
     "inr_tv_grad": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_float, _P, _P, _P]),
     "inr_center_pairs_grad": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int64, C.c_float, _P, _P, _P]),
     "inr_train_step": (C.c_int, [_P, C.POINTER(LossDesc), _P, _P, _P, _P, _P, _P, C.c_int64, C.POINTER(Workspace), _P,

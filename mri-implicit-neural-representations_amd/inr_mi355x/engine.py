@@ -236,6 +236,21 @@ class MLPEngine:
                                        _ptr(dout, "dout"), self._stream()))
         return self._loss[0], dout
 
+    def loss_tv_grad(self, spec: LossSpec, out: torch.Tensor, gt: torch.Tensor, count: int, rows_own: int, W: int, H: int,
+                     mask: Optional[torch.Tensor] = None, hdr_A: float = 0.0, weight: float = 1e-4):
+        """loss_grad + tv_grad of R = out.shape[0] / W image rows in one pass (inr_loss_tv_grad): the masked pointwise loss on
+        the first rows_own rows, tv_loss (losses.py:326-343) on the grid.  Returns (loss scalar (device), dout)."""
+        R = out.shape[0] // W
+        assert R * W == out.shape[0] and out.shape[1] == 2
+        _shape(gt, "gt", out.shape[0], 2)
+        _shape(mask, "mask", out.shape[0])
+        dout = torch.empty_like(out)
+        ld = self.loss_desc(spec, count, hdr_A)
+        L.check(self.lib.inr_loss_tv_grad(C.byref(ld), _ptr(out, "out"), _ptr(gt, "gt"), _ptr(mask, "mask", torch.uint8), R,
+                                          rows_own, W, H, C.c_float(weight), _ptr(self._loss, "loss"), _ptr(dout, "dout"),
+                                          self._stream()))
+        return self._loss[0], dout
+
     def tv_grad(self, out: torch.Tensor, dout: torch.Tensor, rows_own: int, W: int, H: int,
                 weight: float = 1e-4):
         """tv_loss (losses.py:326-343) on out [R*W,2] = R image rows of width W (first rows_own owned,

@@ -344,12 +344,11 @@ class INRTrainer:
             self.engine.grads.zero_()
             return torch.zeros((), device=self.device)
         ye = min(y1 + 1, H)
-        slo, sown, shi = lo + y0 * W, lo + y1 * W, lo + ye * W
+        slo, shi = lo + y0 * W, lo + ye * W
         out = self.engine.forward(self._inputs(slo, shi), self.enc_B, save=True)
-        m = self.mask[slo:shi].clone()
-        m[sown - slo:] = 0
-        loss, dout = self.engine.loss_grad(self.loss, out, self.image[slo:shi], count, mask=m, hdr_A=A)
-        loss = self.engine.tv_grad(out, dout, y1 - y0, W, H)
+        # pointwise loss on the owned rows' sampled coordinates + TV on the grid, one pass (inr_loss_tv_grad)
+        loss, dout = self.engine.loss_tv_grad(self.loss, out, self.image[slo:shi], count, y1 - y0, W, H,
+                                              mask=self.mask[slo:shi], hdr_A=A)
         self.engine.backward(self._inputs(slo, shi), self.enc_B, dout)
         return loss
 

@@ -127,3 +127,33 @@ def test_undersampled_fused_step_matches_oracle(dev):
     ref = O.train_single_scale(cfg, sd, B, coords, masked.reshape(-1, 2), 6, mask=gm[:, 0])
     got = np.array([s[1] for s in tr.fit(6, log_every=1)])
     np.testing.assert_allclose(got, np.array(ref), rtol=5e-5)
+
+
+@pytest.mark.parametrize("halo", [0, 1])
+def test_loss_tv_grad_one_pass_matches_the_two_calls(dev, halo):
+    """inr_loss_tv_grad (one pass, 256 workgroups) == inr_loss_grad on the owned rows' sampled coordinates followed by
+    inr_tv_grad: same formulas, other summation order (losses.py:326-343; train.py:172-182).  With a halo row (a
+    data-parallel rank's slab): the halo row takes no pointwise loss although its mask bytes are set."""
+    import inr_mi355x as M
+    from inr_mi355x import _lib as L
+    H, W = 37, 52
+    R_own = 20
+    R = R_own + halo
+    g = torch.Generator().manual_seed(11 + halo)
+    out = (torch.randn(R * W, 2, generator=g) * 0.3).to(dev)
+    gt = (torch.randn(R * W, 2, generator=g) * 0.3).to(dev)
+    mask = (torch.rand(R * W, generator=g) < 0.3).to(torch.uint8).to(dev)
+    net = dict(network_input_size=16, network_output_size=2, network_depth=3, network_width=32, last_tanh=True)
+    eng = M.SIREN(net).to(dev).fused_engine(8)
+    spec = M.LossSpec(L.LOSS_L2_HALF)
+    m2 = mask.clone()
+    m2[R_own * W:] = 0
+    count = int(m2.sum())
+    l_a, d_a = eng.loss_grad(spec, out, gt, count, mask=m2)
+    l_a = float(eng.tv_grad(out, d_a, R_own, W, H))
+    d_a = d_a.clone()
+    l_b, d_b = eng.loss_tv_grad(spec, out, gt, count, R_own, W, H, mask=mask)
+    assert abs(float(l_b) - l_a) <= 1e-6 * abs(l_a), (float(l_b), l_a)
+    torch.testing.assert_close(d_b, d_a, rtol=1e-6, atol=1e-9)
+    l_c, d_c = eng.loss_tv_grad(spec, out, gt, count, R_own, W, H, mask=mask)
+    assert float(l_c) == float(l_b) and torch.equal(d_c, d_b)
