@@ -59,6 +59,15 @@ def _run(case, rank, world, pg=None):
         return [], tr.predict_all().cpu()
     else:
         tr = INRTrainer(cfg, image, coords, shape, dev, seed=1, rank=rank, world=world, process_group=pg)
+    if case.endswith("_bf16"):
+        # bf16 cases also hand back the initial weights and the (all-reduced) gradient of the first step: what a wrong
+        # shard, halo row or collective would change at O(1), where five Adam steps of lr each cannot tell
+        init = tr.engine.params.detach().cpu().clone()
+        l0 = float(tr.step(0, 0))
+        g0 = tr.engine.grads.detach().cpu().clone()
+        losses = [l0] + [s[1] for s in tr.fit(5, log_every=1)]
+        layout = [(o, n) for (o, n, s_, c) in tr.model._layout]
+        return losses, torch.cat([tr.engine.params.detach().cpu(), init, g0]), layout
     losses = [s[1] for s in tr.fit(5, log_every=1)]
     return losses, tr.engine.params.detach().cpu().clone()
 
@@ -69,8 +78,8 @@ def _worker(rank, world, port, case, q):
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        losses, params = _run(case, rank, world)
-        q.put((rank, losses, params.numpy()))
+        res = _run(case, rank, world)
+        q.put((rank, res[0], res[1].numpy()))
     finally:
         dist.destroy_process_group()
 
@@ -78,7 +87,8 @@ def _worker(rank, world, port, case, q):
 @pytest.mark.parametrize("case", ["siren", "tv", "fourier", "multiscale", "multiscale_tv", "ensemble", "siren_bf16", "tv_bf16"])
 def test_two_ranks_equal_one(case):
     assert torch.cuda.is_available()
-    ref_losses, ref_params = _run(case, 0, 1)
+    ref = _run(case, 0, 1)
+    ref_losses, ref_params = ref[0], ref[1]
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -101,8 +111,24 @@ def test_two_ranks_equal_one(case):
             # losses to 1 % (bf16 forward; the runs drift apart by the rounding of five steps), weights to five Adam steps of
             # lr each in the worst entry and to 2 % of the update in relative L2
             np.testing.assert_allclose(np.array(losses), np.array(ref_losses), rtol=1e-2, err_msg=f"{case} rank {rank}")
-            ref = ref_params.numpy()
-            assert np.abs(params - ref).max() <= 5 * 1e-4 * 1.01, np.abs(params - ref).max()
+            P = params.shape[0] // 3
+            (p2, i2, g2), (p1, i1, g1) = np.split(params, 3), np.split(ref_params.numpy(), 3)
+            np.testing.assert_array_equal(i2, i1)
+            assert np.abs(p2 - p1).max() <= 5 * 1e-4 * 1.01, np.abs(p2 - p1).max()
+            # the summed gradient of step 1, tensor by tensor, against the single-rank bf16 gradient: each shard runs under
+            # its own 8-bit gradient scale and its own tile boundaries, so the two differ by the path's rounding noise --
+            # twice the device-to-oracle distances of tests/test_gpu_bf16.py (8e-3 first layer, 4e-3 hidden, 1e-3 last) --
+            # while a dropped shard, a halo row counted twice or a missing all-reduce is 0.3 .. 1
+            nl = len(ref[2]) // 2
+            for idx, (o, n) in enumerate(ref[2]):
+                bound = 2.0 * (8e-3 if idx // 2 == 0 else (2e-3 if idx // 2 == nl - 1 else 4e-3)) * 1.5
+                num = np.linalg.norm((g2[o:o + n] - g1[o:o + n]).astype(np.float64))
+                den = np.linalg.norm(g1[o:o + n].astype(np.float64)) + 1e-30
+                assert num / den <= bound, (case, rank, idx, num / den, bound)
+            # the update after six steps: Adam's first steps move every entry by about lr whatever the gradient's size, so
+            # sign flips of near-zero gradient entries dominate -- 2 % is not reachable; a gross error is (> 0.5)
+            upd = np.linalg.norm((p2 - i2) - (p1 - i1)) / (np.linalg.norm(p1 - i1) + 1e-30)
+            assert upd <= 0.35, upd
             continue
         np.testing.assert_allclose(np.array(losses), np.array(ref_losses), rtol=2e-5, err_msg=f"{case} rank {rank}")
         if case == "ensemble":  # assembled [N,2] prediction: identical on both ranks and equal to the 1-rank sweep
