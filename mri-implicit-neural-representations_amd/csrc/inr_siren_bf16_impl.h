@@ -335,10 +335,16 @@ struct SirenTile {
       w2_wait4<(E < PN_PD ? 4 * (PN_PD + E) : 8 * PN_PD)>(pz[set]);
     }
     const unsigned pw = pz[set][g];
-    const float c = __builtin_amdgcn_cosf((float)((pw >> (8 * j)) & 255u) * 0.00390625f);
+    // cos(2 pi p / 256) with ONE instruction in front of v_cos_f32 (which takes revolutions): the float 128 + p / 256 =
+    // 0x43000000 | p << 8, its bytes picked by v_perm_b32 -- {0x43 from the constant, 0, byte j of the phase dword, 0}.
+    // (Convert + multiply were two; at one value per MFMA slot every vector instruction counts: the kernel issues ~8 per
+    // MFMA where ~5 hide, profiles/r03_bf16_pmc_by_grid.csv.)
+    const unsigned cb = __builtin_amdgcn_perm(0x43000000u, pw, 0x070C000Cu | ((unsigned)j << 8));
+    const float c = __builtin_amdgcn_cosf(__builtin_bit_cast(float, cb));
     const float dz = acc[V] * c;
     if constexpr (j & 1) {
-      amax = fmaxf(amax, fmaxf(fabsf(eprev), fabsf(dz)));
+      // amax = max(amax, |eprev|, |dz|) as the one instruction it is (the compiler made three of it)
+      asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(amax) : "v"(eprev), "v"(dz));
       epk = (unsigned)__builtin_amdgcn_cvt_pk_bf8_f32(eprev, dz, j == 1 ? 0 : (int)epk, j == 3);
       unsigned d = pack_bf16(eprev, dz);
       asm volatile("" : "+v"(d), "+v"(epk));
