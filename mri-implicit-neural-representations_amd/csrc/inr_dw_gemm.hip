@@ -115,20 +115,55 @@ __device__ __forceinline__ void dwg_body(const DwGemmArgs& a, const DwGemmItem& 
 #pragma unroll 1
   for (int s = 0; s < n_steps; ++s) {
     const int sn = s + 1;
-    if (sn < n_steps)
-      dwg_fetch(v, a.save + (size_t)(t0 + sn / KS) * a.save_floats_per_tile, roff, sn % KS);
+    // (unconditional, so that the stage is one basic block: the last stage fetches itself again and writes the buffer
+    // nobody reads any more)
+    const int sf = sn < n_steps ? sn : s;
+    dwg_fetch(v, a.save + (size_t)(t0 + sf / KS) * a.save_floats_per_tile, roff, sf % KS);
     const float* Ab = As + (s & 1) * DWG_STAGE;
     const float* Bb = Bs + (s & 1) * DWG_STAGE;
+    // The stage as ONE scheduled stream (round 4): fragments of quarter q + 1 are read while quarter q multiplies, the next
+    // stage's global loads go out behind the first MFMAs and its LDS writes behind those of the last quarter (the other
+    // stage buffer has been free since the barrier that ended the previous stage) -- every memory / LDS instruction in the
+    // matrix pipe's shadow.  Left to the compiler's order (loads, then per quarter: reads, MFMAs; writes; barrier) a
+    // stage took 4.5 us for 3.6 us of MFMAs.
+    f32x4 A[2][WBM], B[2][WB];
+#pragma unroll
+    for (int i = 0; i < WBM; ++i) A[0][i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * DWG_LD);
+#pragma unroll
+    for (int j = 0; j < WB; ++j) B[0][j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * DWG_LD);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      f32x4 A[WBM], B[WB];
+      if (q < 3) {
 #pragma unroll
-      for (int i = 0; i < WBM; ++i) A[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * DWG_LD + 8 * q);
+        for (int i = 0; i < WBM; ++i) A[(q + 1) & 1][i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * DWG_LD + 8 * (q + 1));
 #pragma unroll
-      for (int j = 0; j < WB; ++j) B[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * DWG_LD + 8 * q);
-      dwg_mma<WBM, WB, BIAS>(acc, bsum, A, B);
+        for (int j = 0; j < WB; ++j) B[(q + 1) & 1][j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * DWG_LD + 8 * (q + 1));
+      } else {
+        dwg_stash(lds + (sn & 1) * DWG_STAGE, v, t);
+      }
+      dwg_mma<WBM, WB, BIAS>(acc, bsum, A[q & 1], B[q & 1]);
+      if (q == 0) {
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // one global load of the next stage
+        }
+      }
+      if (q < 3) {
+#pragma unroll
+        for (int i = 0; i < WBM + WB; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // one fragment read of the next quarter
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // one LDS write of the next stage
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (sn < n_steps) dwg_stash(lds + (sn & 1) * DWG_STAGE, v, t);
     __syncthreads();
   }
   float* slab = a.slabs + (size_t)kc * a.slab_floats;
