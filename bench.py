@@ -331,6 +331,31 @@ def config4_shard_sweep(tr, dev, reps=6):
         return e0.elapsed_time(e1) / n
 
     t_adam = timed(lambda: eng.adam_step(lr, tr.config["beta1"], tr.config["beta2"], 1e-8, tr.config["weight_decay"]), reps)
+
+    def sharded_local(n):
+        """what MLPEngine.adam_step_sharded launches on a rank of n besides the two collectives: Adam on P / n entries, the
+        chunk copies, the copy back of the gathered vector and the re-pack"""
+        from inr_mi355x import _lib as L
+        from inr_mi355x.engine import _ptr
+        P = eng.n_params
+        chunk = -(-(P + 1) // n)
+        gchunk, pchunk, pgather = (torch.zeros(chunk, device=dev), torch.zeros(chunk, device=dev),
+                                   torch.zeros(chunk * n, device=dev))
+        pgather[:P].copy_(eng.params)
+        hi_ = min(chunk, P)
+
+        def fn():
+            eng.step += 1
+            L.check(eng.lib.inr_adam_step_shard(eng.plan, _ptr(eng.params, "params"), _ptr(gchunk, "g"),
+                                                _ptr(eng.exp_avg, "m"), _ptr(eng.exp_avg_sq, "v"), 0, hi_, lr,
+                                                tr.config["beta1"], tr.config["beta2"], 1e-8, tr.config["weight_decay"],
+                                                0.0, 0.0, eng.step, eng._stream()))
+            pchunk.copy_(gchunk)
+            pchunk[:hi_].copy_(eng.params[:hi_])
+            eng.params.copy_(pgather[:P])
+            eng.pack()
+        return timed(fn, reps)
+
     t1 = None
     for n in (1, 2, 4, 8):
         shi = lo + (hi - lo) // n
@@ -340,10 +365,15 @@ def config4_shard_sweep(tr, dev, reps=6):
         if n == 1:
             t1 = t_grad + t_adam
         ar = [2.0 * (n - 1) / n * out["allreduce_bytes"] / (rings * 100e9) * 1e3 for rings in (1, 4)]
+        t_sh = sharded_local(n) if n > 1 else t_adam
         out["by_n"][str(n)] = {"rows": shi - lo, "tiles": nt, "workgroups": nb, "grad_path_ms": t_grad, "adam_ms": t_adam,
+                               "sharded_update_ms": t_sh,
                                "allreduce_est_ms": {"one_ring": ar[0], "four_rings": ar[1]},
                                "ceiling": {"one_ring": t1 / (t_grad + t_adam + ar[0]),
-                                           "four_rings": t1 / (t_grad + t_adam + ar[1])}}
+                                           "four_rings": t1 / (t_grad + t_adam + ar[1])},
+                               # reduce-scatter + all-gather move the bytes of one ring all-reduce
+                               "ceiling_sharded_update": {"one_ring": t1 / (t_grad + t_sh + ar[0]),
+                                                          "four_rings": t1 / (t_grad + t_sh + ar[1])}}
     return out
 
 
@@ -386,7 +416,8 @@ def multiscale_config4(dev, rank, world, pg, steps, warmup, barrier):
             "scaling": "strong", "global_batch": tr.bs, "steps": steps, "warmup": warmup,
             "ms_per_step": dt / steps * 1e3, "radii": [float(r) for r in tr.radii],
             "achieved_tflops_all_gpus": ach, "frac_f32_mfma_per_gpu": ach / world / F32_MFMA_PEAK_TFLOPS,
-            "allreduce_bytes": 4 * (tr.engine.n_params + 1)}
+            "allreduce_bytes": 4 * (tr.engine.n_params + 1),
+            "update": "sharded (reduce-scatter, Adam on 1/N, all-gather, re-pack)" if tr.sharded_update else "replicated"}
 
 
 def main():

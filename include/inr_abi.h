@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define INR_ABI_VERSION 6
+#define INR_ABI_VERSION 7
 
 /* error codes */
 #define INR_OK 0
@@ -314,6 +314,16 @@ int inr_plan_heads(const inr_plan* plan, int32_t* n_heads);
 int inr_adam_step(const inr_plan* plan, float* params, const float* grads, float* exp_avg,
                   float* exp_avg_sq, float* packed, double lr, double beta1, double beta2, double eps,
                   double weight_decay, double l1, double l2, int32_t step, void* stream);
+
+/* The update of a data-parallel job whose ranks each own 1/N of the flat parameter vector (no reference counterpart:
+ * train_kspace_multiscale.py:161-201 is single-process; this is torch.optim.Adam on a slice): the same arithmetic as
+ * inr_adam_step on the entries [lo, hi) only.  `grads_shard[i - lo]` is the summed gradient of entry i -- the rank's
+ * chunk of a reduce-scatter of the flat gradient; params / exp_avg / exp_avg_sq are the full-length vectors (only
+ * [lo, hi) is read and written).  No image is refreshed: after the all-gather of the updated parameters every rank calls
+ * inr_pack_params.  lo == hi is a no-op (a rank whose chunk lies in the padding). */
+int inr_adam_step_shard(const inr_plan* plan, float* params, const float* grads_shard, float* exp_avg,
+                        float* exp_avg_sq, int64_t lo, int64_t hi, double lr, double beta1, double beta2,
+                        double eps, double weight_decay, double l1, double l2, int32_t step, void* stream);
 
 /* inr_train_step and inr_adam_step as ONE call for single-rank steps (nothing sits between the reduction and the
  * update): the Adam update and the re-pack ride in the slab reduction's launch (flat-layout plans: SIREN / FFN, fp32 and

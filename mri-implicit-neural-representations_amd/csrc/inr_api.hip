@@ -1497,6 +1497,34 @@ int inr_adam_step(const inr_plan* plan, float* params, const float* grads, float
   return INR_OK;
 }
 
+int inr_adam_step_shard(const inr_plan* plan, float* params, const float* grads_shard, float* exp_avg,
+                        float* exp_avg_sq, int64_t lo, int64_t hi, double lr, double beta1, double beta2, double eps,
+                        double weight_decay, double l1, double l2, int32_t step, void* stream) {
+  if (plan == nullptr || params == nullptr || grads_shard == nullptr || exp_avg == nullptr || exp_avg_sq == nullptr)
+    return fail(INR_ERR_INVALID, "inr_adam_step_shard: null argument");
+  if (step < 1) return fail(INR_ERR_INVALID, "inr_adam_step_shard: step %d (counts from 1)", step);
+  if (lo < 0 || hi < lo || hi > plan->nd.P)
+    return fail(INR_ERR_INVALID, "inr_adam_step_shard: entries [%lld, %lld) of %d", (long long)lo, (long long)hi,
+                plan->nd.P);
+  inr::AdamArgs aa;
+  aa.do_update = 1;
+  aa.sched = nullptr;
+  aa.step_dev = nullptr;
+  aa.n_sched = 0;
+  adam_bias_terms(lr, beta1, beta2, step, &aa.step_size, &aa.bc2_sqrt);
+  aa.omb1 = (float)(1.0 - beta1);
+  aa.beta2 = (float)beta2;
+  aa.omb2 = (float)(1.0 - beta2);
+  aa.eps = (float)eps;
+  aa.weight_decay = (float)weight_decay;
+  aa.l1 = (float)l1;
+  aa.l2 = (float)l2;
+  hipError_t e = inr::launch_adam_shard(plan->nd, params, grads_shard, exp_avg, exp_avg_sq, (int)lo, (int)hi, aa,
+                                        (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "inr_adam_step_shard");
+  return INR_OK;
+}
+
 int inr_train_adam_step(const inr_plan* plan, const inr_loss_desc* loss, float* params, float* packed, const float* x,
                         const float* enc_B, const float* gt, const uint8_t* mask, int64_t B, const inr_workspace* ws,
                         float* grads, float* loss_out, float* exp_avg, float* exp_avg_sq, double lr, double beta1,

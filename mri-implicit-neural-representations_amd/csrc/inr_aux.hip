@@ -1,6 +1,8 @@
 // inr_aux.hip -- HBM-bound helper kernels of the INR engine (gfx950): slab reduction,
 // Adam + weight re-packing, gauss encoder, pointwise losses.  All are coalesced streaming
 // kernels; none reshapes its work into a GEMM.
+#include <algorithm>
+#include <cstdlib>
 #include "inr_device.h"
 #include "inr_aux.h"
 #include "inr_w2.h"
@@ -306,10 +308,9 @@ __device__ __forceinline__ void put_w2(const NetDesc& nd, int l, float* packed, 
   }
 }
 
-// one flat entry: Adam update from gradient `g` (do_update), then its image entries
-__device__ __forceinline__ void adam_pack_entry(const NetDesc& nd, int i, float g, float* __restrict__ params,
-                                                float* __restrict__ m1, float* __restrict__ m2,
-                                                float* __restrict__ packed, const AdamArgs& aa) {
+// one flat entry: the Adam update from gradient `g` (do_update); returns the entry's (new) value
+__device__ __forceinline__ float adam_update_entry(const NetDesc& nd, int i, float g, float* __restrict__ params,
+                                                   float* __restrict__ m1, float* __restrict__ m2, const AdamArgs& aa) {
   float p = params[i];
   bool live = true;
   if (aa.has_dead) {
@@ -337,6 +338,14 @@ __device__ __forceinline__ void adam_pack_entry(const NetDesc& nd, int i, float 
     m2[i] = v;
     params[i] = p;
   }
+  return p;
+}
+
+// one flat entry: Adam update (adam_update_entry), then its image entries
+__device__ __forceinline__ void adam_pack_entry(const NetDesc& nd, int i, float g, float* __restrict__ params,
+                                                float* __restrict__ m1, float* __restrict__ m2,
+                                                float* __restrict__ packed, const AdamArgs& aa) {
+  const float p = adam_update_entry(nd, i, g, params, m1, m2, aa);
   if (aa.all_real) {  // SIREN / FFN: one weight entry or one bias entry, no sign, no pair
     for (int l = 0; l < nd.ND; ++l) {
       const LayerDesc& L = nd.L[l];
@@ -425,6 +434,63 @@ __global__ __launch_bounds__(256) void reduce_adam_real_kernel(const NetDesc nd,
     loss_words_sum(slabs_all, n_blocks_all, (size_t)slab_floats, nd.slab_loss_off, loss_out);
 }
 
+// Sharded data-parallel update: the entries [lo, hi) of the flat vector, gradient = this rank's chunk of the
+// reduce-scatter (grads_shard[i - lo]); no image is written -- every rank re-packs after the all-gather of the parameters.
+__global__ __launch_bounds__(256) void adam_shard_kernel(const NetDesc nd, float* __restrict__ params,
+                                                         const float* __restrict__ grads_shard, float* __restrict__ m1,
+                                                         float* __restrict__ m2, int lo, int hi, AdamArgs aa) {
+  const int i = lo + blockIdx.x * 256 + threadIdx.x;
+  if (i >= hi) return;
+  adam_update_entry(nd, i, grads_shard[i - lo], params, m1, m2, aa);
+}
+
+// The images of LT_REAL layers written in IMAGE order (one float4 slot per thread, blockIdx.y = layer): coalesced
+// stores, the weights gathered through the L2 -- where adam_pack_entry scatters 4-byte stores (16 segments per wave).
+// Slots: forward image Kpad8 * Mblk * 8 | transposed image Mpad8 * Kblk * 8 (if any) | bias image Mblk * 8; padding slots
+// are written as zeros (what they hold anyway).  The inverse of put_fwd / put_tr above.
+__global__ __launch_bounds__(256) void pack_images_real_kernel(const NetDesc nd, const float* __restrict__ params,
+                                                               float* __restrict__ packed) {
+  const LayerDesc& L = nd.L[blockIdx.y];
+  const int nf = L.Kpad8 * L.Mblk * 8, nt = L.pb_off >= 0 ? L.Mpad8 * L.Kblk * 8 : 0, nb = L.Mblk * 8;
+  int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= nf + nt + nb) return;
+  const float* __restrict__ W = params + L.w_off;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (q < nf) {
+    const int lane = q & 63, g = (q >> 6) / L.Mblk, mb = (q >> 6) - g * L.Mblk;
+    const int h = lane >> 5, row = mb * 32 + (lane & 31);
+    if (row < L.M) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int sidx = 4 * g + c;
+        const int k = L.korder == 1 ? (sidx < nd.E ? h * nd.E + sidx : L.K) : 2 * sidx + h;
+        if (k < L.K) v[c] = W[(size_t)row * L.K + k];
+      }
+    }
+    *reinterpret_cast<f32x4*>(packed + L.pf_off + (size_t)q * 4) = v;
+    return;
+  }
+  q -= nf;
+  if (q < nt) {
+    const int lane = q & 63, g = (q >> 6) / L.Kblk, kb = (q >> 6) - g * L.Kblk;
+    const int h = lane >> 5, k = kb * 32 + (lane & 31);
+    if (k < L.K) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int row = 2 * (4 * g + c) + h;
+        if (row < L.M) v[c] = W[(size_t)row * L.K + k];
+      }
+    }
+    *reinterpret_cast<f32x4*>(packed + L.pb_off + (size_t)q * 4) = v;
+    return;
+  }
+  q -= nt;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+    if (4 * q + c < L.bn) v[c] = params[L.b_off + 4 * q + c];
+  *reinterpret_cast<f32x4*>(packed + L.pbias_off + (size_t)q * 4) = v;
+}
+
 __global__ void step_advance_kernel(int* step_dev) { *step_dev += 1; }
 
 hipError_t launch_step_advance(int* step_dev, hipStream_t st) {
@@ -441,10 +507,41 @@ hipError_t launch_adam_pack(const NetDesc& nd, float* params, const float* grads
     aa.all_real = aa.all_real && (nd.L[l].ltype == LT_REAL || nd.L[l].ltype == LT_GABOR_MU);
     aa.has_dead = aa.has_dead || nd.L[l].live == 0;
   }
+  // large plain-layer networks (BASELINE config 4: 4.47 M entries): the update elementwise, then the images in image order
+  // (INR_PACK_BY_IMAGE=0 / 1 forces the choice where both exist: the tests hold one against the other)
+  const char* force = getenv("INR_PACK_BY_IMAGE");
+  const bool big = force != nullptr ? force[0] == '1' : nd.P >= (1 << 18);
+  bool by_image = aa.all_real && !nd.bf16 && !nd.rs && !nd.gabor && big;
+  int slots = 0;
+  for (int l = 0; l < nd.ND && by_image; ++l) {
+    const LayerDesc& L = nd.L[l];
+    by_image = L.ltype == LT_REAL && L.pf_off >= 0 && (L.pf_off & 3) == 0 && (L.pb_off < 0 || (L.pb_off & 3) == 0) &&
+               (L.pbias_off & 3) == 0;
+    slots = std::max(slots, L.Kpad8 * L.Mblk * 8 + (L.pb_off >= 0 ? L.Mpad8 * L.Kblk * 8 : 0) + L.Mblk * 8);
+  }
+  if (by_image) {
+    if (aa.do_update)
+      hipLaunchKernelGGL(adam_shard_kernel, dim3((nd.P + 255) / 256), dim3(256), 0, st, nd, params, grads, m1, m2, 0, nd.P,
+                         aa);
+    hipLaunchKernelGGL(pack_images_real_kernel, dim3((slots + 255) / 256, nd.ND), dim3(256), 0, st, nd, params, packed);
+    return hipGetLastError();
+  }
   const int grid = (nd.P + 255) / 256;
   hipLaunchKernelGGL(adam_pack_kernel, dim3(grid), dim3(256), 0, st, nd, params, grads, m1, m2, packed, aa);
   if (nd.gabor)
     hipLaunchKernelGGL(gabor_m2_kernel, dim3(nd.L[nd.mu0].M, nd.mfn_n + 1), dim3(64), 0, st, nd, params, packed);
+  return hipGetLastError();
+}
+
+hipError_t launch_adam_shard(const NetDesc& nd, float* params, const float* grads_shard, float* m1, float* m2, int lo,
+                             int hi, const AdamArgs& aa_in, hipStream_t st) {
+  if (hi <= lo) return hipSuccess;
+  AdamArgs aa = aa_in;
+  aa.all_real = 0;
+  aa.has_dead = 0;
+  for (int l = 0; l < nd.ND; ++l) aa.has_dead = aa.has_dead || nd.L[l].live == 0;
+  hipLaunchKernelGGL(adam_shard_kernel, dim3((hi - lo + 255) / 256), dim3(256), 0, st, nd, params, grads_shard, m1, m2, lo,
+                     hi, aa);
   return hipGetLastError();
 }
 

@@ -36,7 +36,7 @@ class LossDesc(C.Structure):
                 ("cons_inv", C.c_float * 4)]
 
 
-ABI_VERSION = 6  # INR_ABI_VERSION of include/inr_abi.h
+ABI_VERSION = 7  # INR_ABI_VERSION of include/inr_abi.h
 
 
 class Workspace(C.Structure):
@@ -89,6 +89,8 @@ SYMBOLS = {
                                        C.POINTER(Workspace), _P, _P, _P]),
     "inr_adam_step": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_double, C.c_double, C.c_double, C.c_double,
                                 C.c_double, C.c_double, C.c_double, C.c_int32, _P]),
+    "inr_adam_step_shard": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_double,
+                                      C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, _P]),
     "inr_train_adam_step": (C.c_int, [_P, C.POINTER(LossDesc), _P, _P, _P, _P, _P, _P, C.c_int64, C.POINTER(Workspace),
                                       _P, _P, _P, _P, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
                                       C.c_double, C.c_double, C.c_int32, _P]),

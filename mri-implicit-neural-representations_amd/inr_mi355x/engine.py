@@ -56,6 +56,34 @@ def _ptr(t: Optional[torch.Tensor], name: str, dtype=torch.float32) -> Optional[
     return t.data_ptr()
 
 
+def sharded_exchange(gbuf_pad: torch.Tensor, gchunk: torch.Tensor, pchunk: torch.Tensor, pgather: torch.Tensor,
+                     params: torch.Tensor, rank: int, world: int, group, update) -> torch.Tensor:
+    """The collectives of a sharded data-parallel update (MLPEngine.adam_step_sharded).
+    ``gbuf_pad`` [world * chunk] = [gradient (P) | loss word | zero padding] of this rank, chunk = ceil((P + 1) / world).
+    reduce-scatter (SUM) -> ``update(lo, hi, gchunk)`` changes params[lo:hi] from gchunk[:hi - lo] (the rank's entries;
+    lo == hi for a rank whose chunk is all padding) -> all-gather of [updated entries | what the chunk holds behind them:
+    the summed loss on the rank that owns word P, padding] -> params <- gathered[:P].  Returns the summed loss.
+    gloo has no reduce-scatter on device tensors: there (CPU-side rehearsals of the GPU path) the same chunk is cut from
+    an all-reduce -- the same sums in the same order per element."""
+    import torch.distributed as dist
+    P, chunk = params.numel(), gchunk.numel()
+    assert gbuf_pad.numel() == pgather.numel() == chunk * world and pchunk.numel() == chunk and chunk * world > P
+    if gbuf_pad.is_cuda and dist.get_backend(group) == "gloo":
+        dist.all_reduce(gbuf_pad, op=dist.ReduceOp.SUM, group=group)
+        gchunk.copy_(gbuf_pad[rank * chunk:(rank + 1) * chunk])
+    else:
+        dist.reduce_scatter_tensor(gchunk, gbuf_pad, op=dist.ReduceOp.SUM, group=group)
+    lo = min(rank * chunk, P)
+    hi = min(lo + chunk, P)
+    update(lo, hi, gchunk)
+    pchunk.copy_(gchunk)
+    if hi > lo:
+        pchunk[:hi - lo].copy_(params[lo:hi])
+    dist.all_gather_into_tensor(pgather, pchunk, group=group)
+    params.copy_(pgather[:P])
+    return pgather[P].clone()
+
+
 class MLPEngine:
     """One plan + its device buffers.  Mirrors what nn.Module + torch.optim.Adam hold for SIREN / FFN
     in the reference (models/networks.py:48-124; train.py:75-78)."""
@@ -122,6 +150,8 @@ class MLPEngine:
             # a training step (which may be under graph capture)
             with torch.cuda.device(dev):
                 self.grad_scale_state()
+        if getattr(self, "_shard", None) is not None:  # re-bound (checkpoint load): keep the sharded-update buffers
+            self.enable_sharded_update(self._shard[0], self._shard[1])
         self.pack()
 
     def launch_dims(self, B: int):
@@ -322,6 +352,51 @@ class MLPEngine:
                                        _ptr(self.exp_avg, "exp_avg"), _ptr(self.exp_avg_sq, "exp_avg_sq"),
                                        _ptr(self.packed, "packed"), lr, beta1, beta2, eps, weight_decay, l1, l2,
                                        self.step, self._stream()))
+
+    # ---- data-parallel update with the parameters sharded over the ranks ------------------------
+    def enable_sharded_update(self, rank: int, world: int) -> None:
+        """Buffers of adam_step_sharded: the gradient buffer padded to `world` equal chunks (the loss word still sits
+        behind the gradient and travels with it), the rank's chunk of the reduce-scatter, the chunk it contributes to the
+        all-gather and the gathered vector.  Call once, before the first step (the gradient buffer is re-allocated)."""
+        P = self.n_params
+        chunk = -(-(P + 1) // world)
+        dev = self.params.device
+        self._gbuf_pad = torch.zeros(chunk * world, device=dev)
+        self.gbuf = self._gbuf_pad[:P + 1]
+        self.grads = self.gbuf[:P]
+        self._loss_word = self.gbuf[P:]
+        self._gchunk = torch.zeros(chunk, device=dev)
+        self._pchunk = torch.zeros(chunk, device=dev)
+        self._pgather = torch.zeros(chunk * world, device=dev)
+        self._shard = (rank, world, chunk)
+
+    def shard_bounds(self):
+        """[lo, hi) of the flat parameter entries this rank updates (empty for a rank whose chunk is all padding)."""
+        rank, world, chunk = self._shard
+        lo = min(rank * chunk, self.n_params)
+        return lo, min(lo + chunk, self.n_params)
+
+    def adam_step_sharded(self, group, lr: float, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,
+                          weight_decay: float = 0.0, l1: float = 0.0, l2: float = 0.0) -> torch.Tensor:
+        """The exchange + update of a data-parallel step with every rank owning 1/N of the parameters: reduce-scatter
+        of [gradient | loss] (SUM) -> torch.optim.Adam on the rank's entries (inr_adam_step_shard) -> all-gather of the
+        updated entries (the summed loss rides in the word behind the last parameter) -> every rank re-packs its weight
+        images.  The replicas' parameters come out of the same gathered buffer: bitwise equal on every rank; equal to
+        all-reduce + inr_adam_step up to the collective's summation order.  Returns the global loss; `self.grads` is
+        left holding this rank's PARTIAL gradient."""
+        self.step += 1
+
+        def update(lo: int, hi: int, gchunk: torch.Tensor) -> None:
+            L.check(self.lib.inr_adam_step_shard(self.plan, _ptr(self.params, "params"), _ptr(gchunk, "grads_shard"),
+                                                 _ptr(self.exp_avg, "exp_avg"), _ptr(self.exp_avg_sq, "exp_avg_sq"), lo,
+                                                 hi, lr, beta1, beta2, eps, weight_decay, l1, l2, self.step,
+                                                 self._stream()))
+
+        rank, world, _ = self._shard
+        loss = sharded_exchange(self._gbuf_pad, self._gchunk, self._pchunk, self._pgather, self.params, rank, world,
+                                group, update)
+        self.pack()
+        return loss
 
     # ---- the step as a HIP graph ----------------------------------------------------------------
     N_SCHED = 32768  # both fp32 bias-correction terms have converged long before (include/inr_abi.h)

@@ -91,6 +91,34 @@ def allreduce_step_outputs(grads: torch.Tensor, loss: torch.Tensor, world: int, 
     return loss
 
 
+SHARDED_UPDATE_MIN_PARAMS = 1 << 20  # below this the step's exchange is latency, not bytes: one all-reduce is cheaper
+
+
+def wants_sharded_update(config: dict, n_params: int, world: int) -> bool:
+    """config["dp_sharded_update"] (True / False; default: networks of >= 2^20 parameters, i.e. BASELINE config 4's
+    4.47 M, not the 0.33 M of SIREN 5x256) decides between the two exchange steps of exchange_and_update."""
+    if world <= 1:
+        return False
+    v = config.get("dp_sharded_update")
+    return n_params >= SHARDED_UPDATE_MIN_PARAMS if v is None else bool(v)
+
+
+def exchange_and_update(engine, loss: torch.Tensor, world: int, group, sharded: bool, lr: float, beta1: float,
+                        beta2: float, eps: float = 1e-8, weight_decay: float = 0.0, l1: float = 0.0,
+                        l2: float = 0.0) -> torch.Tensor:
+    """Exchange step + optimizer step of one data-parallel iteration (single process in the reference:
+    train.py:189-190, train_kspace_multiscale.py:199-200).  Replicated: ONE all-reduce of [gradient | loss], then every
+    rank runs the whole Adam update.  Sharded: reduce-scatter, Adam on 1/N of the entries, all-gather, re-pack
+    (MLPEngine.adam_step_sharded) -- the same bytes on the links, 1/N of the update per rank.  Returns the global loss."""
+    if sharded:
+        if loss.data_ptr() != engine._loss_word.data_ptr():
+            engine._loss_word.copy_(loss.reshape(1))
+        return engine.adam_step_sharded(group, lr, beta1, beta2, eps, weight_decay, l1, l2)
+    loss = allreduce_step_outputs(engine.grads, loss, world, group, engine.gbuf)
+    engine.adam_step(lr, beta1, beta2, eps, weight_decay, l1, l2)
+    return loss
+
+
 def center_pair_rows(kcoords: torch.Tensor, min_sample: int, n_bands: int = 2):
     """The row pairs of CenterLoss's N_BANDS radial bands (losses.py:176-194), as the reference draws them: band k
     compares dist^2 = ky^2 + kx^2 with the RATIOS (k-1)/N (0.1 for the first band) and k/N; n = min(min_sample, |inner|,
@@ -145,6 +173,9 @@ class INRTrainer:
         else:
             self.engine = self.model._engine()
             self.enc_B = None
+        self.sharded_update = wants_sharded_update(config, self.engine.n_params, world)
+        if self.sharded_update:
+            self.engine.enable_sharded_update(rank, world)
         self.loss = LossSpec.from_config(config)
         reg = config["regularization"]
         self.l1 = float(reg["strenght"]) if reg["type"] == "L1" else 0.0
@@ -267,18 +298,18 @@ class INRTrainer:
             else:
                 m = self.mask[slo:shi] if self.mask is not None else None
                 loss = self._fused(slo, shi, count, m, A)
-        loss = allreduce_step_outputs(self.engine.grads, loss, self.world, self.pg, self.engine.gbuf)
-        # the loss the reference logs includes the penalty VALUE (train.py:185-192); its gradient is formed inside
-        # the Adam kernel.  Every rank holds the same parameters: added once, after the all-reduce.
+        # the loss the reference logs includes the penalty VALUE at the parameters the step starts from
+        # (train.py:185-192); its gradient is formed inside the Adam kernel.  Every rank holds the same parameters.
+        penalty = None
         if self.l1:
-            loss = loss + self.l1 * self.engine.params.abs().sum()
+            penalty = self.l1 * self.engine.params.abs().sum()
         if self.l2:
-            loss = loss + self.l2 * (self.engine.params * self.engine.params).sum()
+            penalty = self.l2 * (self.engine.params * self.engine.params).sum()
         lr = self.config["lr"] * lr_factor(epoch, self.config["max_epoch"])
-        self.engine.adam_step(lr, self.config["beta1"], self.config["beta2"], 1e-8, self.config["weight_decay"],
-                              self.l1, self.l2)
+        loss = exchange_and_update(self.engine, loss, self.world, self.pg, self.sharded_update, lr, self.config["beta1"],
+                                   self.config["beta2"], 1e-8, self.config["weight_decay"], self.l1, self.l2)
         self.global_step += 1
-        return loss
+        return loss if penalty is None else loss + penalty
 
     def _graph_step(self, epoch: int, it: int, lo: int, hi: int, count: int, A: float) -> torch.Tensor:
         cfg = self.config

@@ -19,7 +19,7 @@ from .engine import ConsistencySpec, LossSpec
 from .evalchain import psnr, reconstruct
 from .mfn import MultiscaleBoundedFourier, MultiscaleKFourier
 from .networks import Positional_Encoder
-from .train import allreduce_step_outputs, lr_factor, set_default_configs, shard_rows
+from .train import exchange_and_update, lr_factor, set_default_configs, shard_rows, wants_sharded_update
 
 
 def create_pairs(values: Sequence[float], multiplication_factor: int):
@@ -68,6 +68,9 @@ class MultiscaleTrainer:
         else:  # 'LogF' / 'none': the filters read encoder.embedding(coords) from memory (train_kspace_multiscale.py:169)
             self.engine = self.model._engine("x")
             self.enc_B = None
+        self.sharded_update = wants_sharded_update(config, self.engine.n_params, world)
+        if self.sharded_update:
+            self.engine.enable_sharded_update(rank, world)
         self.pairs = create_pairs(list(radii), 1)
         # undersampling / per-coil batches / TV as in the single-scale loop (models/utils.py:102-123;
         # train_kspace_multiscale.py:173-182)
@@ -152,9 +155,9 @@ class MultiscaleTrainer:
                                               count=count, mask=None if self.mask is None else self.mask[slo:shi],
                                               dist=self.dist[slo:shi], scale=self.scale,
                                               cons=self._cons_spec(it, lo, hi))
-        loss = allreduce_step_outputs(self.engine.grads, loss, self.world, self.pg, self.engine.gbuf)
         lr = self.config["lr"] * lr_factor(epoch, self.config["max_epoch"])
-        self.engine.adam_step(lr, self.config["beta1"], self.config["beta2"], 1e-8, self.config["weight_decay"])
+        loss = exchange_and_update(self.engine, loss, self.world, self.pg, self.sharded_update, lr, self.config["beta1"],
+                                   self.config["beta2"], 1e-8, self.config["weight_decay"])
         self.global_step += 1
         return loss
 

@@ -38,6 +38,13 @@ def _cases():
         "multiscale_tv": dict(BASE, model="MultiscaleKFourier", loss="LSL", loss_opts=dict(eps=3e-3), batch_size=1,
                               per_coil=True, use_tv=True, undersampling="grid-2*2",
                               partition=dict(no_steps=20, no_models=4), net=dict(NET, network_depth=8)),
+        # the sharded update (reduce-scatter -> Adam on 1/N of the entries -> all-gather -> re-pack) forced on small
+        # networks; with an L2 penalty, whose value is logged at the parameters the step starts from
+        "siren_sharded": dict(BASE, model="SIREN", batch_size=333, dp_sharded_update=True,
+                              regularization=dict(type="L2", strenght=1e-4)),
+        "multiscale_sharded": dict(BASE, model="MultiscaleKFourier", loss="LSL", loss_opts=dict(eps=3e-3), batch_size=400,
+                                   partition=dict(no_steps=20, no_models=4), net=dict(NET, network_depth=8),
+                                   dp_sharded_update=True),
         "ensemble": dict(BASE, model="SIREN", batch_size=SHAPE[1] * SHAPE[2], partition=dict(no_steps=20, no_models=3)),
     }
 
@@ -50,7 +57,7 @@ def _run(case, rank, world, pg=None):
     cfg = _cases()[case]
     image, coords, shape = make_kspace(*SHAPE)
     dev = torch.device("cuda:0")
-    if case in ("multiscale", "multiscale_tv"):
+    if case.startswith("multiscale"):
         dist = torch.sqrt(coords[:, 1] ** 2 + coords[:, 2] ** 2)
         tr = MultiscaleTrainer(cfg, image, coords, dist, None, shape, dev, seed=1, rank=rank, world=world, process_group=pg)
     elif case == "ensemble":
@@ -59,6 +66,7 @@ def _run(case, rank, world, pg=None):
         return [], tr.predict_all().cpu()
     else:
         tr = INRTrainer(cfg, image, coords, shape, dev, seed=1, rank=rank, world=world, process_group=pg)
+    assert tr.sharded_update == (world > 1 and case.endswith("_sharded"))
     if case.endswith("_bf16"):
         # bf16 cases also hand back the initial weights and the (all-reduced) gradient of the first step: what a wrong
         # shard, halo row or collective would change at O(1), where five Adam steps of lr each cannot tell
@@ -84,8 +92,10 @@ def _worker(rank, world, port, case, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case", ["siren", "tv", "fourier", "multiscale", "multiscale_tv", "ensemble", "siren_bf16", "tv_bf16"])
-def test_two_ranks_equal_one(case):
+@pytest.mark.parametrize("case,world", [("siren", 2), ("tv", 2), ("fourier", 2), ("multiscale", 2), ("multiscale_tv", 2),
+                                        ("ensemble", 2), ("siren_bf16", 2), ("tv_bf16", 2), ("siren_sharded", 2),
+                                        ("siren_sharded", 3), ("multiscale_sharded", 2), ("multiscale_sharded", 3)])
+def test_ranks_equal_one(case, world):
     assert torch.cuda.is_available()
     ref = _run(case, 0, 1)
     ref_losses, ref_params = ref[0], ref[1]
@@ -95,17 +105,17 @@ def test_two_ranks_equal_one(case):
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, case, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case, q)) for r in range(world)]
     for p in procs:
         p.start()
     got = {}
-    for _ in range(2):
+    for _ in range(world):
         rank, losses, params = q.get(timeout=300)
         got[rank] = (losses, params)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank in (0, 1):
+    for rank in range(world):
         losses, params = got[rank]
         if case.endswith("_bf16"):
             # losses to 1 % (bf16 forward; the runs drift apart by the rounding of five steps), weights to five Adam steps of
@@ -135,5 +145,6 @@ def test_two_ranks_equal_one(case):
             np.testing.assert_allclose(params, ref_params.numpy(), rtol=1e-5, atol=1e-6)
         else:  # replicated weights after 5 steps
             np.testing.assert_allclose(params, ref_params.numpy(), rtol=2e-4, atol=2e-6, err_msg=f"{case} rank {rank}")
-    if case != "ensemble":  # replicas stay bitwise identical: same reduced gradient, same Adam
-        np.testing.assert_array_equal(got[0][1], got[1][1])
+    if case != "ensemble":  # replicas stay bitwise identical: same reduced gradient, same Adam (or the same gathered buffer)
+        for rank in range(1, world):
+            np.testing.assert_array_equal(got[0][1], got[rank][1])

@@ -23,7 +23,7 @@ def test_abi_header_symbols_exported():
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.inr_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.inr_abi_version() == _lib.ABI_VERSION == 7
 
 
 def test_adam_schedule_table():
