@@ -315,6 +315,20 @@ int inr_adam_step(const inr_plan* plan, float* params, const float* grads, float
                   float* exp_avg_sq, float* packed, double lr, double beta1, double beta2, double eps,
                   double weight_decay, double l1, double l2, int32_t step, void* stream);
 
+/* Replaces the backward of `train_loss += regularization(model.parameters())` (train.py:185-187;
+ * models/regularization.py:21-36) for ANY plan, complex64 tensors included (WIRE / WIRE2D: interleaved (re, im) pairs in
+ * the flat vector): adds to grads[i - lo], lo <= i < hi, the gradient of
+ *   l1 * sum |p|         -- real entries sign(p); a complex entry z contributes |z|: (re, im) / |z|, 0 at z = 0
+ *   l2 * |S|, S = sum p^2 over every Parameter -- complex when the model has complex tensors (z^2 = a^2 - b^2 + 2iab):
+ *                           with u = conj(S) / |S|: real entry 2 p Re(u); d/d re = 2 Re(u z), d/d im = -2 Im(u z).
+ * `l2_dir` = device pointer to (Re u, Im u); NULL means (1, 0) and is required to be non-NULL only for l2 != 0 on a plan
+ * with complex tensors.  The caller forms S -- it also holds the squares of the frozen omega_0 / scale_0 Parameters
+ * (networks.py:191-192), which the flat vector does not carry -- and the penalty VALUE it logs.  The Adam entry points
+ * form the real-entry terms themselves (l1, l2 arguments) and refuse l1 / l2 != 0 on plans with complex tensors: there,
+ * call this first and pass them 0.  [lo, hi) = [0, P) for a whole gradient, or a rank's chunk before inr_adam_step_shard. */
+int inr_reg_grad(const inr_plan* plan, const float* params, float* grads, int64_t lo, int64_t hi, double l1,
+                 double l2, const float* l2_dir, void* stream);
+
 /* The update of a data-parallel job whose ranks each own 1/N of the flat parameter vector (no reference counterpart:
  * train_kspace_multiscale.py:161-201 is single-process; this is torch.optim.Adam on a slice): the same arithmetic as
  * inr_adam_step on the entries [lo, hi) only.  `grads_shard[i - lo]` is the summed gradient of entry i -- the rank's

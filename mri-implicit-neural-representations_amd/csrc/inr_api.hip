@@ -1431,6 +1431,20 @@ int inr_train_step_multi(const inr_plan* plan, const inr_loss_desc* loss, const 
                         "inr_train_step_multi");
 }
 
+static bool has_complex_tensors(const NetDesc& nd) {
+  for (int l = 0; l < nd.ND; ++l)
+    if (nd.L[l].ltype == LT_WIRE_HIDDEN || nd.L[l].ltype == LT_WIRE_LAST) return true;
+  return false;
+}
+
+// the Adam kernels form the penalty gradients per REAL entry: right for every tensor of a real model, wrong for complex64
+static int check_real_penalty(const inr_plan* plan, double l1, double l2, const char* who) {
+  if ((l1 != 0.0 || l2 != 0.0) && has_complex_tensors(plan->nd))
+    return fail(INR_ERR_INVALID, "%s: l1 / l2 on a plan with complex64 tensors -- add the penalty gradient with "
+                "inr_reg_grad and pass l1 = l2 = 0", who);
+  return INR_OK;
+}
+
 // torch computes these in Python doubles and passes them to fp32 kernels as scalars
 static void adam_bias_terms(double lr, double beta1, double beta2, int32_t step, float* step_size, float* bc2_sqrt) {
   const double bc1 = 1.0 - std::pow(beta1, (double)step);
@@ -1452,6 +1466,7 @@ int inr_adam_step_dev(const inr_plan* plan, float* params, const float* grads, f
       packed == nullptr || sched == nullptr || step_dev == nullptr)
     return fail(INR_ERR_INVALID, "inr_adam_step_dev: null argument");
   if (n_sched < 1) return fail(INR_ERR_INVALID, "inr_adam_step_dev: empty schedule");
+  if (int rc = check_real_penalty(plan, l1, l2, "inr_adam_step_dev")) return rc;
   inr::AdamArgs aa;
   aa.do_update = 1;
   aa.step_size = 0.f;
@@ -1479,6 +1494,7 @@ int inr_adam_step(const inr_plan* plan, float* params, const float* grads, float
       packed == nullptr)
     return fail(INR_ERR_INVALID, "inr_adam_step: null argument");
   if (step < 1) return fail(INR_ERR_INVALID, "inr_adam_step: step %d (counts from 1)", step);
+  if (int rc = check_real_penalty(plan, l1, l2, "inr_adam_step")) return rc;
   inr::AdamArgs aa;
   aa.do_update = 1;
   aa.sched = nullptr;
@@ -1497,12 +1513,26 @@ int inr_adam_step(const inr_plan* plan, float* params, const float* grads, float
   return INR_OK;
 }
 
+int inr_reg_grad(const inr_plan* plan, const float* params, float* grads, int64_t lo, int64_t hi, double l1, double l2,
+                 const float* l2_dir, void* stream) {
+  if (plan == nullptr || params == nullptr || grads == nullptr) return fail(INR_ERR_INVALID, "inr_reg_grad: null argument");
+  if (lo < 0 || hi < lo || hi > plan->nd.P)
+    return fail(INR_ERR_INVALID, "inr_reg_grad: entries [%lld, %lld) of %d", (long long)lo, (long long)hi, plan->nd.P);
+  if (l2 != 0.0 && l2_dir == nullptr && has_complex_tensors(plan->nd))
+    return fail(INR_ERR_INVALID, "inr_reg_grad: l2 on a plan with complex64 tensors needs l2_dir (conj(S) / |S|)");
+  hipError_t e = inr::launch_reg_grad(plan->nd, params, grads, (int)lo, (int)hi, (float)l1, (float)l2, l2_dir,
+                                      (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "inr_reg_grad");
+  return INR_OK;
+}
+
 int inr_adam_step_shard(const inr_plan* plan, float* params, const float* grads_shard, float* exp_avg,
                         float* exp_avg_sq, int64_t lo, int64_t hi, double lr, double beta1, double beta2, double eps,
                         double weight_decay, double l1, double l2, int32_t step, void* stream) {
   if (plan == nullptr || params == nullptr || grads_shard == nullptr || exp_avg == nullptr || exp_avg_sq == nullptr)
     return fail(INR_ERR_INVALID, "inr_adam_step_shard: null argument");
   if (step < 1) return fail(INR_ERR_INVALID, "inr_adam_step_shard: step %d (counts from 1)", step);
+  if (int rc = check_real_penalty(plan, l1, l2, "inr_adam_step_shard")) return rc;
   if (lo < 0 || hi < lo || hi > plan->nd.P)
     return fail(INR_ERR_INVALID, "inr_adam_step_shard: entries [%lld, %lld) of %d", (long long)lo, (long long)hi,
                 plan->nd.P);
@@ -1533,6 +1563,8 @@ int inr_train_adam_step(const inr_plan* plan, const inr_loss_desc* loss, float* 
   if (grads == nullptr || exp_avg == nullptr || exp_avg_sq == nullptr)
     return fail(INR_ERR_INVALID, "inr_train_adam_step: null argument");
   if (step < 1) return fail(INR_ERR_INVALID, "inr_train_adam_step: step %d (counts from 1)", step);
+  if (plan != nullptr)
+    if (int rc = check_real_penalty(plan, l1, l2, "inr_train_adam_step")) return rc;
   AdamFuse af;
   af.params = params, af.m1 = exp_avg, af.m2 = exp_avg_sq, af.packed = packed;
   memset(&af.aa, 0, sizeof(af.aa));

@@ -39,6 +39,8 @@ hipError_t launch_step_advance(int* step_dev, hipStream_t st);
 hipError_t launch_reduce_slabs_adam(const NetDesc& nd, const float* slabs, int n_blocks, float* grads, float* loss_out,
                                     float* params, float* m1, float* m2, float* packed, const AdamArgs& aa,
                                     hipStream_t st, SlabSplit split);
+hipError_t launch_reg_grad(const NetDesc& nd, const float* params, float* grads, int lo, int hi, float l1, float l2,
+                           const float* l2_dir, hipStream_t st);
 hipError_t launch_adam_shard(const NetDesc& nd, float* params, const float* grads_shard, float* m1, float* m2, int lo,
                              int hi, const AdamArgs& aa, hipStream_t st);
 hipError_t launch_adam_pack(const NetDesc& nd, float* params, const float* grads, float* m1, float* m2,

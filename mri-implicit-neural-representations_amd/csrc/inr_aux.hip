@@ -491,6 +491,49 @@ __global__ __launch_bounds__(256) void pack_images_real_kernel(const NetDesc nd,
   *reinterpret_cast<f32x4*>(packed + L.pbias_off + (size_t)q * 4) = v;
 }
 
+// Gradient of the penalties of models/regularization.py:21-36 added to the flat gradient entries [lo, hi) (grads[i - lo]),
+// for plans with complex64 tensors too (WIRE / WIRE2D hidden and last layers, stored as interleaved (re, im) pairs):
+//   L1  lambda * sum |p|:  real entries sign(p); a complex z = a + ib contributes |z|, i.e. (a, b) / |z| (0 at z = 0)
+//   L2  lambda * |S|, S = sum p^2 over every Parameter -- a COMPLEX sum when the model has complex tensors (z^2 = a^2 - b^2
+//       + 2iab):  with u = conj(S) / |S| = (ur, ui):  real entry 2 p ur;  d/da = 2 (ur a - ui b),  d/db = -2 (ur b + ui a).
+// u is read from device memory (the caller forms S, which also holds the squares of the frozen omega_0 / scale_0
+// Parameters, networks.py:191-192); l2_dir == nullptr means u = (1, 0): all-real models.  Reads params, writes grads only:
+// a pair's two entries never race.
+__global__ __launch_bounds__(256) void reg_grad_kernel(const NetDesc nd, const float* __restrict__ params,
+                                                       float* __restrict__ grads, int lo, int hi, float l1, float l2,
+                                                       const float* __restrict__ l2_dir) {
+  const int i = lo + blockIdx.x * 256 + threadIdx.x;
+  if (i >= hi) return;
+  int role = 0;  // 0: real entry, 1 / 2: real / imaginary part of a complex entry
+  for (int l = 0; l < nd.ND; ++l) {
+    const LayerDesc& L = nd.L[l];
+    if (L.ltype != LT_WIRE_HIDDEN && L.ltype != LT_WIRE_LAST) continue;
+    const int off = i - L.w_off, ob = i - L.b_off;
+    if (off >= 0 && off < L.wn) role = 1 + (off & 1);
+    if (ob >= 0 && ob < L.bn) role = 1 + (ob & 1);
+  }
+  float ur = 1.f, ui = 0.f;
+  if (l2_dir != nullptr) {
+    ur = l2_dir[0];
+    ui = l2_dir[1];
+  }
+  const float p = params[i];
+  float add = 0.f;
+  if (role == 0) {
+    if (l1 != 0.f) add += l1 * (p > 0.f ? 1.f : (p < 0.f ? -1.f : 0.f));
+    if (l2 != 0.f) add += 2.f * l2 * p * ur;
+  } else {
+    const float q = params[role == 1 ? i + 1 : i - 1];
+    const float a = role == 1 ? p : q, b = role == 1 ? q : p;
+    if (l1 != 0.f) {
+      const float r = hypotf(a, b);
+      if (r > 0.f) add += l1 * (p / r);
+    }
+    if (l2 != 0.f) add += role == 1 ? 2.f * l2 * (ur * a - ui * b) : -2.f * l2 * (ur * b + ui * a);
+  }
+  grads[i - lo] += add;
+}
+
 __global__ void step_advance_kernel(int* step_dev) { *step_dev += 1; }
 
 hipError_t launch_step_advance(int* step_dev, hipStream_t st) {
@@ -530,6 +573,14 @@ hipError_t launch_adam_pack(const NetDesc& nd, float* params, const float* grads
   hipLaunchKernelGGL(adam_pack_kernel, dim3(grid), dim3(256), 0, st, nd, params, grads, m1, m2, packed, aa);
   if (nd.gabor)
     hipLaunchKernelGGL(gabor_m2_kernel, dim3(nd.L[nd.mu0].M, nd.mfn_n + 1), dim3(64), 0, st, nd, params, packed);
+  return hipGetLastError();
+}
+
+hipError_t launch_reg_grad(const NetDesc& nd, const float* params, float* grads, int lo, int hi, float l1, float l2,
+                           const float* l2_dir, hipStream_t st) {
+  if (hi <= lo || (l1 == 0.f && l2 == 0.f)) return hipSuccess;
+  hipLaunchKernelGGL(reg_grad_kernel, dim3((hi - lo + 255) / 256), dim3(256), 0, st, nd, params, grads, lo, hi, l1, l2,
+                     l2_dir);
   return hipGetLastError();
 }
 

@@ -89,6 +89,7 @@ SYMBOLS = {
                                        C.POINTER(Workspace), _P, _P, _P]),
     "inr_adam_step": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_double, C.c_double, C.c_double, C.c_double,
                                 C.c_double, C.c_double, C.c_double, C.c_int32, _P]),
+    "inr_reg_grad": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, C.c_double, C.c_double, _P, _P]),
     "inr_adam_step_shard": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_double,
                                       C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, _P]),
     "inr_train_adam_step": (C.c_int, [_P, C.POINTER(LossDesc), _P, _P, _P, _P, _P, _P, C.c_int64, C.POINTER(Workspace),

@@ -353,6 +353,16 @@ class MLPEngine:
                                        _ptr(self.packed, "packed"), lr, beta1, beta2, eps, weight_decay, l1, l2,
                                        self.step, self._stream()))
 
+    def reg_grad(self, l1: float, l2: float, l2_dir: Optional[torch.Tensor] = None, grads: Optional[torch.Tensor] = None,
+                 lo: int = 0, hi: Optional[int] = None) -> None:
+        """Adds the gradient of Regularization_L1 / _L2 (models/regularization.py:21-36) to ``grads`` (default: the
+        engine's gradient; entries [lo, hi), grads[i - lo]) -- the form that is right for complex64 tensors too
+        (inr_reg_grad).  ``l2_dir`` = device tensor (Re, Im) of conj(S) / |S|, S = sum of squares of every Parameter."""
+        g = self.grads if grads is None else grads
+        hi = self.n_params if hi is None else hi
+        L.check(self.lib.inr_reg_grad(self.plan, _ptr(self.params, "params"), _ptr(g, "grads"), lo, hi, l1, l2,
+                                      None if l2_dir is None else _ptr(l2_dir, "l2_dir"), self._stream()))
+
     # ---- data-parallel update with the parameters sharded over the ranks ------------------------
     def enable_sharded_update(self, rank: int, world: int) -> None:
         """Buffers of adam_step_sharded: the gradient buffer padded to `world` equal chunks (the loss word still sits
@@ -377,7 +387,8 @@ class MLPEngine:
         return lo, min(lo + chunk, self.n_params)
 
     def adam_step_sharded(self, group, lr: float, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,
-                          weight_decay: float = 0.0, l1: float = 0.0, l2: float = 0.0) -> torch.Tensor:
+                          weight_decay: float = 0.0, l1: float = 0.0, l2: float = 0.0,
+                          reg: Optional[tuple] = None) -> torch.Tensor:
         """The exchange + update of a data-parallel step with every rank owning 1/N of the parameters: reduce-scatter
         of [gradient | loss] (SUM) -> torch.optim.Adam on the rank's entries (inr_adam_step_shard) -> all-gather of the
         updated entries (the summed loss rides in the word behind the last parameter) -> every rank re-packs its weight
@@ -387,6 +398,8 @@ class MLPEngine:
         self.step += 1
 
         def update(lo: int, hi: int, gchunk: torch.Tensor) -> None:
+            if reg is not None and hi > lo:  # (l1, l2, l2_dir): penalties of a model with complex tensors, see reg_grad
+                self.reg_grad(reg[0], reg[1], reg[2], grads=gchunk, lo=lo, hi=hi)
             L.check(self.lib.inr_adam_step_shard(self.plan, _ptr(self.params, "params"), _ptr(gchunk, "grads_shard"),
                                                  _ptr(self.exp_avg, "exp_avg"), _ptr(self.exp_avg_sq, "exp_avg_sq"), lo,
                                                  hi, lr, beta1, beta2, eps, weight_decay, l1, l2, self.step,

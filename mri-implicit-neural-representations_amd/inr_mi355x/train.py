@@ -105,17 +105,24 @@ def wants_sharded_update(config: dict, n_params: int, world: int) -> bool:
 
 def exchange_and_update(engine, loss: torch.Tensor, world: int, group, sharded: bool, lr: float, beta1: float,
                         beta2: float, eps: float = 1e-8, weight_decay: float = 0.0, l1: float = 0.0,
-                        l2: float = 0.0) -> torch.Tensor:
+                        l2: float = 0.0, cplx_reg: Optional[tuple] = None) -> torch.Tensor:
     """Exchange step + optimizer step of one data-parallel iteration (single process in the reference:
     train.py:189-190, train_kspace_multiscale.py:199-200).  Replicated: ONE all-reduce of [gradient | loss], then every
     rank runs the whole Adam update.  Sharded: reduce-scatter, Adam on 1/N of the entries, all-gather, re-pack
-    (MLPEngine.adam_step_sharded) -- the same bytes on the links, 1/N of the update per rank.  Returns the global loss."""
+    (MLPEngine.adam_step_sharded) -- the same bytes on the links, 1/N of the update per rank.  ``cplx_reg`` = (l1, l2, l2_dir) replaces l1 / l2
+    for models with complex64 tensors (INRTrainer._penalty).  Returns the global loss."""
     if sharded:
         if loss.data_ptr() != engine._loss_word.data_ptr():
             engine._loss_word.copy_(loss.reshape(1))
+        if cplx_reg is not None:
+            return engine.adam_step_sharded(group, lr, beta1, beta2, eps, weight_decay, reg=cplx_reg)
         return engine.adam_step_sharded(group, lr, beta1, beta2, eps, weight_decay, l1, l2)
     loss = allreduce_step_outputs(engine.grads, loss, world, group, engine.gbuf)
-    engine.adam_step(lr, beta1, beta2, eps, weight_decay, l1, l2)
+    if cplx_reg is not None:  # (l1, l2, l2_dir) of a model with complex tensors: the penalty gradient by inr_reg_grad, once,
+        engine.reg_grad(*cplx_reg)  # on the summed gradient (every rank holds the same parameters)
+        engine.adam_step(lr, beta1, beta2, eps, weight_decay)
+    else:
+        engine.adam_step(lr, beta1, beta2, eps, weight_decay, l1, l2)
     return loss
 
 
@@ -182,10 +189,29 @@ class INRTrainer:
         self.l2 = float(reg["strenght"]) if reg["type"] == "L2" else 0.0
         if reg["type"] not in ("none", "L1", "L2"):
             raise NotImplementedError(f"regularization {reg['type']!r}")
-        if (self.l1 or self.l2) and config["model"] in ("WIRE", "WIRE2D"):
-            # regularization.py:21-36 on complex64 tensors means sum |z| (L1) and |sum z^2| (L2, a complex square):
-            # the Adam kernel's per-component sign / 2p terms are the REAL-parameter forms
-            raise NotImplementedError("L1 / L2 regularization with complex-weight models (WIRE, WIRE2D)")
+        # regularization.py:21-36 on complex64 tensors means sum |z| (L1) and |sum z^2| (L2, a complex square), and
+        # model.parameters() includes the frozen omega_0 / scale_0 (networks.py:191-192): the Adam kernel's per-entry sign /
+        # 2p terms are the real-parameter forms, so these models take the penalty gradient from inr_reg_grad (_penalty)
+        self._cplx_reg = bool(self.l1 or self.l2) and any(c for (_, _, _, c) in self.model._layout)
+        if self._cplx_reg:
+            P = self.engine.n_params
+            sign = torch.ones(P)
+            re_idx = []
+            for (o, n, _, c) in self.model._layout:
+                if c:
+                    sign[o + 1:o + n:2] = -1.0
+                    re_idx.append(torch.arange(o, o + n, 2))
+            self._sq_sign = sign.to(self.device)  # p^2 enters Re(S) with +1 (real entries, real parts) or -1 (imaginary parts)
+            self._re_idx = torch.cat(re_idx).to(self.device)
+            is_real = torch.ones(P, dtype=torch.bool)
+            for (o, n, _, c) in self.model._layout:
+                if c:
+                    is_real[o:o + n] = False
+            self._real_idx = torch.nonzero(is_real)[:, 0].to(self.device)
+            frozen = [p.detach().double().cpu() for p in self.model.parameters()
+                      if not any(p is q for q in self.model._flat_params)]
+            self._frozen_l1 = float(sum(f.abs().sum() for f in frozen))
+            self._frozen_l2 = float(sum((f * f).sum() for f in frozen))
         # undersampled fit (models/utils.py:102-123): train on the zero-filled k-space with the loss on
         # sampled rows only; validation still compares with the full k-space (val_loader, utils.py:131-137)
         self.image_full = image.to(self.device).contiguous()
@@ -217,8 +243,6 @@ class INRTrainer:
         self.use_tv = bool(config["use_tv"]) and self.mask is not None  # train.py:172-175: only inside the mask branch
         if self.use_tv and not self.per_coil:
             raise ValueError("use_tv needs per_coil batches: tv_loss views the batch as one [H,W,2] coil (train.py:175)")
-        if self.use_tv and self.is_mfn:
-            raise NotImplementedError("use_tv with the multiplicative filter networks")
         if self.loss.kind == L.LOSS_CENTER:
             if self.mask is not None:
                 # the reference indexes the MASKED predictions with radial masks of the UNMASKED coordinates
@@ -235,11 +259,11 @@ class INRTrainer:
         # Single rank only (the gradient all-reduce sits between the two halves) and only where a step is ONE
         # fused launch sequence on resident views.
         self.graph_steps = bool(graph_steps) and world == 1 and not self.use_tv and \
-            self.loss.kind != L.LOSS_CENTER and (self.enc_B is not None or emb == "none")
+            self.loss.kind != L.LOSS_CENTER and (self.enc_B is not None or emb == "none") and not self._cplx_reg
         self._graphs = {}
         # plain single-rank steps of the MLP engines go through inr_train_adam_step (INR_ONE_CALL_STEPS=0: two calls)
         self.one_call_steps = (os.environ.get("INR_ONE_CALL_STEPS", "1") != "0" and not self.is_mfn and not self.use_tv
-                               and self.loss.kind != L.LOSS_CENTER)
+                               and self.loss.kind != L.LOSS_CENTER and not self._cplx_reg)
         if "pretrain" in config:  # train.py:117-121
             self.load_checkpoint(torch.load(config["pretrain"], map_location=self.device))
 
@@ -265,6 +289,25 @@ class INRTrainer:
         """sampled rows of [lo, hi) (all of them without a mask)"""
         return hi - lo if self._mask_cum is None else int(self._mask_cum[hi] - self._mask_cum[lo])
 
+    def _penalty(self):
+        """(value, cplx_reg): the penalty VALUE the reference adds to the logged loss, at the parameters the step starts from
+        (train.py:185-192) -- None without a regulariser -- and, for models with complex64 tensors, the (l1, l2, l2_dir)
+        that exchange_and_update hands to inr_reg_grad: regularization.py:25-28 is sum |z| over complex entries,
+        :34-36 is |S| with S = sum p^2 a complex number (z^2 = a^2 - b^2 + 2iab), over EVERY Parameter, the frozen omega_0 /
+        scale_0 included; l2_dir = conj(S) / |S| stays on the device."""
+        if not (self.l1 or self.l2):
+            return None, None
+        p = self.engine.params
+        if not self._cplx_reg:
+            return (self.l1 * p.abs().sum() if self.l1 else self.l2 * (p * p).sum()), None
+        a, b = p[self._re_idx], p[self._re_idx + 1]
+        if self.l1:
+            return self.l1 * (p[self._real_idx].abs().sum() + torch.hypot(a, b).sum() + self._frozen_l1), (self.l1, 0.0, None)
+        s_re = (self._sq_sign * p * p).sum() + self._frozen_l2
+        s_im = 2.0 * (a * b).sum()
+        mod = torch.hypot(s_re, s_im)
+        return self.l2 * mod, (0.0, self.l2, (torch.stack((s_re, -s_im)) / mod).contiguous())
+
     def step(self, epoch: int, it: int) -> torch.Tensor:
         lo, hi = it * self.bs, min((it + 1) * self.bs, self.n)
         count = self._count(lo, hi)
@@ -274,11 +317,7 @@ class INRTrainer:
         if self.world == 1 and self.one_call_steps and hi > lo:
             # single rank: nothing sits between the reduction and the update -- one call, one launch less
             cfg = self.config
-            penalty = None  # value of the penalty at the parameters the step starts from, as below
-            if self.l1:
-                penalty = self.l1 * self.engine.params.abs().sum()
-            if self.l2:
-                penalty = self.l2 * (self.engine.params * self.engine.params).sum()
+            penalty, _ = self._penalty()  # value of the penalty at the parameters the step starts from, as below
             m = self.mask[lo:hi] if self.mask is not None else None
             loss = self.engine.train_adam_step(self._inputs(lo, hi), self.enc_B, self.image[lo:hi], self.loss,
                                                cfg["lr"] * lr_factor(epoch, cfg["max_epoch"]), count=count, mask=m,
@@ -300,14 +339,10 @@ class INRTrainer:
                 loss = self._fused(slo, shi, count, m, A)
         # the loss the reference logs includes the penalty VALUE at the parameters the step starts from
         # (train.py:185-192); its gradient is formed inside the Adam kernel.  Every rank holds the same parameters.
-        penalty = None
-        if self.l1:
-            penalty = self.l1 * self.engine.params.abs().sum()
-        if self.l2:
-            penalty = self.l2 * (self.engine.params * self.engine.params).sum()
+        penalty, cplx_reg = self._penalty()
         lr = self.config["lr"] * lr_factor(epoch, self.config["max_epoch"])
         loss = exchange_and_update(self.engine, loss, self.world, self.pg, self.sharded_update, lr, self.config["beta1"],
-                                   self.config["beta2"], 1e-8, self.config["weight_decay"], self.l1, self.l2)
+                                   self.config["beta2"], 1e-8, self.config["weight_decay"], self.l1, self.l2, cplx_reg)
         self.global_step += 1
         return loss if penalty is None else loss + penalty
 
@@ -320,11 +355,7 @@ class INRTrainer:
             g = self.engine.capture_step(lambda: self._fused(lo, hi, count, m, A), lr, cfg["beta1"], cfg["beta2"], 1e-8,
                                          cfg["weight_decay"], self.l1, self.l2)
             self._graphs[it] = g
-        penalty = None  # value of the penalty at the parameters the step starts from, as in step()
-        if self.l1:
-            penalty = self.l1 * self.engine.params.abs().sum()
-        if self.l2:
-            penalty = self.l2 * (self.engine.params * self.engine.params).sum()
+        penalty, _ = self._penalty()  # value of the penalty at the parameters the step starts from, as in step()
         loss = g.replay(lr)
         self.global_step += 1
         return loss if penalty is None else loss + penalty
@@ -377,10 +408,12 @@ class INRTrainer:
         ye = min(y1 + 1, H)
         slo, shi = lo + y0 * W, lo + ye * W
         out = self.engine.forward(self._inputs(slo, shi), self.enc_B, save=True)
+        if self.is_mfn:  # the filter networks' engine hands back [heads = 1, B, out] (train.py:165-169 calls model(coords))
+            out = out[0]
         # pointwise loss on the owned rows' sampled coordinates + TV on the grid, one pass (inr_loss_tv_grad)
         loss, dout = self.engine.loss_tv_grad(self.loss, out, self.image[slo:shi], count, y1 - y0, W, H,
                                               mask=self.mask[slo:shi], hdr_A=A)
-        self.engine.backward(self._inputs(slo, shi), self.enc_B, dout)
+        self.engine.backward(self._inputs(slo, shi), self.enc_B, dout.unsqueeze(0) if self.is_mfn else dout)
         return loss
 
     def fit(self, max_steps: Optional[int] = None, log_every: int = 0):

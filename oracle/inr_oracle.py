@@ -766,10 +766,13 @@ def train_single_scale(config: dict, sd, enc_B, coords: Tensor, image: Tensor, m
             loss = loss_fn(out, gt, kc)
             if tv is not None:
                 loss = tv + loss
+            # regularization(model.parameters()) (train.py:185-187) runs over EVERY Parameter, the frozen omega_0 / scale_0 of
+            # the WIRE layers included (networks.py:191-192, wire2d.py:35-36): they add a constant to the L1 value and sit
+            # inside the modulus of the L2 value
             if reg["type"] == "L1":
-                loss = loss + reg_l1(list(params.values()), reg["strenght"])
+                loss = loss + reg_l1(list(sd.values()), reg["strenght"])
             elif reg["type"] == "L2":
-                loss = loss + reg_l2(list(params.values()), reg["strenght"])
+                loss = loss + reg_l2(list(sd.values()), reg["strenght"])
             grads = torch.autograd.grad(loss, list(params.values()), allow_unused=True)
             with torch.no_grad():
                 adam_step({k: p for k, p in params.items()}, dict(zip(keys, grads)), state, lr,

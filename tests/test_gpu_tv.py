@@ -157,3 +157,22 @@ def test_loss_tv_grad_one_pass_matches_the_two_calls(dev, halo):
     torch.testing.assert_close(d_b, d_a, rtol=1e-6, atol=1e-9)
     l_c, d_c = eng.loss_tv_grad(spec, out, gt, count, R_own, W, H, mask=mask)
     assert float(l_c) == float(l_b) and torch.equal(d_c, d_b)
+
+
+@pytest.mark.parametrize("tag", ["Fourier_percoil_tv", "Gabor_percoil_tv"])
+def test_percoil_tv_filter_networks_golden(dev, tag):
+    """tv_loss is model-agnostic in the single-scale loop (train.py:172-175): the filter networks on per-coil batches with
+    a grid mask, reference-driven (tools/make_golden.py: extra_trajectories)."""
+    from inr_mi355x.train import INRTrainer
+    arrs = dict(np.load(os.path.join(GOLD, "trajectory_extra.npz")))
+    meta = json.load(open(os.path.join(GOLD, "trajectory_extra_meta.json")))
+    cfg = meta["cases"][tag]
+    C, H, W = meta["shape"]
+    coords = torch.from_numpy(arrs["coords"]).reshape(-1, 3)
+    full = torch.from_numpy(arrs["full"]).reshape(-1, 2)
+    tr = INRTrainer(cfg, full, coords, (C, H, W), dev, seed=meta["seed"])
+    assert tr.use_tv and tr.is_mfn and tr.bs == H * W
+    torch.testing.assert_close(tr.image.cpu(), torch.from_numpy(arrs["masked"]).reshape(-1, 2), rtol=0, atol=0)
+    got = np.array([s[1] for s in tr.fit(meta["steps"], log_every=1)])
+    np.testing.assert_allclose(got, arrs[tag + "/losses"], rtol=1e-4)
+    torch.testing.assert_close(tr.predict_all().cpu(), torch.from_numpy(arrs[tag + "/final_out"]), rtol=1e-3, atol=5e-5)

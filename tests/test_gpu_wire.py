@@ -181,3 +181,72 @@ def test_wire_trajectory_golden(dev):
     np.testing.assert_allclose(got[:3], ref[:3], rtol=5e-5)
     np.testing.assert_allclose(got[:8], ref[:8], rtol=2e-3)
     np.testing.assert_allclose(got, ref, rtol=3e-2)
+
+
+def test_reg_grad_complex_vs_autograd(dev):
+    """inr_reg_grad on a WIRE and a WIRE2D plan against torch.autograd of the oracle's Regularization_L1 / _L2
+    (regularization.py:21-36) over every Parameter, frozen omega_0 / scale_0 included: complex64 tensors contribute |z| and
+    sit inside the complex sum of squares; also on a sub-range (a rank's chunk of the sharded update), and the Adam entry
+    points refuse l1 / l2 on such plans."""
+    import inr_mi355x as M
+    for kind in ("WIRE", "WIRE2D"):
+        net = dict(network_input_size=3, network_output_size=2, network_depth=3, network_width=37 if kind == "WIRE" else 32,
+                   first_omega_0=20, hidden_omega_0=20, scale=10, last_tanh=kind == "WIRE2D")
+        torch.manual_seed(11)
+        model = (M.WIRE if kind == "WIRE" else M.WIRE2D)(net).to(dev)
+        eng = model._engine()
+        flat_ps = list(model._flat_params)
+        frozen = [p for p in model.parameters() if not any(p is q for q in flat_ps)]
+        assert len(frozen) == 2 * (net["network_depth"] + 1)  # omega_0, scale_0 of every Gabor layer
+        leaves = [p.detach().cpu().clone().requires_grad_(True) for p in flat_ps]
+        every = leaves + [f.detach().cpu() for f in frozen]
+        for l1, l2 in ((3e-3, 0.0), (0.0, 2e-3)):
+            val = O.reg_l1(every, l1) if l1 else O.reg_l2(every, l2)
+            ref = torch.autograd.grad(val, leaves)
+            ref = torch.cat([(torch.view_as_real(g) if g.is_complex() else g).reshape(-1) for g in ref])
+            l2_dir = None
+            if l2:
+                S = sum(torch.sum(p.detach().to(torch.complex128 if p.is_complex() else torch.float64).pow(2)) for p in every)
+                S = torch.as_tensor(S, dtype=torch.complex128)
+                u = torch.conj(S) / torch.abs(S)
+                l2_dir = torch.tensor([u.real, u.imag], dtype=torch.float32, device=dev)
+            base = torch.randn(eng.n_params, generator=torch.Generator().manual_seed(2)).to(dev) * 1e-3
+            eng.grads.copy_(base)
+            eng.reg_grad(l1, l2, l2_dir)
+            got = (eng.grads - base).cpu()
+            assert rel_l2(got, ref) < 2e-6, (kind, l1, l2, rel_l2(got, ref))
+            lo, hi = 101, eng.n_params - 57  # odd bounds: pairs cut at both ends
+            chunk = base[lo:hi].clone()
+            eng.reg_grad(l1, l2, l2_dir, grads=chunk, lo=lo, hi=hi)
+            assert torch.equal((chunk - base[lo:hi]).cpu(), got[lo:hi])
+            with pytest.raises(RuntimeError, match="inr_reg_grad"):
+                eng.adam_step(1e-3, l1=l1, l2=l2)
+        with pytest.raises(RuntimeError, match="l2_dir"):
+            eng.reg_grad(0.0, 1e-3, None)
+
+
+@pytest.mark.parametrize("tag", ["WIRE_regL1", "WIRE_regL2", "WIRE2D_regL2"])
+def test_complex_regularisation_trajectory_golden(dev, tag):
+    """train.py:185-192 with Regularization_L1 / _L2 on WIRE / WIRE2D, reference-driven (tools/make_golden.py:
+    extra_trajectories): logged losses (penalty value included), final prediction, final parameters."""
+    from inr_mi355x.train import INRTrainer
+    arrs = _load("trajectory_extra.npz")
+    meta = json.load(open(os.path.join(GOLD, "trajectory_extra_meta.json")))
+    cfg = meta["cases"][tag]
+    coords, image = _t(arrs["coords"]).reshape(-1, 3), _t(arrs["full"]).reshape(-1, 2)
+    tr = INRTrainer(cfg, image, coords, tuple(meta["shape"]), dev, seed=meta["seed"])
+    assert tr._cplx_reg and not tr.one_call_steps
+    got = [s[1] for s in tr.fit(meta["steps"], log_every=1)]
+    np.testing.assert_allclose(np.array(got), arrs[tag + "/losses"], rtol=2e-4, err_msg=tag)
+    # eight Adam steps through Gabor wavelets of omega_0 = 30: single entries move by up to a step of lr where a tiny
+    # gradient component rounds differently (|g| ~ eps of Adam), so the comparison is per tensor in relative L2 plus an
+    # absolute bound of one step (lr = 2e-4) per entry; a missing or real-form penalty gradient moves EVERY entry
+    from conftest import record_parity
+    e_out = rel_l2(tr.predict_all().cpu(), _t(arrs[tag + "/final_out"]))
+    record_parity("wire_reg_trajectory", tag=tag, e_out=e_out)
+    assert e_out < 5e-4, e_out
+    for k, v in tr.model.state_dict().items():
+        ref = _t(arrs[f"{tag}/final_sd/{k}"], complex_=v.is_complex())
+        a, b = (torch.view_as_real(v.cpu()), torch.view_as_real(ref)) if v.is_complex() else (v.cpu(), ref)
+        assert rel_l2(a, b) < 2e-4, (tag, k, rel_l2(a, b))
+        assert float((a - b).abs().max()) <= 2e-4, (tag, k)

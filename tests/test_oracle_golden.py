@@ -257,6 +257,30 @@ def test_percoil_tv_trajectory_golden(golden_dir):
     torch.testing.assert_close(out, _t(arrs["percoil_tv/final_out"]), rtol=1e-3, atol=2e-5)
 
 
+def test_extra_trajectories_golden(golden_dir):
+    """Regularization_L1 / _L2 on complex64 parameters (regularization.py:21-36 with WIRE / WIRE2D: sum |z| and
+    |sum z^2|, a complex square) and tv_loss with filter networks on per-coil batches (train.py:172-177), reference-driven
+    (tools/make_golden.py: extra_trajectories)."""
+    arrs = _load(golden_dir, "trajectory_extra.npz")
+    meta = json.load(open(os.path.join(golden_dir, "trajectory_extra_meta.json")))
+    C, H, W = meta["shape"]
+    coords = _t(arrs["coords"]).reshape(-1, 3)
+    mask = _t(arrs["mask"])[:, 0]
+    for tag, cfg in meta["cases"].items():
+        tv = cfg.get("use_tv", False)
+        image = _t(arrs["masked" if tv else "full"]).reshape(-1, 2)
+        torch.manual_seed(meta["seed"])
+        B = O.encoder_init(cfg["encoder"])
+        sd = O.init_model(cfg["model"], cfg["net"])
+        losses = O.train_single_scale(cfg, sd, B, coords, image, meta["steps"], mask=mask if tv else None, grid_hw=(H, W))
+        ref = arrs[tag + "/losses"]
+        assert len(losses) == len(ref)
+        np.testing.assert_allclose(np.array(losses), ref, rtol=5e-5, err_msg=tag)
+        with torch.no_grad():
+            out = O.model_forward(cfg["model"], sd, O.encode(coords, B, cfg["encoder"]["embedding"]), cfg["net"])
+        torch.testing.assert_close(out, _t(arrs[tag + "/final_out"]), rtol=1e-3, atol=2e-5, msg=lambda m: f"{tag}: {m}")
+
+
 def test_multiscale_trajectories_golden(golden_dir):
     arrs = _load(golden_dir, "trajectory_ms.npz")
     meta = json.load(open(os.path.join(golden_dir, "trajectory_ms_meta.json")))

@@ -563,6 +563,87 @@ def undersampling_vectors():
         os.chdir(cwd)
 
 
+def extra_trajectories():
+    """Trajectories of loop branches the first rounds refused: Regularization_L1 / _L2 (regularization.py:21-36) on the
+    complex64 parameters of WIRE / WIRE2D (train.py:185-187), and tv_loss (train.py:172-175) with filter networks on per-coil
+    batches.  Same re-stated loop as trajectory() / undersampling_vectors() around the imported reference classes."""
+    from torch.optim.lr_scheduler import LambdaLR
+    from undersampling.undersampler import Undersampler
+    C, H, W = 2, 24, 20
+    k = synth_kspace(C, H, W, 9)
+    Z, Y, X = torch.meshgrid(torch.linspace(-1, 1, C), torch.linspace(-1, 1, H), torch.linspace(-1, 1, W), indexing="ij")
+    coords_full = torch.hstack((Z.reshape(-1, 1), Y.reshape(-1, 1), X.reshape(-1, 1)))
+    cwd = os.getcwd()
+    os.chdir("/tmp")  # the reference saves undersampling_mask.png into the cwd
+    try:
+        masked, grid, grid_mask = quiet(Undersampler("grid").apply, k, [3, 2])
+    finally:
+        os.chdir(cwd)
+    base = dict(loss="L2", lr=2e-4, max_epoch=3, weight_decay=0.0, beta1=0.9, beta2=0.999)
+    none_enc = dict(embedding="none", scale=0, embedding_size=0, coordinates_size=3)
+    gauss_enc = dict(embedding="gauss", scale=2, embedding_size=8, coordinates_size=3)
+    cases = {
+        "WIRE_regL1": dict(base, model="WIRE", batch_size=240, regularization=dict(type="L1", strenght=1e-5),
+                           net=TINY["WIRE"], encoder=none_enc),
+        "WIRE_regL2": dict(base, model="WIRE", batch_size=240, regularization=dict(type="L2", strenght=1e-4),
+                           net=TINY["WIRE"], encoder=none_enc),
+        "WIRE2D_regL2": dict(base, model="WIRE2D", batch_size=240, regularization=dict(type="L2", strenght=1e-4),
+                             weight_decay=1e-3, net=TINY["WIRE2D_tanh"], encoder=none_enc),
+        "Fourier_percoil_tv": dict(base, model="Fourier", batch_size=H * W, per_coil=True, use_tv=True,
+                                   undersampling="grid-3*2", net=TINY["Fourier"], encoder=gauss_enc),
+        "Gabor_percoil_tv": dict(base, model="Gabor", batch_size=H * W, per_coil=True, use_tv=True,
+                                 undersampling="grid-3*2", net=TINY["Gabor"], encoder=gauss_enc),
+    }
+    arrs = {"full": npy(k), "masked": npy(masked), "coords": npy(grid), "mask": grid_mask.numpy()}
+    assert torch.equal(grid.reshape(-1, 3), coords_full)
+    meta = {"shape": [C, H, W], "grid": [3, 2], "cases": cases, "seed": 4, "steps": 8}
+    for tag, cfg in cases.items():
+        torch.manual_seed(meta["seed"])
+        encoder = Positional_Encoder(cfg["encoder"], device="cpu")
+        model = quiet(CTORS[cfg["model"]], cfg["net"])
+        optim = torch.optim.Adam(model.parameters(), lr=cfg["lr"], betas=(cfg["beta1"], cfg["beta2"]),
+                                 weight_decay=cfg["weight_decay"])
+        sched = LambdaLR(optim, lambda x: 0.2 ** min(x / cfg["max_epoch"], 1))
+        reg = None
+        if cfg.get("regularization", {}).get("type") == "L1":
+            reg = Regularization_L1(reg_strength=cfg["regularization"]["strenght"])
+        elif cfg.get("regularization", {}).get("type") == "L2":
+            reg = Regularization_L2(reg_strength=cfg["regularization"]["strenght"])
+        tv = cfg.get("use_tv", False)
+        image = (masked if tv else k).reshape(C * H * W, 2)
+        coords = grid.reshape(-1, 3)
+        bs = cfg["batch_size"]
+        losses, step = [], 0
+        for epoch in range(cfg["max_epoch"]):
+            for lo in range(0, coords.shape[0], bs):
+                if step >= meta["steps"]:
+                    break
+                kc, gt = coords[lo:lo + bs], image[lo:lo + bs]
+                out = model(encoder.embedding(kc))
+                optim.zero_grad()
+                loss = 0
+                if tv:  # train.py:172-177
+                    loss = loss + tv_loss(out.view((H, W, 2)))
+                    m = grid_mask.reshape(-1, 3)[lo:lo + bs, 0]
+                    out, gt = out[m], gt[m]
+                loss = loss + 0.5 * torch.nn.functional.mse_loss(out, gt)
+                if reg is not None:
+                    loss = loss + reg(model.parameters())
+                loss.backward()
+                optim.step()
+                losses.append(float(loss.detach()))
+                step += 1
+            sched.step()
+        arrs[tag + "/losses"] = np.array(losses, dtype=np.float64)
+        with torch.no_grad():
+            arrs[tag + "/final_out"] = npy(model(encoder.embedding(coords)).contiguous())
+        for kname, v in model.state_dict().items():
+            arrs[f"{tag}/final_sd/{kname}"] = npy(v)
+    np.savez_compressed(os.path.join(OUT, "trajectory_extra.npz"), **arrs)
+    with open(os.path.join(OUT, "trajectory_extra_meta.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+
+
 def clustering_vectors():
     """Ring partition (clustering.py:19-135) on a small synthetic k-space.  clustering.py imports
     models.utils at module scope only for its __main__ block (get_config / get_data_loader); that module drags in
@@ -649,7 +730,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     parts = dict(ingest=ingest_vectors, clustering=clustering_vectors, undersampling=undersampling_vectors, init=init_hashes,
                  models=model_vectors, losses=loss_vectors, center=center_vectors, trajectory=trajectory,
-                 multiscale=multiscale_trajectory)
+                 multiscale=multiscale_trajectory, extra=extra_trajectories)
     for name in (sys.argv[1:] or list(parts)):  # python tools/make_golden.py [part ...]; default: everything
         parts[name]()
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
