@@ -1146,14 +1146,20 @@ __device__ __forceinline__ void dw_pass(const float* Rall, int region_stride, BS
 // forward + pointwise loss + backward.
 // ---------------------------------------------------------------------------------------------
 // Diagnostic phase stamps (never compiled into the shipped library): s_memtime per wave at phase
-// boundaries, written to a buffer nothing else reads.
+// boundaries, written to a buffer nothing else reads; s_memrealtime beside the first and the latest one, so that
+// (stamp_last - stamp_0) / (slot 63 - slot 62) x 100 MHz is the clock the wave ran at (MI355X_MICROARCH.md, DVFS (6)).
 #ifdef INR_STAMPS
 #define INR_STAMP(i)                                                                               \
   do {                                                                                             \
     __builtin_amdgcn_sched_barrier(0);                                                             \
     const long long stamp_at_ = ((long long)blockIdx.x * NW + w) * 64 + (i);                       \
-    if (a.dbg != nullptr && lane == 0 && (i) < 64 && stamp_at_ < a.dbg_cap)                       \
+    if (a.dbg != nullptr && lane == 0 && (i) < 62 && stamp_at_ - (i) + 63 < a.dbg_cap) {           \
       a.dbg[stamp_at_] = (long long)__builtin_amdgcn_s_memtime();                                  \
+      /* slots 62 / 63: the 100 MHz counter at the wave's first and latest stamp (in-kernel clock) */ \
+      const long long rt_ = (long long)__builtin_amdgcn_s_memrealtime();                           \
+      if ((i) == 0) a.dbg[stamp_at_ + 62] = rt_;                                                   \
+      a.dbg[stamp_at_ - (i) + 63] = rt_;                                                           \
+    }                                                                                              \
     __builtin_amdgcn_sched_barrier(0);                                                             \
   } while (0)
 #else

@@ -655,10 +655,14 @@ __global__ __launch_bounds__(512, 2) void inr_siren_bf16_kernel(const NetDesc nd
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: LDS-DMA destinations go through M0
   // MODE.FP16_OVFL: conversions to fp16 and bf8 saturate at the largest finite value instead of overflowing to infinity
   // (tools/probes/bf8_clamp_probe.hip) -- a dZ beyond the gradient scale's headroom is clipped, not turned into NaNs
+#ifdef INR_STAMPS  // slot 60 / 61: the 100 MHz counter at kernel entry / exit of each wave (tools/stamps.py: prologue, drain)
+  if (a.dbg != nullptr && lane == 0 && ((long long)blockIdx.x * NW + w) * 64 + 63 < a.dbg_cap)
+    a.dbg[((long long)blockIdx.x * NW + w) * 64 + 60] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
   if (MODE != MODE_FWD) asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1");
   float* bias_lds = reinterpret_cast<float*>(lds_raw + PN_SLOTS * W2_PANEL_BYTES);  // [D][256]
   float* encB_lds = bias_lds + D * 256;                                             // [E][4]
-  float* red_lds = encB_lds + 4 * nd.E;                                             // [8]
+  float* red_lds = encB_lds + 4 * nd.E;                                             // [2][8]: loss partials, |dZ| maxima
   const int E = nd.E;
   for (int i = tid; i < D * 256; i += 64 * NW) bias_lds[i] = a.packed[nd.w2_bias_off + i];
   for (int i = tid; i < 4 * E; i += 64 * NW)  // rows padded to 16 bytes: one broadcast read per feature
@@ -701,10 +705,18 @@ __global__ __launch_bounds__(512, 2) void inr_siren_bf16_kernel(const NetDesc nd
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (MODE != MODE_FWD) {
     // the step's largest scaled |dZ|: non-negative floats order like their bit patterns
+    // ONE atomic per workgroup: 2 048 waves updating the same word took 12 us of a 102 us launch (the updates of one
+    // address are served one after the other at the memory side; profiles/r04_stamps_bf16_65536.txt)
     float m = amax;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-    if (lane == 0 && st != nullptr && m > 0.f) atomicMax(reinterpret_cast<unsigned*>(st) + 1, __builtin_bit_cast(unsigned, m));
+    if (lane == 0) red_lds[NW + w] = m;
+    __syncthreads();
+    if (tid == 0 && st != nullptr) {
+      float mw = 0.f;
+      for (int i = 0; i < NW; ++i) mw = fmaxf(mw, red_lds[NW + i]);
+      if (mw > 0.f) atomicMax(reinterpret_cast<unsigned*>(st) + 1, __builtin_bit_cast(unsigned, mw));
+    }
     if (blockIdx.x == 0 && tid == 0 && st != nullptr) {
       st[2] = mult;
       st[3] = st[0];
@@ -724,11 +736,15 @@ __global__ __launch_bounds__(512, 2) void inr_siren_bf16_kernel(const NetDesc nd
       a.slabs[(size_t)blockIdx.x * nd.slab_floats + nd.slab_loss_off] = t;
     }
   }
+#ifdef INR_STAMPS
+  if (a.dbg != nullptr && lane == 0 && ((long long)blockIdx.x * NW + w) * 64 + 63 < a.dbg_cap)
+    a.dbg[((long long)blockIdx.x * NW + w) * 64 + 61] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 template <int MODE, int NH>
 inline hipError_t launch_siren_bf16_nh(const NetDesc& nd, const LossDesc& ld, const MlpArgs& a, int grid, hipStream_t st) {
-  const size_t lds_bytes = (size_t)PN_SLOTS * W2_PANEL_BYTES + ((size_t)nd.D * 256 + 4 * (size_t)nd.E + PN_WAVES) * sizeof(float);
+  const size_t lds_bytes = (size_t)PN_SLOTS * W2_PANEL_BYTES + ((size_t)nd.D * 256 + 4 * (size_t)nd.E + 2 * PN_WAVES) * sizeof(float);
   if (lds_bytes > 160 * 1024 || a.save_by_block) return hipErrorInvalidValue;
   if (MODE != MODE_FWD && (a.save == nullptr || a.dz_state == nullptr)) return hipErrorInvalidValue;
   if (MODE == MODE_FUSED && a.slabs == nullptr) return hipErrorInvalidValue;

@@ -71,9 +71,17 @@ nt, nb = eng.launch_dims(B)
 NWV = 8 if PREC == "bf16" else WAVES_PER_WORKGROUP  # (the bf16 kernel: eight waves, two tile groups)
 dbg = torch.zeros(nb * NWV * 64, dtype=torch.int64, device=dev)
 lib.inr_debug_set_stamp_buffer(dbg.data_ptr(), dbg.numel())
+import time
 for _ in range(3):
     step()
 torch.cuda.synchronize()
+# >= 2.5 s of back-to-back steps on random data before the launch whose stamps are read: the clock a kernel holds under load
+# is reached only after seconds (MI355X_MICROARCH.md, DVFS (6)); every launch overwrites the stamps, the last one stays
+t_warm = time.perf_counter()
+while time.perf_counter() - t_warm < 2.5:
+    for _ in range(50):
+        step()
+    torch.cuda.synchronize()
 if PREC == "bf16":  # wall time of the fused kernel alone (grads = NULL) in this build: cycles / time = the clock it ran at
     ws = eng._ws(*eng.workspace(B)); ld = eng.loss_desc(M.LossSpec(L.LOSS_L2_HALF), B)
     def fused_only():
@@ -132,6 +140,30 @@ else:
         order = list(range(len(labels)))
         last = len(labels) - 1
 tot = (d[:, :, last] - d[:, :, 0])
+rt = d[:, :, 63] - d[:, :, 62]
+ok = (rt > 0) & (tot > 0)
+ghz = (tot[ok] / rt[ok] * 0.1)
+rt0, rt1 = d[:, :, 62][d[:, :, 62] > 0], d[:, :, 63][d[:, :, 63] > 0]
+print(f"100 MHz counter, all waves of the launch: first stamp of the earliest wave -> last stamp of the latest "
+      f"{(rt1.max() - rt0.min()) / 100:.1f} us; first stamps spread over {(rt0.max() - rt0.min()) / 100:.1f} us, last stamps over "
+      f"{(rt1.max() - rt1.min()) / 100:.1f} us")
+if PREC == "bf16":  # slots 60 / 61: the counter at kernel entry / exit of each wave
+    e0, e1 = d[:, :, 60], d[:, :, 61]
+    print(f"kernel entry of the earliest wave -> exit of the latest: {(e1.max() - e0.min()) / 100:.1f} us; entry -> first stamp "
+          f"(tables, first panels, barrier): median {float((d[:, :, 62] - e0).median()) / 100:.2f} us; last stamp -> exit (drain, "
+          f"scale state, loss word): median {float((e1 - d[:, :, 63]).median()) / 100:.2f} us; entries spread over "
+          f"{(e0.max() - e0.min()) / 100:.2f} us")
+if d.shape[0] >= 8:  # workgroup b runs on XCD b % 8 (round-robin dispatch): do the slow waves share an XCD?
+    q = torch.quantile(tot.flatten(), torch.tensor([0.5, 0.9, 0.99], dtype=tot.dtype))
+    print(f"cycles/wave quantiles: median {q[0]:.0f}  p90 {q[1]:.0f}  p99 {q[2]:.0f}  max {tot.max():.0f}")
+    wg_end = d[:, :, 63].max(dim=1).values
+    for x in range(8):
+        sel = torch.arange(d.shape[0]) % 8 == x
+        t_x, r_x = tot[sel], rt[sel]
+        print(f"  XCD {x}: cycles/wave mean {t_x.mean():.0f} max {t_x.max():.0f}; clock {float((t_x / r_x).mean()) * 0.1:.3f} GHz; "
+              f"last workgroup ends {(wg_end[sel].max() - rt0.min()) / 100:.1f} us after the launch's first stamp")
+print(f"in-kernel clock (d s_memtime / d s_memrealtime x 100 MHz, first to last stamp of a wave, after >= 2.5 s of launches): "
+      f"median {ghz.median():.3f} GHz, min {ghz.min():.3f}, max {ghz.max():.3f} over {int(ok.sum())} waves")
 print(f"B={B} blocks={nb} (last tile of each) total cycles/wave: mean {tot.mean():.0f} min {tot.min():.0f} max {tot.max():.0f}")
 if PREC == "bf16":
     span = float((d[:, :, last].max(dim=1).values - d[:, :, 0].min(dim=1).values).mean())
@@ -141,4 +173,8 @@ prev = order[0]
 for i in order[1:]:
     seg = d[:, :, i] - d[:, :, prev]
     print(f"  {names[i]:>24s}: mean {seg.mean():9.0f}  per-wave means {[round(float(seg[:, w].mean())) for w in range(NWV)]}")
+    if d.shape[0] >= 8:
+        xs = [float(seg[torch.arange(d.shape[0]) % 8 == x].mean()) for x in range(8)]
+        if max(xs) > 1.08 * sorted(xs)[3]:  # an XCD more than 8 % above the median XCD in this phase
+            print(f"  {'':>24s}  by XCD {[round(v) for v in xs]}")
     prev = i

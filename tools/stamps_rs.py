@@ -41,9 +41,12 @@ for _ in range(200):
 e1.record(); torch.cuda.synchronize()
 us = e0.elapsed_time(e1) / 200 * 1e3
 lib.inr_debug_set_stamp_buffer(dbg.data_ptr(), dbg.numel())
-for _ in range(3):
-    fused_only()
-torch.cuda.synchronize()
+import time
+t_warm = time.perf_counter()  # >= 2.5 s of back-to-back launches before the one whose stamps stay (DVFS settles in seconds)
+while time.perf_counter() - t_warm < 2.5:
+    for _ in range(200):
+        fused_only()
+    torch.cuda.synchronize()
 lib.inr_debug_set_stamp_buffer(None, 0)
 d = dbg.cpu().view(NB, 4, 64).double()
 live = d[:, 0, 40] > 0
@@ -58,6 +61,14 @@ for l in range(D - 2, 0, -1):
         order += [(30 + l, f"epilogue dZ_{l-1} + syncs")]
 order += [(40, "dZ_0 -> stash")]
 tot = d[:, :, 40] - d[:, :, 0]
+rt = d[:, :, 63] - d[:, :, 62]
+ghz = (tot / rt * 0.1)[rt > 0]
+rt0, rt1 = d[:, :, 62][d[:, :, 62] > 0], d[:, :, 63][d[:, :, 63] > 0]
+print(f"100 MHz counter, all waves of the launch: first stamp of the earliest wave -> last stamp of the latest "
+      f"{(rt1.max() - rt0.min()) / 100:.1f} us; first stamps spread over {(rt0.max() - rt0.min()) / 100:.1f} us, last stamps over "
+      f"{(rt1.max() - rt1.min()) / 100:.1f} us")
+print(f"in-kernel clock (d s_memtime / d s_memrealtime x 100 MHz, first to last stamp of a wave, after >= 2.5 s of launches): "
+      f"median {ghz.median():.3f} GHz, min {ghz.min():.3f}, max {ghz.max():.3f}")
 print(f"B={B} D={D}: fused kernel alone {us:.1f} us per launch; workgroups with a tile {int(live.sum())}; last tile of each: "
       f"cycles/wave mean {tot.mean():.0f} min {tot.min():.0f} max {tot.max():.0f}  -> >= {tot.max() / us / 1e3:.2f} GHz")
 prev = 0
