@@ -18,6 +18,15 @@
 #include "inr_dw_gemm_bf16.h"
 #include "inr_w2.h"
 
+#ifdef INR_STAMPS
+namespace inr {
+long long* g_stamp_buf = nullptr;  // diagnostic build only (make dbg): phase stamps of the fused kernels, entry / exit
+long long g_stamp_cap = 0;         // stamps of the GEMMs; entries behind it: a stamp whose index is not below this is dropped
+}  // namespace inr
+using inr::g_stamp_buf;
+using inr::g_stamp_cap;
+#endif
+
 namespace {
 
 thread_local char g_err[512] = "";
@@ -45,10 +54,6 @@ inline int pick_nb(int need, std::initializer_list<int> built) {
 
 constexpr int kMaxBlocks = 256;  // one persistent workgroup per CU (MI355X: 256 CUs)
 
-#ifdef INR_STAMPS
-long long* g_stamp_buf = nullptr;  // diagnostic build only (make dbg): phase stamps of the fused kernels
-long long g_stamp_cap = 0;         // entries behind it: INR_STAMP drops a stamp whose index is not below this
-#endif
 
 }  // namespace
 

@@ -42,6 +42,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define LOSS_MSLE_HALF 5
 #define LOSS_CENTER 6
 
+#include "inr_stamp_rt.h"
+
 struct LayerDesc {
   int K, M;          // in / out features of the (virtual) real matrix the kernel multiplies
   int Kpad8;         // K rounded up to a multiple of 8 (4 k-steps of 2 per A-fragment float4)

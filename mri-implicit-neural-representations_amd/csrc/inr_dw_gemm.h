@@ -14,6 +14,8 @@ struct DwGemmItem {
 };
 
 struct DwGemmArgs {
+  long long* dbg = nullptr;  // diagnostic builds (-DINR_STAMPS) only: entry / exit stamps (set by the launcher)
+  long long dbg_cap = 0;
   const float* save;   // per-tile stash, n_tiles slots
   float* slabs;        // n_chunks slabs of slab_floats floats (layout of the fused kernels' slabs)
   long long save_floats_per_tile;

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include "inr_dw_gemm.h"
+#include "inr_stamp_rt.h"
 #include "inr_launch.h"
 
 namespace inr {
@@ -192,6 +193,7 @@ __device__ __forceinline__ void dwg_body(const DwGemmArgs& a, const DwGemmItem& 
 template <int TL, int WBM, int WB>
 __global__ __launch_bounds__(256) void dw_gemm_kernel(const DwGemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  INR_RT_STAMP(a.dbg, a.dbg_cap, 4, threadIdx.x >> 6, threadIdx.x & 63, 44);
   const int kc = blockIdx.x / a.blocks_per_chunk;
   const int unit = blockIdx.x - kc * a.blocks_per_chunk;
   int k = 0;
@@ -203,6 +205,7 @@ __global__ __launch_bounds__(256) void dw_gemm_kernel(const DwGemmArgs a) {
     dwg_body<TL, WBM, WB, true>(a, it, kc, 2 * WBM * mi, 0, lds);
   else
     dwg_body<TL, WBM, WB, false>(a, it, kc, 2 * WBM * mi, 2 * WB * ni, lds);
+  INR_RT_STAMP(a.dbg, a.dbg_cap, 4, threadIdx.x >> 6, threadIdx.x & 63, 45);
 }
 
 template <int TL, int WBM, int WB>
@@ -217,8 +220,16 @@ static hipError_t launch_tl(const DwGemmArgs& a, dim3 grid, hipStream_t st) {
   return hipGetLastError();
 }
 
+#ifdef INR_STAMPS
+extern long long* g_stamp_buf;  // inr_api.hip
+extern long long g_stamp_cap;
+#endif
+
 hipError_t launch_dw_gemm(DwGemmArgs& a, hipStream_t st) {
   if (a.n_items <= 0) return hipSuccess;
+#ifdef INR_STAMPS
+  a.dbg = g_stamp_buf, a.dbg_cap = g_stamp_cap;
+#endif
   if (a.n_items > INR_DWG_MAX_ITEMS || a.n_chunks <= 0 || a.tiles_per_chunk <= 0) return hipErrorInvalidValue;
   a.blocks_per_chunk = dw_gemm_units(a);
   a.units = a.blocks_per_chunk;

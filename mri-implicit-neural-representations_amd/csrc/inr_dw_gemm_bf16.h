@@ -20,6 +20,8 @@ struct DwGemmBf16Unit {
 };
 
 struct DwGemmBf16Args {
+  long long* dbg = nullptr;  // diagnostic builds (-DINR_STAMPS) only: entry / exit stamps (set by the launcher)
+  long long dbg_cap = 0;
   const void* save;    // per-tile stash, n_tiles slots
   float* slabs;        // n_chunks slabs of slab_floats floats
   const float* coords; // [B,3] (first-layer units)

@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 
 #include "inr_dw_gemm_bf16.h"
+#include "inr_stamp_rt.h"
 #include "inr_launch.h"
 #include "inr_w2.h"
 
@@ -401,6 +402,7 @@ __device__ __forceinline__ void dwgb_body(const DwGemmBf16Args& a, const DwGemmB
 template <int TL>
 __global__ __launch_bounds__(GB_NT, 2) void dw_gemm_bf16_kernel(const DwGemmBf16Args a) {
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+  INR_RT_STAMP(a.dbg, a.dbg_cap, GB_NT / 64, threadIdx.x >> 6, threadIdx.x & 63, 44);
   int b = blockIdx.x, kc, u, tpc;
   const int enc_wgs = a.n_enc_units * a.n_chunks_enc;
   if (b < enc_wgs) {
@@ -423,6 +425,7 @@ __global__ __launch_bounds__(GB_NT, 2) void dw_gemm_bf16_kernel(const DwGemmBf16
   }
   // the next step's gradient scale (inr_w2.h): nothing in this launch reads words 0 and 1
   if (a.dz_state != nullptr && blockIdx.x == 0 && threadIdx.x == 0) dz_state_roll(a.dz_state, a.dz_count);
+  INR_RT_STAMP(a.dbg, a.dbg_cap, GB_NT / 64, threadIdx.x >> 6, threadIdx.x & 63, 45);
 }
 
 __global__ void dz_roll_kernel(float* st, float* cnt) { dz_state_roll(st, cnt); }
@@ -438,7 +441,16 @@ extern "C" int inr_debug_gemm_stamps(long long* host_out) {
 }
 #endif
 
-hipError_t launch_dw_gemm_bf16(const DwGemmBf16Args& a, hipStream_t st) {
+#ifdef INR_STAMPS
+extern long long* g_stamp_buf;  // inr_api.hip
+extern long long g_stamp_cap;
+#endif
+
+hipError_t launch_dw_gemm_bf16(const DwGemmBf16Args& a_in, hipStream_t st) {
+  DwGemmBf16Args a = a_in;
+#ifdef INR_STAMPS
+  a.dbg = g_stamp_buf, a.dbg_cap = g_stamp_cap;
+#endif
   if (a.n_units <= 0 || a.n_units > INR_DWGB_MAX_UNITS || a.n_chunks <= 0 || a.tiles_per_chunk <= 0 || a.TL != 128 ||
       a.E > 1024 || a.n_enc_units < 0 || a.n_enc_units >= a.n_units ||
       (a.n_enc_units > 0 && (a.n_chunks_enc <= 0 || a.tiles_per_chunk_enc <= 0)))

@@ -545,6 +545,7 @@ __global__ __launch_bounds__(256) void inr_mlp_rs_kernel(const NetDesc nd, const
   constexpr int NQ = (NCB + 3) / 4;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  INR_RT_STAMP(a.dbg, a.dbg_cap, NW, w, lane, 44);  // (diagnostic builds: kernel entry / exit of each wave, slots 44 / 45)
   const int kq = lane >> 4, jj = lane & 15;
   const int D = nd.D, E = nd.E;
   lfloat* img = (lfloat*)lds;
@@ -772,6 +773,7 @@ __global__ __launch_bounds__(256) void inr_mlp_rs_kernel(const NetDesc nd, const
       slab[nd.slab_loss_off] = a.accumulate ? slab[nd.slab_loss_off] + tsum : tsum;
     }
   }
+  INR_RT_STAMP(a.dbg, a.dbg_cap, NW, w, lane, 45);
 }
 
 inline size_t rs_lds_bytes(const NetDesc& nd) {

@@ -5,15 +5,23 @@ set -o pipefail
 R=${1:-r03}
 export TMPDIR=/tmp
 mkdir -p gpurun_out
+[ -f mri-implicit-neural-representations_amd/lib/libinr_mi355x_dbg.so ] || { echo "build the diagnostic library first (here, not on the GPU box): tools/build_dbg_rs.sh inr_siren_bf16_m0 inr_siren_bf16_m1 inr_siren_bf16_m2 inr_mlp_nb8 inr_dw_gemm inr_dw_gemm_bf16"; exit 1; }
 echo "== bench"; timeout -k 10 400 python bench.py > gpurun_out/${R}_bench.json 2> gpurun_out/${R}_bench.err || { tail -5 gpurun_out/${R}_bench.err; exit 1; }
+echo "== bench, the command the driver runs"; timeout -k 10 400 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${R}_bench_driver_command.json 2> gpurun_out/${R}_bench_driver_command.err || { tail -5 gpurun_out/${R}_bench_driver_command.err; exit 1; }
 echo "== kernel trace + PMC of the bench command"; timeout -k 10 900 bash tools/pmc_round.sh $R > gpurun_out/${R}_pmc_round.log 2>&1 || { tail -5 gpurun_out/${R}_pmc_round.log; exit 1; }
 echo "== bench_models"; timeout -k 10 400 python tools/bench_models.py > gpurun_out/${R}_bench_models.json 2> gpurun_out/${R}_bench_models.err || { tail -5 gpurun_out/${R}_bench_models.err; exit 1; }
 echo "== bf16 kernel durations by batch"; timeout -k 10 300 bash tools/prof_bf16.sh ${R}_bf16 65536 25000 > gpurun_out/${R}_prof_bf16.log 2>&1 || { tail -5 gpurun_out/${R}_prof_bf16.log; exit 1; }
 echo "== bf16 PMC"; timeout -k 10 600 bash tools/pmc_bf16.sh ${R}_bf16 65536 > gpurun_out/${R}_pmc_bf16.log 2>&1 || { tail -5 gpurun_out/${R}_pmc_bf16.log; exit 1; }
-echo "== stamps"
-for a in "65536 bf16" "25000 bf16" "25000 f32"; do
+# (afterwards, in the repository: cp gpurun_out/${R}_pmc_by_grid.csv profiles/ && python tools/traffic_from_pmc.py profiles/${R}_pmc_by_grid.csv)
+echo "== stamps (phases, in-kernel clock) and launch-level stamps (entry / exit of every wave)"
+for a in "65536 bf16" "25000 bf16" "65536 f32"; do
   set -- $a
   timeout -k 10 200 python3 tools/stamps.py $1 $2 > gpurun_out/${R}_stamps_$2_$1.txt 2>&1 || { tail -3 gpurun_out/${R}_stamps_$2_$1.txt; exit 1; }
+done
+timeout -k 10 200 python3 tools/stamps_rs.py 25000 > gpurun_out/${R}_stamps_rs_25000.txt 2>&1 || { tail -3 gpurun_out/${R}_stamps_rs_25000.txt; exit 1; }
+for a in "25000 f32" "65536 f32" "25000 bf16" "65536 bf16"; do
+  set -- $a
+  timeout -k 10 200 python3 tools/stamps_launch.py $1 $2 > gpurun_out/${R}_launch_$2_$1.txt 2>&1 || { tail -3 gpurun_out/${R}_launch_$2_$1.txt; exit 1; }
 done
 echo "== rounding oracle distances"; timeout -k 10 300 python3 tests/debug_bf16_oracle.py 127 4133 32845 > gpurun_out/${R}_bf16_oracle_distances.txt 2>&1 || { tail -3 gpurun_out/${R}_bf16_oracle_distances.txt; exit 1; }
 echo "== probes"
