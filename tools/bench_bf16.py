@@ -1,5 +1,5 @@
 """Quick timing of the bf16 path (GPU): fused kernel alone, gradient path (fused + dW GEMM + reduction), per batch size.
-python tools/bench_bf16.py [B ...]   (HIP events on the current stream, 100 repetitions after 30 warm-up)"""
+python tools/bench_bf16.py [B ...]   (HIP events on the current stream, 200 repetitions after 0.6 s of warm-up)"""
 import os, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "mri-implicit-neural-representations_amd"))
@@ -18,9 +18,15 @@ encB = enc.B.contiguous()
 spec = M.LossSpec(L.LOSS_L2_HALF)
 
 
-def timed(fn, reps=100, warm=30):
-    for _ in range(warm):
+def timed(fn, reps=200, warm=30):
+    import time
+    t0 = time.perf_counter()
+    n = 0
+    while n < warm or time.perf_counter() - t0 < 0.6:  # the chip's clocks settle after some 0.5 s of load
         fn()
+        n += 1
+        if n % 50 == 0:
+            torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()

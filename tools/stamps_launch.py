@@ -65,6 +65,9 @@ def collect(fn, nw, s0, s1):
     d = dbg.cpu().view(-1, 64)
     d = d[: (d.shape[0] // nw) * nw].view(-1, nw, 64).double()
     live = (d[:, :, s0] > 0).all(dim=1) & (d[:, :, s1] > 0).all(dim=1)
+    if s0 < 60:  # shader-clock counter two slots on: the clock each wave ran at between entry and exit
+        clk = ((d[live][:, :, s1 + 2] - d[live][:, :, s0 + 2]) / (d[live][:, :, s1] - d[live][:, :, s0]) * 0.1).flatten()
+        print(f"   [entry -> exit clock of the next kernel: median {clk.median():.3f} GHz, min {clk.min():.3f}, max {clk.max():.3f}]")
     return d[live][:, :, s0], d[live][:, :, s1], torch.nonzero(live)[:, 0]
 
 
@@ -77,6 +80,11 @@ def report(name, us, e0, e1, blocks):
           f"{(wg1.max() - wg1.min()) / 100:.1f} us")
     print(f"   workgroup duration: median {q[0]:.1f}  p90 {q[1]:.1f}  p99 {q[2]:.1f}  max {dur.max():.1f} us; a wave of the "
           f"workgroup exits up to {float(((e1.max(dim=1).values - e1.min(dim=1).values) / 100).max()):.1f} us before its last")
+    n = len(blocks)
+    tenths = [dur[(blocks >= blocks.min() + (blocks.max() + 1 - blocks.min()) * i // 10) &
+                  (blocks < blocks.min() + (blocks.max() + 1 - blocks.min()) * (i + 1) // 10)] for i in range(10)]
+    print("   by tenth of the grid, in block order (mean / max us): " +
+          "  ".join(f"{float(v.mean()):.1f}/{float(v.max()):.1f}" if len(v) else "-" for v in tenths))
     by = [dur[blocks % 8 == x] for x in range(8)]
     print("   by XCD (mean / max us): " + "  ".join(f"{float(v.mean()):.1f}/{float(v.max()):.1f}" if len(v) else "-" for v in by))
 
