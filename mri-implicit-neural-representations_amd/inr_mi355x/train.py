@@ -97,10 +97,13 @@ SHARDED_UPDATE_MIN_PARAMS = 1 << 20  # below this the step's exchange is latency
 def wants_sharded_update(config: dict, n_params: int, world: int) -> bool:
     """config["dp_sharded_update"] (True / False; default: networks of >= 2^20 parameters, i.e. BASELINE config 4's
     4.47 M, not the 0.33 M of SIREN 5x256) decides between the two exchange steps of exchange_and_update."""
-    if world <= 1:
-        return False
     v = config.get("dp_sharded_update")
-    return n_params >= SHARDED_UPDATE_MIN_PARAMS if v is None else bool(v)
+    if v is None:
+        return world > 1 and n_params >= SHARDED_UPDATE_MIN_PARAMS
+    if world <= 1:  # an explicit True on one rank runs the same collectives over a one-rank group (rehearsals of the nccl calls)
+        import torch.distributed as dist
+        return bool(v) and dist.is_available() and dist.is_initialized()
+    return bool(v)
 
 
 def exchange_and_update(engine, loss: torch.Tensor, world: int, group, sharded: bool, lr: float, beta1: float,
@@ -314,7 +317,7 @@ class INRTrainer:
         A = self._batch_hdr_A(it, lo, hi)
         if self.graph_steps:
             return self._graph_step(epoch, it, lo, hi, count, A)
-        if self.world == 1 and self.one_call_steps and hi > lo:
+        if self.world == 1 and self.one_call_steps and not self.sharded_update and hi > lo:
             # single rank: nothing sits between the reduction and the update -- one call, one launch less
             cfg = self.config
             penalty, _ = self._penalty()  # value of the penalty at the parameters the step starts from, as below

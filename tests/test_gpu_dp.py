@@ -49,7 +49,7 @@ def _cases():
     }
 
 
-def _run(case, rank, world, pg=None):
+def _run(case, rank, world, pg=None, one_rank_group=False):
     from inr_mi355x.synthetic import make_kspace
     from inr_mi355x.train import INRTrainer
     from inr_mi355x.train_kspace_multiscale import MultiscaleTrainer
@@ -66,7 +66,7 @@ def _run(case, rank, world, pg=None):
         return [], tr.predict_all().cpu()
     else:
         tr = INRTrainer(cfg, image, coords, shape, dev, seed=1, rank=rank, world=world, process_group=pg)
-    assert tr.sharded_update == (world > 1 and case.endswith("_sharded"))
+    assert tr.sharded_update == ((world > 1 or one_rank_group) and case.endswith("_sharded"))
     if case.endswith("_bf16"):
         # bf16 cases also hand back the initial weights and the (all-reduced) gradient of the first step: what a wrong
         # shard, halo row or collective would change at O(1), where five Adam steps of lr each cannot tell
@@ -148,3 +148,38 @@ def test_ranks_equal_one(case, world):
     if case != "ensemble":  # replicas stay bitwise identical: same reduced gradient, same Adam (or the same gathered buffer)
         for rank in range(1, world):
             np.testing.assert_array_equal(got[0][1], got[rank][1])
+
+
+def _nccl_one_rank_worker(port, case, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        res = _run(case, 0, 1, one_rank_group=True)
+        q.put((res[0], res[1].numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["siren_sharded", "multiscale_sharded"])
+def test_sharded_update_through_rccl_on_one_rank(case):
+    """The collectives of the sharded update as the multi-GPU runs issue them -- reduce_scatter_tensor and
+    all_gather_into_tensor of the nccl (= RCCL) backend on device tensors -- over a one-rank group on this GPU: argument
+    shapes, padding and the in-place views are what RCCL accepts, and with one rank the step must equal the replicated
+    update bit for bit (the reduce-scatter is a copy; inr_adam_step_shard + inr_pack_params against inr_adam_step)."""
+    assert torch.cuda.is_available()
+    ref = _run(case, 0, 1)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_one_rank_worker, args=(port, case, q))
+    p.start()
+    losses, params = q.get(timeout=300)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    np.testing.assert_array_equal(np.array(losses), np.array(ref[0]))
+    np.testing.assert_array_equal(params, ref[1].numpy())
