@@ -121,6 +121,13 @@ def test_row_split_vs_oracle_and_tile_kernel(dev, force_rs, B):
     _case(dev, force_rs, B)
 
 
+@pytest.mark.parametrize("B", [112, 113, 24576, 28672, 28673])
+def test_row_split_tile_boundaries(dev, force_rs, B):
+    """exactly one 7-block tile and one coordinate more; every workgroup with exactly 6 / exactly 7 column blocks
+    (256 x 6 x 16, 256 x 7 x 16 rows); one coordinate beyond a full round of 7-block tiles (a second round begins)"""
+    _case(dev, force_rs, B)
+
+
 def test_row_split_full_rounds_forced(dev, force_rs):
     """65 536 rows fill inr_mlp_kernel's rounds exactly, so the library keeps that kernel; forced, the row-split kernel
     deals 6 + 6 + 4 column blocks per workgroup over three rounds and must agree"""
@@ -144,6 +151,8 @@ def test_row_split_masked_hdr_ffn_outputs(dev, force_rs):
     _case(dev, force_rs, 3000, kind="FFN")
     _case(dev, force_rs, 3000, out_f=3)            # four computed last-layer rows (MO = 4)
     _case(dev, force_rs, 3000, out_f=1, last_tanh=True)
+    _case(dev, force_rs, 5000, kind="FFN", masked=True, width=255, E=160)
+    _case(dev, force_rs, 5000, loss_name="HDR", depth=3, width=130, E=512)
 
 
 def test_step_info_matches_what_runs(dev, force_rs):
