@@ -39,6 +39,9 @@
 extern "C" {
 #endif
 
+/* 7: inr_adam_step_shard (data-parallel update on the entries a rank owns), inr_reg_grad (penalty gradients, complex64 tensors
+ *    included; the Adam entry points refuse l1 / l2 != 0 on plans with complex tensors).
+ * 6: inr_plan_step_info, inr_loss_tv_grad, 16-word gradient-scale state.  5: bf16 plans.  4: inr_adam_step_dev.  3: inr_workspace. */
 #define INR_ABI_VERSION 7
 
 /* error codes */
