@@ -8,7 +8,9 @@ namespace inr {
 struct AdamArgs {
   int do_update;      // 0: pack only
   int all_real;       // set by the launcher: every layer is LT_REAL (fast scatter path)
-  int has_dead;       // set by the launcher: some layer has live == 0
+  int has_dead;       // set by the launcher (adam_dead_ranges): some layer has live == 0 ...
+  int n_dead;         // ... and its flat entries are these merged ranges [dead_lo, dead_hi); -1: more than fit, walk the layers
+  int dead_lo[8], dead_hi[8];
   float step_size;    // lr / (1 - beta1^t), computed in double on the host like torch does
   float bc2_sqrt;     // sqrt(1 - beta2^t)
   float omb1;         // float(1 - beta1): the lerp weight torch passes to exp_avg.lerp_

@@ -314,9 +314,14 @@ __device__ __forceinline__ float adam_update_entry(const NetDesc& nd, int i, flo
   float p = params[i];
   bool live = true;
   if (aa.has_dead) {
-    for (int l = 0; l < nd.ND; ++l) {
-      const LayerDesc& L = nd.L[l];
-      if ((i >= L.w_off && i < L.w_off + L.wn) || (i >= L.b_off && i < L.b_off + L.bn)) live = L.live != 0;
+    if (aa.n_dead >= 0) {  // (a handful of ranges in kernel arguments: scalar compares -- the walk over 26 layer descriptors
+      for (int r = 0; r < aa.n_dead; ++r)  //  below was most of the update's time on the 8 x 512 filter network)
+        if (i >= aa.dead_lo[r] && i < aa.dead_hi[r]) live = false;
+    } else {
+      for (int l = 0; l < nd.ND; ++l) {
+        const LayerDesc& L = nd.L[l];
+        if ((i >= L.w_off && i < L.w_off + L.wn) || (i >= L.b_off && i < L.b_off + L.bn)) live = L.live != 0;
+      }
     }
   }
   if (aa.do_update && live) {
@@ -541,15 +546,42 @@ hipError_t launch_step_advance(int* step_dev, hipStream_t st) {
   return hipGetLastError();
 }
 
+// has_dead / the dead layers' flat entries as merged ranges (MultiscaleKFourier's unused heads and last stage: SURVEY A.4 #3)
+static void adam_dead_ranges(const NetDesc& nd, AdamArgs& aa) {
+  aa.has_dead = 0;
+  aa.n_dead = 0;
+  int lo[2 * INR_MAX_LAYERS], hi[2 * INR_MAX_LAYERS], n = 0;
+  for (int l = 0; l < nd.ND; ++l) {
+    const LayerDesc& L = nd.L[l];
+    if (L.live != 0) continue;
+    aa.has_dead = 1;
+    if (L.wn > 0) lo[n] = L.w_off, hi[n] = L.w_off + L.wn, ++n;
+    if (L.bn > 0) lo[n] = L.b_off, hi[n] = L.b_off + L.bn, ++n;
+  }
+  for (int i = 1; i < n; ++i)  // by offset (insertion sort: a few dozen entries at most)
+    for (int j = i; j > 0 && lo[j] < lo[j - 1]; --j) std::swap(lo[j], lo[j - 1]), std::swap(hi[j], hi[j - 1]);
+  int m = 0;
+  for (int i = 0; i < n; ++i) {
+    if (m > 0 && lo[i] <= hi[m - 1]) {
+      hi[m - 1] = std::max(hi[m - 1], hi[i]);
+    } else {
+      lo[m] = lo[i], hi[m] = hi[i], ++m;
+    }
+  }
+  if (m > 8) {
+    aa.n_dead = -1;
+    return;
+  }
+  aa.n_dead = m;
+  for (int i = 0; i < m; ++i) aa.dead_lo[i] = lo[i], aa.dead_hi[i] = hi[i];
+}
+
 hipError_t launch_adam_pack(const NetDesc& nd, float* params, const float* grads, float* m1, float* m2,
                             float* packed, const AdamArgs& aa_in, hipStream_t st) {
   AdamArgs aa = aa_in;
   aa.all_real = 1;
-  aa.has_dead = 0;
-  for (int l = 0; l < nd.ND; ++l) {
-    aa.all_real = aa.all_real && (nd.L[l].ltype == LT_REAL || nd.L[l].ltype == LT_GABOR_MU);
-    aa.has_dead = aa.has_dead || nd.L[l].live == 0;
-  }
+  for (int l = 0; l < nd.ND; ++l) aa.all_real = aa.all_real && (nd.L[l].ltype == LT_REAL || nd.L[l].ltype == LT_GABOR_MU);
+  adam_dead_ranges(nd, aa);
   // large plain-layer networks (BASELINE config 4: 4.47 M entries): the update elementwise, then the images in image order
   // (INR_PACK_BY_IMAGE=0 / 1 forces the choice where both exist: the tests hold one against the other)
   const char* force = getenv("INR_PACK_BY_IMAGE");
@@ -589,8 +621,7 @@ hipError_t launch_adam_shard(const NetDesc& nd, float* params, const float* grad
   if (hi <= lo) return hipSuccess;
   AdamArgs aa = aa_in;
   aa.all_real = 0;
-  aa.has_dead = 0;
-  for (int l = 0; l < nd.ND; ++l) aa.has_dead = aa.has_dead || nd.L[l].live == 0;
+  adam_dead_ranges(nd, aa);
   hipLaunchKernelGGL(adam_shard_kernel, dim3((hi - lo + 255) / 256), dim3(256), 0, st, nd, params, grads_shard, m1, m2, lo,
                      hi, aa);
   return hipGetLastError();
@@ -609,8 +640,7 @@ hipError_t launch_reduce_slabs_adam(const NetDesc& nd, const float* slabs, int n
   }
   AdamArgs aa = aa_in;
   aa.all_real = 1;
-  aa.has_dead = 0;
-  for (int l = 0; l < nd.ND; ++l) aa.has_dead = aa.has_dead || nd.L[l].live == 0;
+  adam_dead_ranges(nd, aa);
   const int grid = (nd.P + 255) / 256;
   hipLaunchKernelGGL(reduce_adam_real_kernel, dim3(grid + 1), dim3(256), 0, st, nd, slabs, n_blocks, grads, loss_out, split,
                      params, m1, m2, packed, aa);

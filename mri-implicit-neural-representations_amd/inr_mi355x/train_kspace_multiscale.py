@@ -12,6 +12,7 @@ from __future__ import annotations
 import math
 from typing import Optional, Sequence
 
+import numpy as np
 import torch
 
 from . import _lib as L
@@ -93,6 +94,7 @@ class MultiscaleTrainer:
         self.coords = coords.to(self.device).contiguous()
         self.image = image.to(self.device).contiguous()
         self.dist_cpu = dist.reshape(-1).contiguous()
+        self._dist_np = self.dist_cpu.detach().cpu().numpy()
         self.dist = self.dist_cpu.to(self.device)
         self.bs = int(shape[1] * shape[2]) if self.per_coil else int(config["batch_size"])
         self.steps_per_epoch = math.ceil(self.n / self.bs)
@@ -106,10 +108,12 @@ class MultiscaleTrainer:
 
     def _cons_spec(self, it: int, lo: int, hi: int) -> ConsistencySpec:
         if it not in self._cons:
-            d = self.dist_cpu[lo:hi]
+            # (numpy, not torch: a torch CPU reduction per step leaves its worker threads spinning, which drove the container
+            # into its CPU quota -- 87 ms stalls, profiles/r03_config5_steps.txt; here: a first visit of every batch of epoch 0)
+            d = self._dist_np[lo:hi]
             inv = []
             for (blo, bhi) in self.pairs[:-1]:
-                n_rows = int(((d < blo) | (d > bhi)).sum())
+                n_rows = int(np.count_nonzero((d < blo) | (d > bhi)))
                 inv.append(1.0 / (2.0 * n_rows) if n_rows else 0.0)  # mse_loss mean over rows x 2 channels
             self._cons[it] = ConsistencySpec(0.1, self.pairs, inv + [0.0], 2)
         return self._cons[it]
