@@ -91,12 +91,15 @@ def allreduce_step_outputs(grads: torch.Tensor, loss: torch.Tensor, world: int, 
     return loss
 
 
-SHARDED_UPDATE_MIN_PARAMS = 1 << 20  # below this the step's exchange is latency, not bytes: one all-reduce is cheaper
+# Below this the replicated update is cheaper than the sharded one's two collectives, chunk copies and re-pack launch:
+# measured on one MI355X, Adam + re-pack of BASELINE config 4's 4.47 M parameters is 0.038 ms replicated against 0.039 ms of
+# local work per rank sharded 8 ways -- the sharded update starts to pay at several times that size.
+SHARDED_UPDATE_MIN_PARAMS = 1 << 24
 
 
 def wants_sharded_update(config: dict, n_params: int, world: int) -> bool:
-    """config["dp_sharded_update"] (True / False; default: networks of >= 2^20 parameters, i.e. BASELINE config 4's
-    4.47 M, not the 0.33 M of SIREN 5x256) decides between the two exchange steps of exchange_and_update."""
+    """config["dp_sharded_update"] (True / False; default: networks of >= 2^24 parameters -- none of the BASELINE
+    configs) decides between the two exchange steps of exchange_and_update."""
     v = config.get("dp_sharded_update")
     if v is None:
         return world > 1 and n_params >= SHARDED_UPDATE_MIN_PARAMS
