@@ -49,6 +49,17 @@ def _cases():
         "siren_bf16_sharded": dict(BASE, model="SIREN", batch_size=700, precision="bf16", lr=1e-4, dp_sharded_update=True,
                                    net=dict(NET, network_input_size=64, network_width=256, network_depth=4),
                                    encoder=dict(ENC, embedding_size=32)),
+        # complex-weight model with the L2 penalty (inr_reg_grad on the summed gradient / on a rank's chunk: pairs cut by the
+        # chunk boundary read their partner from the replicated parameters)
+        "wire_reg": dict(BASE, model="WIRE", batch_size=300, regularization=dict(type="L2", strenght=1e-4),
+                         net=dict(network_input_size=3, network_output_size=2, network_depth=2, network_width=46,
+                                  first_omega_0=30, hidden_omega_0=30, scale=15),
+                         encoder=dict(embedding="none", scale=0, embedding_size=0, coordinates_size=3)),
+        "wire_reg_sharded": dict(BASE, model="WIRE", batch_size=300, regularization=dict(type="L1", strenght=1e-5),
+                                 dp_sharded_update=True,
+                                 net=dict(network_input_size=3, network_output_size=2, network_depth=2, network_width=46,
+                                          first_omega_0=30, hidden_omega_0=30, scale=15),
+                                 encoder=dict(embedding="none", scale=0, embedding_size=0, coordinates_size=3)),
         "ensemble": dict(BASE, model="SIREN", batch_size=SHAPE[1] * SHAPE[2], partition=dict(no_steps=20, no_models=3)),
     }
 
@@ -99,7 +110,7 @@ def _worker(rank, world, port, case, q):
 @pytest.mark.parametrize("case,world", [("siren", 2), ("tv", 2), ("fourier", 2), ("multiscale", 2), ("multiscale_tv", 2),
                                         ("ensemble", 2), ("siren_bf16", 2), ("tv_bf16", 2), ("siren_sharded", 2),
                                         ("siren_sharded", 3), ("multiscale_sharded", 2), ("multiscale_sharded", 3),
-                                        ("siren_bf16_sharded", 2)])
+                                        ("siren_bf16_sharded", 2), ("wire_reg", 2), ("wire_reg_sharded", 3)])
 def test_ranks_equal_one(case, world):
     assert torch.cuda.is_available()
     ref = _run(case, 0, 1)
