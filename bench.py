@@ -678,16 +678,26 @@ def main():
                               "unit": "TFLOP/s", "gradient_path_ms": ns_p,
                               "gradient_path_frac": ns_pach / F32_MFMA_PEAK_TFLOPS,
                               "ms_per_step": ns_dt * 1e3, "coord_samples_per_s": nsb / ns_dt}
+    # The objects below ride in the same line but are not the graded metric: a failure in one of them is reported in its
+    # place ({"error": ...}, also on stderr) instead of taking the line -- and the driver's measurement -- down with it.
+    def secondary(name, fn):
+        try:
+            return fn()
+        except Exception as e:  # noqa: BLE001
+            import traceback
+            traceback.print_exc(file=sys.stderr)
+            return {"error": f"{name}: {type(e).__name__}: {e}"}
+
     if world == 1 and rank == 0 and not args.no_bf16:
-        out["bf16_path"] = bf16_path(cfg, image, coords, shape, dev, args, fused_kernel_ms_of, out)
+        out["bf16_path"] = secondary("bf16_path", lambda: bf16_path(cfg, image, coords, shape, dev, args, fused_kernel_ms_of, out))
         ref = out.get("cpu_baseline", {}).get("reference_psnr")
         if ref is not None and "psnr_at_1k_steps" in out["bf16_path"]:
             out["bf16_path"]["psnr_at_1k_steps"]["delta_vs_reference_db"] = (
                 out["bf16_path"]["psnr_at_1k_steps"]["psnr_db"] - ref["psnr_db"])
     if world == 1 and rank == 0 and not args.no_config5:
-        out["config5_percoil_tv"] = config5_percoil(dev)
+        out["config5_percoil_tv"] = secondary("config5_percoil_tv", lambda: config5_percoil(dev))
     if not args.no_multiscale:  # every rank takes part (strong scaling over the world)
-        ms = multiscale_config4(dev, rank, world, pg, args.ms_steps, 3, barrier)
+        ms = secondary("multiscale_config4", lambda: multiscale_config4(dev, rank, world, pg, args.ms_steps, 3, barrier))
         if rank == 0:
             out["multiscale_config4"] = ms
     if rank == 0:
