@@ -97,12 +97,21 @@ __device__ __forceinline__ float slab_sum(const float* __restrict__ p, size_t st
 #pragma unroll
     for (int k = 0; k < 16; ++k) s += v[k];
   }
-  if (b < n) {  // the tail the same way (clamped addresses, selects after the loads): a chunk-slab set of 23 is a
-    float v[16];  // batch of 16 and then 7 -- as a scalar loop those were 7 serialized L2 / HBM round trips
+  // the tail the same way (clamped addresses, selects after the loads): a chunk-slab set of 23 is a batch of 16 and then 7
+  // -- as a scalar loop those were 7 serialized L2 / HBM round trips.  A short tail takes a short batch (wave-uniform n): the
+  // 4 chunk slabs of the 8 x 512 filter network were 16 loads per entry, 12 of them of the same word.
+  if (n - b > 4) {
+    float v[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) v[k] = p[(size_t)(b + k < n ? b + k : n - 1) * stride];
 #pragma unroll
     for (int k = 0; k < 16; ++k) s += b + k < n ? v[k] : 0.f;
+  } else if (b < n) {
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = p[(size_t)(b + k < n ? b + k : n - 1) * stride];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s += b + k < n ? v[k] : 0.f;
   }
   return s;
 }
