@@ -43,8 +43,11 @@ def step():
 
 
 def timed(fn, n=200):
-    for _ in range(20):
-        fn()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.8:  # (the chip's clocks settle after some 0.5 s of load: a cold figure reads 10 % high)
+        for _ in range(50):
+            fn()
+        torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(); e0.record()
     for _ in range(n):
