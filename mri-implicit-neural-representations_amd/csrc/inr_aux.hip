@@ -296,11 +296,13 @@ __device__ __forceinline__ void put_w2(const NetDesc& nd, int l, float* packed, 
   __bf16* img = reinterpret_cast<__bf16*>(packed + nd.w2_off);
   const int D = nd.D, E = nd.E;
   int t, h, j;
-  if (l == 0) {  // gauss features: K-step t = sines (half 0) / cosines (half 1) of features 8t .. 8t+7; two K-steps per panel
-    h = k >= E;
-    const int kk = h ? k - E : k;
+  if (l == 0) {  // gauss features: K-step t holds frequencies 8t .. 8t+7 -- lane half h the four 8t + 4h .. + 3, as (sine,
+    // cosine) pairs in elements (2i, 2i+1): one phase chain per pair in the kernel; two K-steps per panel
+    const int trig = k >= E;
+    const int kk = trig ? k - E : k;
     t = kk >> 3;
-    j = kk & 7;
+    h = (kk & 7) >> 2;
+    j = 2 * (kk & 3) + trig;
     img[w2_index(t >> 1, (t & 1) * 8 + (row >> 5), h * 32 + (row & 31), j)] = (__bf16)(v * w2_krev(nd, 0));
   } else {
     w2_kperm_inv(k, t, h, j);

@@ -447,7 +447,6 @@ struct SirenTile {
         sampled = valid && half == 0 && mk != 0;
       }
     }
-    const float quarter = half ? 0.25f : 0.f;
     int si = 0;  // diagnostic builds: phase stamps 0, 1, 2, ... in program order (tools/stamps.py)
     constexpr int NW = PN_WAVES;
     (void)si;
@@ -464,35 +463,37 @@ struct SirenTile {
         f32x16 acc8[8];
         u32x4 bq[2][4];  // B operands of the chunk being multiplied / being generated
         bf16x8 A[2][8];
-        float fprev = 0.f;
-        // feature j of K-step s of chunk ch into dst; the feature's row of the encoder matrix was read from LDS a slot
-        // earlier (nb), the next one's (of chunk chn: the same chunk, or the next behind its last feature) is read here
-        f32x4 nb[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};  // rows of features q, q+1 (set q & 1), read two slots ahead
-        auto enc_row = [&](int ch, int q, f32x4& dst) {  // q = 8 s + j < 32
-          dst = *reinterpret_cast<const f32x4*>(encB_lds + 4 * (32 * ch + q));
+        float fprev = 0.f, fph = 0.f;
+        // Element j of K-step s of chunk ch into dst.  A lane half holds the sine AND the cosine of four frequencies per
+        // K-step -- elements (2i, 2i+1) = (sin, cos) of frequency 8 s + 4 half + i of the chunk (the weight panels are packed
+        // in that k order, inr_aux.hip put_w2) -- so ONE phase chain serves two elements (both halves used to run the same
+        // eight chains, the cosine half from a start of 1/4 turn).  The frequency's row of the encoder matrix was read from
+        // LDS two slots earlier; the next one's (of chunk chn: the same chunk, or the next behind its last element) here.
+        f32x4 nbr = {0.f, 0.f, 0.f, 0.f};
+        auto enc_row = [&](int ch, int q, f32x4& dst) {  // q = 8 s + j < 32, j even
+          dst = *reinterpret_cast<const f32x4*>(encB_lds + 4 * (32 * ch + (q & ~7) + 4 * half + ((q & 7) >> 1)));
         };
         auto gen_value = [&](int ch, int chn, auto SC, auto JC, u32x4 (&dst)[4]) {
           constexpr int s = decltype(SC)::value, j = decltype(JC)::value, q = 8 * s + j;
-          const f32x4 b = nb[q & 1];
-          const float f = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(fmaf(x2, b[2], fmaf(x1, b[1], fmaf(x0, b[0], quarter)))));
-          if constexpr (q + 2 < 32)
-            enc_row(ch, q + 2, nb[q & 1]);
-          else
-            enc_row(chn, q + 2 - 32, nb[q & 1]);
-          if constexpr (j & 1) {
-            unsigned d = pack_bf16(fprev, f);
+          if constexpr ((j & 1) == 0) {
+            const f32x4 b = nbr;
+            fph = __builtin_amdgcn_fractf(fmaf(x2, b[2], fmaf(x1, b[1], x0 * b[0])));
+            fprev = __builtin_amdgcn_sinf(fph);
+            if constexpr (q + 2 < 32)
+              enc_row(ch, q + 2, nbr);
+            else
+              enc_row(chn, q + 2 - 32, nbr);
+            asm volatile("" : "+v"(fprev));
+          } else {
+            unsigned d = pack_bf16(fprev, __builtin_amdgcn_cosf(fph));
             asm volatile("" : "+v"(d));
             dst[s][j >> 1] = d;
-          } else {
-            fprev = f;
-            asm volatile("" : "+v"(fprev));
           }
         };
         if (ACTIVE) {
 #pragma unroll
           for (int m = 0; m < 8; ++m) acc8[m] = zero16();
-          enc_row(0, 0, nb[0]);
-          enc_row(0, 1, nb[1]);
+          enc_row(0, 0, nbr);
           static_for<0, 4>([&](auto sc) { static_for<0, 8>([&](auto jc) { gen_value(0, nq0 > 1 ? 1 : 0, sc, jc, bq[0]); }); });
         }
         for (int ch = 0; ch < nq0; ch += 2) {  // an interval = two chunks (one at an odd tail); the B operand sets alternate

@@ -60,25 +60,10 @@ def _rev_cos(rev: Tensor) -> Tensor:
     return torch.cos((2.0 * np.pi) * rev.double()).float()
 
 
-def gauss_features_rev(coords: Tensor, enc_B: Tensor) -> Tensor:
-    """[B, 2E] encoder features (Positional_Encoder.embedding 'gauss', networks.py:30-33) as the kernels form them:
-    sin(2 pi frac(x . B_j)) and, for the cosine half, sin(2 pi frac(x . B_j + 1/4)), fp32 fma chain x0 -> x1 -> x2."""
-    x, Bm = coords.double(), enc_B.double()
-
-    def chain(q: float) -> Tensor:
-        t = torch.full((coords.shape[0], Bm.shape[0]), q, dtype=torch.float64)
-        for k in range(3):  # fmaf(x2, b2, fmaf(x1, b1, fmaf(x0, b0, quarter))): each fma rounds once, to fp32
-            t = (x[:, k:k + 1] * Bm[None, :, k] + t).float().double()
-        t = t.float()
-        return t - torch.floor(t)
-
-    return torch.cat([_rev_sin(chain(0.0)), _rev_sin(chain(0.25))], dim=1)
-
-
 def gauss_features_gemm(coords: Tensor, enc_B: Tensor) -> Tensor:
-    """The same features as the weight-gradient GEMM regenerates them (csrc/inr_dw_gemm_bf16.hip, first-layer units): one
-    phase chain per frequency, its sine and its COSINE (the forward pass starts a second chain at 1/4 turn for the cosine
-    half: equal to an ulp of the phase)."""
+    """[B, 2E] encoder features (Positional_Encoder.embedding 'gauss', networks.py:30-33) as both bf16 kernels form them
+    (csrc/inr_siren_bf16_impl.h layer 0; csrc/inr_dw_gemm_bf16.hip, first-layer units): one fp32 fma chain x0 -> x1 -> x2
+    per frequency, t = frac(x . B_j) in revolutions, then sin(2 pi t) and cos(2 pi t)."""
     x, Bm = coords.double(), enc_B.double()
     t = torch.zeros((coords.shape[0], Bm.shape[0]), dtype=torch.float64)
     for k in range(3):
@@ -110,7 +95,7 @@ def siren_bf16_step(sd: Dict[str, Tensor], coords: Tensor, enc_B: Tensor, net: d
     kr = np.float32(SIREN_W0) * INV_2PI_F32  # w0 / 2 pi as the packing kernel forms it (fp32 product)
     W = [sd[f"model.{k}.linear.weight"].float() for k in range(D)]
     b = [sd[f"model.{k}.linear.bias"].float() for k in range(D)]
-    feat32 = gauss_features_rev(coords, enc_B)
+    feat32 = gauss_features_gemm(coords, enc_B)  # (since round 4 the forward pass, too, takes sine and cosine from ONE chain)
     h = _bf16(feat32)
     P = []
     for l in range(D - 1):
